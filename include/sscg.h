@@ -1,0 +1,157 @@
+/*
+ * sscg.h - C ABI of libsscg.so: the MI355X (gfx950) kernels behind the CycleGAN training step of
+ * arnab39/Semi-supervised-segmentation-cycleGAN (model.py:370-552, `semisuper_cycleGAN.train`).
+ *
+ * The reference has no FFI of its own: every arithmetic op on its hot path is a stock torch.nn module
+ * (SURVEY.md section 8(b)).  Each entry point below therefore names the torch call site it replaces
+ * (reference file:line).  INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes, no torch types.  All tensors fp32, channels-last
+ *     (NHWC: [N][H][W][C]); conv weights [K][R][S][C] (= torch `[K,C,R,S]` in channels_last);
+ *     labels int64.
+ *   - `stream` is a hipStream_t passed as void*.  Calls are asynchronous and stream ordered, re-entrant,
+ *     allocate nothing and keep no mutable global state; scratch memory is caller provided (`ws`) and
+ *     sized by the matching *_workspace() query.
+ *   - return value: 0 = ok, <0 = library error (SSCG_ERR_*), >0 = hipError_t.  Never throws/aborts.
+ */
+#ifndef SSCG_H
+#define SSCG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSCG_ABI_VERSION 1
+
+#define SSCG_ERR_BAD_ARG (-1)
+#define SSCG_ERR_UNSUPPORTED (-2)
+#define SSCG_ERR_WORKSPACE (-3)
+
+/* activation codes (conv epilogue, norm apply) */
+#define SSCG_ACT_NONE 0
+#define SSCG_ACT_RELU 1  /* nn.ReLU            arch/ops.py:50,57 */
+#define SSCG_ACT_LRELU 2 /* nn.LeakyReLU(0.2)  arch/ops.py:44, arch/discriminators.py:46,71,74 */
+#define SSCG_ACT_TANH 3  /* nn.Tanh            arch/generators.py:91 */
+
+#define SSCG_PAD_ZEROS 0
+#define SSCG_PAD_REFLECT 1 /* nn.ReflectionPad2d folded into the conv loader: arch/ops.py:62,67; arch/generators.py:73,84,89 */
+
+int sscg_abi_version(void);
+
+/* ------------------------------------------------------------------ convolution (K1, K2, K5) */
+typedef struct sscg_conv_desc {
+    int32_t N, H, W, C; /* input  [N][H][W][C] */
+    int32_t K, R, S;    /* weight [K][R][S][C] */
+    int32_t P, Q;       /* output [N][P][Q][K];  P = (H + 2*pad - dil*(R-1) - 1)/stride + 1 */
+    int32_t stride, pad, dil;
+    int32_t pad_mode;   /* SSCG_PAD_* (reflect: forward and wgrad only) */
+    int32_t act;        /* fused epilogue activation of the forward */
+    float slope;        /* LeakyReLU slope */
+} sscg_conv_desc;
+
+/* nn.Conv2d forward: arch/ops.py:43,49,68; arch/generators.py:85,90,325,331,336,373,388,415;
+ * arch/discriminators.py:45,58,70-75.  y = act(conv(x, w) + bias); bias may be NULL. */
+int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* stream);
+
+/* Data gradient of the same conv (autograd of model.py:472,539), and nn.ConvTranspose2d forward
+ * (arch/ops.py:55-56): dx = act(dgrad(dy, wt) + bias).  `wt` = weight re-laid as [C][R][S][K]
+ * by sscg_weight_krsc_to_crsk.  bias NULL / act NONE for a pure gradient. */
+int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const float* wt, const float* bias, float* dx,
+                      int act, float slope, void* stream);
+
+/* Weight gradient: dw = beta*dw + wgrad(x, dy); dw is [K][R][S][C]. */
+size_t sscg_conv2d_wgrad_workspace(const sscg_conv_desc* d);
+int sscg_conv2d_wgrad(const sscg_conv_desc* d, const float* x, const float* dy, float* dw, float beta, void* ws,
+                      size_t ws_bytes, void* stream);
+
+int sscg_weight_krsc_to_crsk(const float* w, float* wt, int K, int RS, int C, void* stream);
+
+/* out[c] = beta*out[c] + sum_r x[r][c]  (bias gradient).  ws: sscg_colsum_workspace bytes. */
+size_t sscg_colsum_workspace(int64_t rows, int cols);
+int sscg_colsum(const float* x, float* out, int64_t rows, int cols, float beta, void* ws, size_t ws_bytes, void* stream);
+
+/* tuning/test hook: force the forward/dgrad tile configuration (-1 = heuristic) */
+int sscg_debug_set_conv_cfg(int cfg);
+
+/* ------------------------------------------------------------------ normalisation (K3, K4, K7)
+ * x is viewed as [G][L][C]: InstanceNorm2d (arch/ops.py:11: affine=False, no running stats) has G = N,
+ * L = H*W; BatchNorm2d (arch/generators.py:326-337,390,417; arch/ops.py:9) has G = 1, L = N*H*W.
+ * eps 1e-5, biased variance for normalisation, unbiased for running_var (torch semantics). */
+size_t sscg_norm_stats_workspace(int G, int64_t L, int C);
+/* mean[G][C], rstd[G][C]; if running_mean != NULL (G must be 1):
+ * running = (1-momentum)*running + momentum*batch (running_var from the unbiased batch variance). */
+int sscg_norm_stats(const float* x, int G, int64_t L, int C, float eps, float* mean, float* rstd,
+                    float* running_mean, float* running_var, float momentum, void* ws, size_t ws_bytes, void* stream);
+/* y = act((x-mean)*rstd*gamma + beta + residual); gamma/beta/residual nullable (gamma,beta are [C]). */
+int sscg_norm_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const float* residual, float* y, int G, int64_t L, int C, int act, float slope, void* stream);
+/* eval-mode BatchNorm: mean = running_mean, rstd = 1/sqrt(running_var + eps) */
+int sscg_rstd_from_var(const float* var, float* rstd, int n, float eps, void* stream);
+/* backward of norm_apply (+ of the statistics): dx always; dres (= masked dy) if non-NULL;
+ * dgamma/dbeta accumulate (+=) if non-NULL.  `y` (the forward output) supplies the activation mask.
+ * With stats_grad == 0 the statistics are treated as constants (eval-mode BN). */
+size_t sscg_norm_bwd_workspace(int G, int64_t L, int C);
+int sscg_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd,
+                  const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int G, int64_t L, int C,
+                  int act, float slope, int stats_grad, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ pointwise / pooling / resize */
+/* standalone activation (nn.ReLU / nn.LeakyReLU / nn.Tanh not adjacent to a norm) */
+int sscg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream);
+int sscg_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, void* stream);
+/* y = a + b */
+int sscg_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* nn.Dropout(0.5) in training mode (arch/ops.py:66): y = x * keep / (1-p); keep is derived from a
+ * counter-based hash of (seed, element index), so backward can regenerate it. */
+int sscg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* nn.MaxPool2d(3, 2, 1, ceil_mode=True) (arch/generators.py:394); idx = window position 0..8 of the first max */
+int sscg_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, int P, int Q, void* stream);
+int sscg_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, int P, int Q, void* stream);
+/* nn.Upsample(size, mode='bilinear', align_corners=True) (model.py:268, calls :390-392,:413-415) */
+int sscg_upsample_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, void* stream);
+int sscg_upsample_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, void* stream);
+/* nn.ReflectionPad2d as a materialised copy (only for callers that cannot fold it) */
+int sscg_reflect_pad(const float* x, float* y, int N, int H, int W, int C, int pad, void* stream);
+/* layout plumbing at the NCHW boundary of the reference's module interface */
+int sscg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
+int sscg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------ class-axis ops (K10, K12) : x is [rows][C] */
+/* nn.Softmax2d (model.py:273, calls :401-402,:420-421) */
+int sscg_softmax_fwd(const float* x, float* y, int64_t rows, int C, void* stream);
+int sscg_softmax_bwd(const float* dy, const float* y, float* dx, int64_t rows, int C, void* stream);
+/* fake_gt.data.max(1)[1] -> make_one_hot (model.py:435-437,:509-511; utils.py:344-348): first max wins */
+int sscg_argmax_onehot(const float* x, float* onehot, int64_t* index, int64_t rows, int C, void* stream);
+/* make_one_hot(labels) (utils.py:314-350) */
+int sscg_label_onehot(const int64_t* labels, float* onehot, int64_t rows, int C, void* stream);
+
+/* ------------------------------------------------------------------ losses (K10, K11), mean reduction
+ * Each forward writes one fp32 scalar to `loss` (device).  Each backward takes the upstream gradient as
+ * a device scalar `gscale` (NULL = 1) times the host factor `w`. */
+size_t sscg_loss_workspace(int64_t n);
+/* nn.CrossEntropyLoss (model.py:272; calls :398,:455): logits [rows][C], labels [rows] */
+int sscg_ce_fwd(const float* logits, const int64_t* labels, int64_t rows, int C, float* loss, void* ws, size_t ws_bytes, void* stream);
+int sscg_ce_bwd(const float* logits, const int64_t* labels, int64_t rows, int C, const float* gscale, float w, float* dx, void* stream);
+/* nn.MSELoss against a constant target map of ones/zeros (LSGAN; model.py:445-446,452,521-528) */
+int sscg_mse_const_fwd(const float* x, int64_t n, float target, float* loss, void* ws, size_t ws_bytes, void* stream);
+int sscg_mse_const_bwd(const float* x, int64_t n, float target, const float* gscale, float w, float* dx, void* stream);
+/* nn.L1Loss (model.py:271; call :461) */
+int sscg_l1_fwd(const float* a, const float* b, int64_t n, float* loss, void* ws, size_t ws_bytes, void* stream);
+int sscg_l1_bwd(const float* a, const float* b, int64_t n, const float* gscale, float w, float* da, void* stream);
+/* out = sum_i w[i] * (*terms[i]) for up to 8 device scalars (gen_loss / discriminator_loss, model.py:464-468,538) */
+int sscg_weighted_sum(const float* const* terms, const float* w, int n, float* out, void* stream);
+
+/* ------------------------------------------------------------------ optimiser (K14)
+ * torch.optim.Adam (model.py:286-287; steps :474,:542): eps 1e-8, no weight decay, no amsgrad.
+ * One launch over a flat arena; grad is multiplied by grad_scale first (1/world_size under data parallel). */
+int sscg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                   double beta2, double eps, int step, float grad_scale, void* stream);
+int sscg_fill(float* x, int64_t n, float v, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSCG_H */

@@ -1,0 +1,279 @@
+"""TEST INFRASTRUCTURE (see oracle/__init__.py) - functional CPU restatement of the reference networks.
+
+Every function takes a flat state dict (the reference's own state_dict keys, which are the checkpoint
+ABI - SURVEY 8(b)) and an input tensor, and evaluates the network with stock torch CPU ops in the
+dtype of the input (fp32 or fp64).  Each function cites the reference lines it restates.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as TF
+
+EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# --------------------------------------------------------------------------- specs (key -> (shape, kind))
+def _conv(spec, key, cout, cin, k, bias):
+    spec[key + ".weight"] = ((cout, cin, k, k), "conv")
+    if bias:
+        spec[key + ".bias"] = ((cout,), "bias")
+
+
+def _bn(spec, key, c):
+    spec[key + ".weight"] = ((c,), "bn_weight")
+    spec[key + ".bias"] = ((c,), "bn_bias")
+    spec[key + ".running_mean"] = ((c,), "running_mean")
+    spec[key + ".running_var"] = ((c,), "running_var")
+    spec[key + ".num_batches_tracked"] = ((), "nbt")
+
+
+DEEPLAB_LAYERS = ((64, 3, 1, 1), (128, 4, 2, 1), (256, 23, 1, 2), (512, 3, 1, 4))  # planes, blocks, stride, dilation
+
+
+def deeplab_spec(in_c, out_c):
+    """State-dict layout of define_Gen(netG='deeplab') = ResNet(Bottleneck, [3,4,23,3]) (arch/generators.py:384-441,510-511)."""
+    s = OrderedDict()
+    _conv(s, "conv1", 64, in_c, 7, False)
+    _bn(s, "bn1", 64)
+    inplanes = 64
+    for li, (planes, blocks, stride, dil) in enumerate(DEEPLAB_LAYERS, start=1):
+        for b in range(blocks):
+            p = "layer%d.%d" % (li, b)
+            _conv(s, p + ".conv1", planes, inplanes, 1, False)
+            _bn(s, p + ".bn1", planes)
+            _conv(s, p + ".conv2", planes, planes, 3, False)
+            _bn(s, p + ".bn2", planes)
+            _conv(s, p + ".conv3", planes * 4, planes, 1, False)
+            _bn(s, p + ".bn3", planes * 4)
+            if b == 0:  # generators.py:410-416: every first block has a downsample branch
+                _conv(s, p + ".downsample.0", planes * 4, inplanes, 1, False)
+                _bn(s, p + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    for i in range(4):  # four classifier convs exist; only the first two are ever used (generators.py:378-382)
+        _conv(s, "layer5.conv2d_list.%d" % i, out_c, 2048, 3, True)
+    return s
+
+
+def resnet_gen_spec(in_c, out_c, ngf=64, n_blocks=9, norm="instance"):
+    """ResnetGenerator (arch/generators.py:65-95).  With norm='instance' every conv has a bias and norms have no state."""
+    bias = norm == "instance"
+    s = OrderedDict()
+
+    def block(idx, cout, cin, k):
+        _conv(s, "res_model.%d.0" % idx, cout, cin, k, bias)
+        if norm == "batch":
+            _bn(s, "res_model.%d.1" % idx, cout)
+
+    block(1, ngf, in_c, 7)
+    block(2, ngf * 2, ngf, 3)
+    block(3, ngf * 4, ngf * 2, 3)
+    for b in range(n_blocks):
+        i = 4 + b
+        _conv(s, "res_model.%d.res_block.1.0" % i, ngf * 4, ngf * 4, 3, bias)
+        if norm == "batch":
+            _bn(s, "res_model.%d.res_block.1.1" % i, ngf * 4)
+        # without dropout the second conv sits at index 3, with dropout at 4 (arch/ops.py:62-70)
+    return s
+
+
+def resnet_gen_spec_full(in_c, out_c, ngf=64, n_blocks=9, norm="instance", use_dropout=True):
+    bias = norm == "instance"
+    s = OrderedDict()
+
+    def cnr(idx, cout, cin, k, transposed=False):
+        key = "res_model.%d.0" % idx
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        s[key + ".weight"] = (shape, "conv")
+        if bias:
+            s[key + ".bias"] = ((cout,), "bias")
+        if norm == "batch":
+            _bn(s, "res_model.%d.1" % idx, cout)
+
+    cnr(1, ngf, in_c, 7)
+    cnr(2, ngf * 2, ngf, 3)
+    cnr(3, ngf * 4, ngf * 2, 3)
+    second = 4 if use_dropout else 3
+    for b in range(n_blocks):
+        i = 4 + b
+        _conv(s, "res_model.%d.res_block.1.0" % i, ngf * 4, ngf * 4, 3, bias)
+        if norm == "batch":
+            _bn(s, "res_model.%d.res_block.1.1" % i, ngf * 4)
+        _conv(s, "res_model.%d.res_block.%d" % (i, second), ngf * 4, ngf * 4, 3, bias)
+        if norm == "batch":
+            _bn(s, "res_model.%d.res_block.%d" % (i, second + 1), ngf * 4)
+    t = 4 + n_blocks
+    cnr(t, ngf * 2, ngf * 4, 3, transposed=True)
+    cnr(t + 1, ngf, ngf * 2, 3, transposed=True)
+    _conv(s, "res_model.%d" % (t + 3), out_c, ngf, 7, True)
+    return s
+
+
+def pixel_dis_spec(in_c, ndf=64, norm="instance"):
+    """PixelDiscriminator (arch/discriminators.py:66-80)."""
+    bias = norm == "instance"
+    s = OrderedDict()
+    _conv(s, "dis_model.0", ndf, in_c, 1, True)
+    _conv(s, "dis_model.2", ndf * 2, ndf, 1, bias)
+    if norm == "batch":
+        _bn(s, "dis_model.3", ndf * 2)
+    _conv(s, "dis_model.5", 1, ndf * 2, 1, bias)
+    return s
+
+
+def nlayer_dis_spec(in_c, ndf=64, n_layers=3, norm="instance"):
+    """NLayerDiscriminator / 70x70 PatchGAN (arch/discriminators.py:42-63)."""
+    bias = norm == "instance"
+    s = OrderedDict()
+    _conv(s, "dis_model.0", ndf, in_c, 4, True)
+    mult = 1
+    idx = 2
+    for n in range(1, n_layers):
+        prev, mult = mult, min(2 ** n, 8)
+        _conv(s, "dis_model.%d.0" % idx, ndf * mult, ndf * prev, 4, bias)
+        if norm == "batch":
+            _bn(s, "dis_model.%d.1" % idx, ndf * mult)
+        idx += 1
+    prev, mult = mult, min(2 ** n_layers, 8)
+    _conv(s, "dis_model.%d.0" % idx, ndf * mult, ndf * prev, 4, bias)
+    if norm == "batch":
+        _bn(s, "dis_model.%d.1" % idx, ndf * mult)
+    idx += 1
+    _conv(s, "dis_model.%d" % idx, 1, ndf * mult, 4, True)
+    return s
+
+
+# --------------------------------------------------------------------------- building blocks
+def _bn_apply(sd, key, x, train):
+    """nn.BatchNorm2d: batch statistics + running-stat EMA in train mode (running tensors updated in place)."""
+    rm, rv = sd[key + ".running_mean"], sd[key + ".running_var"]
+    y = TF.batch_norm(x, rm, rv, sd[key + ".weight"], sd[key + ".bias"], train, BN_MOMENTUM, EPS)
+    if train:
+        sd[key + ".num_batches_tracked"] += 1
+    return y
+
+
+def _norm(sd, key, x, norm, train):
+    if norm == "instance":  # arch/ops.py:11 (affine=False, track_running_stats=False)
+        return TF.instance_norm(x, eps=EPS)
+    return _bn_apply(sd, key, x, train)
+
+
+def bottleneck(sd, p, x, stride, dil, train):
+    """Bottleneck.forward (arch/generators.py:345-365)."""
+    out = TF.conv2d(x, sd[p + ".conv1.weight"], None, stride)
+    out = torch.relu(_bn_apply(sd, p + ".bn1", out, train))
+    out = TF.conv2d(out, sd[p + ".conv2.weight"], None, 1, dil, dil)
+    out = torch.relu(_bn_apply(sd, p + ".bn2", out, train))
+    out = TF.conv2d(out, sd[p + ".conv3.weight"])
+    out = _bn_apply(sd, p + ".bn3", out, train)
+    if (p + ".downsample.0.weight") in sd:
+        res = TF.conv2d(x, sd[p + ".downsample.0.weight"], None, stride)
+        res = _bn_apply(sd, p + ".downsample.1", res, train)
+    else:
+        res = x
+    return torch.relu(out + res)
+
+
+def deeplab(sd, x, train=True, taps=None):
+    """ResNet.forward (arch/generators.py:430-441) incl. the two-of-four classifier quirk (:378-382).
+    `taps` (optional dict) receives the stage outputs for teacher-forced per-stage checks."""
+    y = TF.conv2d(x, sd["conv1.weight"], None, 2, 3)
+    y = torch.relu(_bn_apply(sd, "bn1", y, train))
+    y = TF.max_pool2d(y, 3, 2, 1, ceil_mode=True)
+    if taps is not None:
+        taps["stem"] = y
+    for li, (planes, blocks, stride, dil) in enumerate(DEEPLAB_LAYERS, start=1):
+        for b in range(blocks):
+            y = bottleneck(sd, "layer%d.%d" % (li, b), y, stride if b == 0 else 1, dil, train)
+        if taps is not None:
+            taps["layer%d" % li] = y
+    out = TF.conv2d(y, sd["layer5.conv2d_list.0.weight"], sd["layer5.conv2d_list.0.bias"], 1, 6, 6)
+    out = out + TF.conv2d(y, sd["layer5.conv2d_list.1.weight"], sd["layer5.conv2d_list.1.bias"], 1, 12, 12)
+    return out
+
+
+def deeplab_stage(sd, name, x, train=True):
+    """One stage of `deeplab` on a given stage input (teacher forcing)."""
+    if name == "stem":
+        y = TF.conv2d(x, sd["conv1.weight"], None, 2, 3)
+        y = torch.relu(_bn_apply(sd, "bn1", y, train))
+        return TF.max_pool2d(y, 3, 2, 1, ceil_mode=True)
+    if name == "layer5":
+        out = TF.conv2d(x, sd["layer5.conv2d_list.0.weight"], sd["layer5.conv2d_list.0.bias"], 1, 6, 6)
+        return out + TF.conv2d(x, sd["layer5.conv2d_list.1.weight"], sd["layer5.conv2d_list.1.bias"], 1, 12, 12)
+    li = int(name[-1])
+    planes, blocks, stride, dil = DEEPLAB_LAYERS[li - 1]
+    y = x
+    for b in range(blocks):
+        y = bottleneck(sd, "layer%d.%d" % (li, b), y, stride if b == 0 else 1, dil, train)
+    return y
+
+
+def resnet_generator(sd, x, n_blocks=9, tanh=True, norm="instance", use_dropout=True, train=True, dropout_masks=None):
+    """ResnetGenerator.forward (arch/generators.py:73-95) with ResidualBlock (arch/ops.py:59-74).
+
+    Dropout(0.5) is active whenever use_dropout (the frozen generators are never put in eval mode,
+    SURVEY App. A).  `dropout_masks` is a list of keep-masks (already scaled by 2) - one per block;
+    None with use_dropout=True draws from torch's RNG like the reference."""
+    def cnr(idx, y, stride, pad):
+        y = TF.conv2d(y, sd["res_model.%d.0.weight" % idx], sd.get("res_model.%d.0.bias" % idx), stride, pad)
+        return torch.relu(_norm(sd, "res_model.%d.1" % idx, y, norm, train))
+
+    y = TF.pad(x, (3, 3, 3, 3), mode="reflect")
+    y = cnr(1, y, 1, 0)
+    y = cnr(2, y, 2, 1)
+    y = cnr(3, y, 2, 1)
+    second = 4 if use_dropout else 3
+    for b in range(n_blocks):
+        i = 4 + b
+        pre = "res_model.%d.res_block." % i
+        h = TF.pad(y, (1, 1, 1, 1), mode="reflect")
+        h = TF.conv2d(h, sd[pre + "1.0.weight"], sd.get(pre + "1.0.bias"))
+        h = torch.relu(_norm(sd, pre + "1.1", h, norm, train))
+        if use_dropout:
+            if dropout_masks is not None:
+                h = h * dropout_masks[b]
+            else:
+                h = TF.dropout(h, 0.5, True)
+        h = TF.pad(h, (1, 1, 1, 1), mode="reflect")
+        h = TF.conv2d(h, sd[pre + "%d.weight" % second], sd.get(pre + "%d.bias" % second))
+        h = _norm(sd, pre + "%d" % (second + 1), h, norm, train)
+        y = y + h
+    t = 4 + n_blocks
+    for idx in (t, t + 1):
+        y = TF.conv_transpose2d(y, sd["res_model.%d.0.weight" % idx], sd.get("res_model.%d.0.bias" % idx), 2, 1, 1)
+        y = torch.relu(_norm(sd, "res_model.%d.1" % idx, y, norm, train))
+    y = TF.pad(y, (3, 3, 3, 3), mode="reflect")
+    y = TF.conv2d(y, sd["res_model.%d.weight" % (t + 3)], sd["res_model.%d.bias" % (t + 3)])
+    return torch.tanh(y) if tanh else y
+
+
+def pixel_discriminator(sd, x, norm="instance", train=True):
+    """PixelDiscriminator.forward (arch/discriminators.py:66-80)."""
+    y = TF.leaky_relu(TF.conv2d(x, sd["dis_model.0.weight"], sd["dis_model.0.bias"]), 0.2)
+    y = TF.conv2d(y, sd["dis_model.2.weight"], sd.get("dis_model.2.bias"))
+    y = TF.leaky_relu(_norm(sd, "dis_model.3", y, norm, train), 0.2)
+    return TF.conv2d(y, sd["dis_model.5.weight"], sd.get("dis_model.5.bias"))
+
+
+def nlayer_discriminator(sd, x, n_layers=3, norm="instance", train=True):
+    """NLayerDiscriminator.forward (arch/discriminators.py:42-63)."""
+    y = TF.leaky_relu(TF.conv2d(x, sd["dis_model.0.weight"], sd["dis_model.0.bias"], 2, 1), 0.2)
+    idx = 2
+    for n in range(1, n_layers + 1):
+        stride = 2 if n < n_layers else 1
+        y = TF.conv2d(y, sd["dis_model.%d.0.weight" % idx], sd.get("dis_model.%d.0.bias" % idx), stride, 1)
+        y = TF.leaky_relu(_norm(sd, "dis_model.%d.1" % idx, y, norm, train), 0.2)
+        idx += 1
+    return TF.conv2d(y, sd["dis_model.%d.weight" % idx], sd["dis_model.%d.bias" % idx], 1, 1)
+
+
+# block-level restatements of arch/ops.py:40-57 (used by the block goldens)
+def conv_norm_act(w, b, x, stride, pad, norm, act, slope=0.2, transposed=False, out_pad=0):
+    if transposed:
+        y = TF.conv_transpose2d(x, w, b, stride, pad, out_pad)
+    else:
+        y = TF.conv2d(x, w, b, stride, pad)
+    y = TF.instance_norm(y, eps=EPS) if norm == "instance" else y
+    return torch.relu(y) if act == "relu" else TF.leaky_relu(y, slope)

@@ -1,0 +1,110 @@
+"""ctypes binding of libsscg.so (the C ABI declared in include/sscg.h).
+
+The library is the product: there is no Python/torch fallback for any kernel.  If the shared object
+is missing or does not export a declared symbol, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsscg.so")
+
+ABI_VERSION = 1
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZEROS, PAD_REFLECT = 0, 1
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `sscg_conv_desc` (include/sscg.h)."""
+
+    _fields_ = [
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("K", C.c_int32), ("R", C.c_int32), ("S", C.c_int32),
+        ("P", C.c_int32), ("Q", C.c_int32),
+        ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
+        ("pad_mode", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
+    ]
+
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_f = C.c_float
+_sz = C.c_size_t
+_dp = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every symbol of include/sscg.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "sscg_abi_version": (_i, []),
+    "sscg_conv2d_fwd": (_i, [_dp, _p, _p, _p, _p, _p]),
+    "sscg_conv2d_dgrad": (_i, [_dp, _p, _p, _p, _p, _i, _f, _p]),
+    "sscg_conv2d_wgrad_workspace": (_sz, [_dp]),
+    "sscg_conv2d_wgrad": (_i, [_dp, _p, _p, _p, _f, _p, _sz, _p]),
+    "sscg_weight_krsc_to_crsk": (_i, [_p, _p, _i, _i, _i, _p]),
+    "sscg_colsum_workspace": (_sz, [_i64, _i]),
+    "sscg_colsum": (_i, [_p, _p, _i64, _i, _f, _p, _sz, _p]),
+    "sscg_debug_set_conv_cfg": (_i, [_i]),
+    "sscg_norm_stats_workspace": (_sz, [_i, _i64, _i]),
+    "sscg_norm_stats": (_i, [_p, _i, _i64, _i, _f, _p, _p, _p, _p, _f, _p, _sz, _p]),
+    "sscg_norm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _f, _p]),
+    "sscg_rstd_from_var": (_i, [_p, _p, _i, _f, _p]),
+    "sscg_norm_bwd_workspace": (_sz, [_i, _i64, _i]),
+    "sscg_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
+    "sscg_act_fwd": (_i, [_p, _p, _i64, _i, _f, _p]),
+    "sscg_act_bwd": (_i, [_p, _p, _p, _i64, _i, _f, _p]),
+    "sscg_add": (_i, [_p, _p, _p, _i64, _p]),
+    "sscg_dropout": (_i, [_p, _p, _i64, _f, C.c_uint64, _p]),
+    "sscg_maxpool3x3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "sscg_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "sscg_upsample_bilinear_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "sscg_upsample_bilinear_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "sscg_reflect_pad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "sscg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "sscg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "sscg_softmax_fwd": (_i, [_p, _p, _i64, _i, _p]),
+    "sscg_softmax_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "sscg_argmax_onehot": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "sscg_label_onehot": (_i, [_p, _p, _i64, _i, _p]),
+    "sscg_loss_workspace": (_sz, [_i64]),
+    "sscg_ce_fwd": (_i, [_p, _p, _i64, _i, _p, _p, _sz, _p]),
+    "sscg_ce_bwd": (_i, [_p, _p, _i64, _i, _p, _f, _p, _p]),
+    "sscg_mse_const_fwd": (_i, [_p, _i64, _f, _p, _p, _sz, _p]),
+    "sscg_mse_const_bwd": (_i, [_p, _i64, _f, _p, _f, _p, _p]),
+    "sscg_l1_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
+    "sscg_l1_bwd": (_i, [_p, _p, _i64, _p, _f, _p, _p]),
+    "sscg_weighted_sum": (_i, [C.POINTER(_p), C.POINTER(_f), _i, _p, _p]),
+    "sscg_adam_step": (_i, [_p, _p, _p, _p, _i64, C.c_double, C.c_double, C.c_double, C.c_double, _i, _f, _p]),
+    "sscg_fill": (_i, [_p, _i64, _f, _p]),
+}
+
+
+class SscgError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libsscg.so not found at %s - build it with `make -C %s/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no fallback path." % (LIB_PATH, _HERE))
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.sscg_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError("libsscg.so ABI version %d != binding version %d" % (v, ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+_ERRS = {-1: "SSCG_ERR_BAD_ARG", -2: "SSCG_ERR_UNSUPPORTED", -3: "SSCG_ERR_WORKSPACE"}
+
+
+def check(rc, what):
+    """Raise on a non-zero return code of an int-returning entry point."""
+    if rc != 0:
+        raise SscgError("%s failed: %s" % (what, _ERRS.get(rc, "hipError_t %d" % rc)))

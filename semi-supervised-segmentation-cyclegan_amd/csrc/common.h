@@ -1,0 +1,65 @@
+// Shared device/host helpers for the sscg HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SSCG_OK 0
+#define SSCG_ERR_BAD_ARG (-1)
+#define SSCG_ERR_UNSUPPORTED (-2)
+#define SSCG_ERR_WORKSPACE (-3)
+
+// Every entry point returns 0 or a negative library code / positive hipError_t.
+#define SSCG_LAUNCH_CHECK()                        \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+// Activation codes shared by conv epilogues and norm kernels.
+enum { SSCG_ACT_NONE = 0, SSCG_ACT_RELU = 1, SSCG_ACT_LRELU = 2, SSCG_ACT_TANH = 3 };
+
+__device__ __forceinline__ float sscg_act(float v, int act, float slope) {
+    if (act == SSCG_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == SSCG_ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == SSCG_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// Division by a runtime-invariant divisor (dividend < 2^31).
+struct FastDiv {
+    uint32_t mul;
+    uint32_t shift;
+    int32_t d;
+};
+
+static inline FastDiv make_fastdiv(int d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while ((1u << l) < (uint32_t)d) ++l;
+    f.shift = l;
+    f.mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - (uint64_t)d)) / (uint64_t)d + 1);
+    return f;
+}
+
+__device__ __forceinline__ int fd_div(int n, const FastDiv& f) {
+    return (int)((__umulhi((uint32_t)n, f.mul) + (uint32_t)n) >> f.shift);
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// wave64 all-lane sum (double) through ds_bpermute-free shuffles
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

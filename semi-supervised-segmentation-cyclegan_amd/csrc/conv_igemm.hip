@@ -1,0 +1,395 @@
+// Implicit-GEMM convolution for NHWC fp32 tensors on CDNA4 (gfx950) matrix cores.
+//
+// One kernel family ("KC": both GEMM operands are K-contiguous in HBM) serves
+//   * Conv2d forward            (reference call sites: arch/ops.py:43,49,68; arch/generators.py:325,331,336,373,388)
+//   * Conv2d data-gradient      (autograd of the above; gather form, no atomics)
+//   * ConvTranspose2d forward   (arch/ops.py:55-56) == data-gradient of the mirrored conv
+//
+// GEMM view:  D[m][n] = sum_k A[m][k] * B[n][k]
+//   m  = output pixel (n_img, oy, ox)      n = output channel       k = (tap, source channel)
+//   A is gathered on the fly from the NHWC source (zero / reflection padding, stride, dilation
+//   are index arithmetic in the tile loader - no im2col buffer, no padded copy);
+//   B is the weight tensor in its physical [Cout][kh][kw][Cin] order (K-contiguous rows).
+//
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles/issue/SIMD).  Each wave owns
+// TM x TN accumulators of 32x32; a 256-thread workgroup is WM x WN waves.
+// LDS image of both operands is [row][BK + 4] (row = m or n, k contiguous, +4 floats of pad so that
+// ds_read_b128 fragment reads are bank-conflict free).  A lane (i = lane & 31, h = lane >> 5) reads
+// four consecutive k of row i at k-offset h*4 with one ds_read_b128 and feeds them to four MFMAs:
+// the k -> (instruction, half) assignment is a permutation applied identically to A and B, which
+// a reduction does not care about.
+#include "common.h"
+#include "sscg_internal.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct KcParams {
+    const float* __restrict__ src;   // A source (input for fwd, dy for dgrad)
+    const float* __restrict__ wgt;   // [Ng][Ktot]
+    const float* __restrict__ bias;  // [Ng] or null
+    float* __restrict__ dst;         // [M][Ng]
+    int M, Ng, Ktot, Cs;
+    int SH, SW;   // source spatial
+    int OH, OW;   // destination spatial (row decode)
+    int R, S;
+    int stride, pad, dil;
+    int pad_mode;
+    int act;
+    float slope;
+    int tiles_n;
+};
+
+template <int MODE, int WM, int WN, int TM, int TN, int VEC>
+__global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    // loader geometry
+    constexpr int KQ = BK / VEC;          // threads along k
+    constexpr int RPP = 256 / KQ;         // rows per pass
+    constexpr int PA = BM / RPP;          // passes for A
+    constexpr int PB = BN / RPP;          // passes for B
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* As = reinterpret_cast<float*>(smem_raw);                 // [2][BM][LDK]
+    float* Bs = As + 2 * BM * LDK;                                  // [2][BN][LDK]
+    int* rowinfo = reinterpret_cast<int*>(Bs + 2 * BN * LDK);       // [BM][4]: pixbase, y0, x0, valid
+    int* tapinfo = rowinfo + BM * 4;                                // [R*S]: (dy << 16) | dx
+
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int tile_n = tile % p.tiles_n;
+    const int tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    for (int r = tid; r < BM; r += 256) {
+        int m = m0 + r;
+        int4 info;
+        if (m < p.M) {
+            int img = m / (p.OH * p.OW);
+            int rem = m - img * (p.OH * p.OW);
+            int oy = rem / p.OW;
+            int ox = rem - oy * p.OW;
+            info.x = img * p.SH * p.SW;
+            if (MODE == MODE_FWD) {
+                info.y = oy * p.stride - p.pad;
+                info.z = ox * p.stride - p.pad;
+            } else {
+                info.y = oy + p.pad;
+                info.z = ox + p.pad;
+            }
+            info.w = 1;
+        } else {
+            info.x = 0; info.y = 0; info.z = 0; info.w = 0;
+        }
+        reinterpret_cast<int4*>(rowinfo)[r] = info;
+    }
+    for (int t = tid; t < p.R * p.S; t += 256) {
+        int ky = t / p.S;
+        int kx = t - ky * p.S;
+        tapinfo[t] = ((ky * p.dil) << 16) | (kx * p.dil);
+    }
+    __syncthreads();
+
+    const int kq = tid % KQ;
+    const int r0 = tid / KQ;
+
+    float ra[PA][VEC];
+    float rb[PB][VEC];
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kq * VEC;
+        const bool kvalid = k < p.Ktot;
+        int tap = 0, ci = 0, tdy = 0, tdx = 0;
+        if (kvalid) {
+            tap = k / p.Cs;
+            ci = k - tap * p.Cs;
+            int ti = tapinfo[tap];
+            tdy = ti >> 16;
+            tdx = ti & 0xffff;
+        }
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            const int r = r0 + ps * RPP;
+            int4 info = reinterpret_cast<const int4*>(rowinfo)[r];
+            bool ok = kvalid && info.w;
+            int sy, sx;
+            if (MODE == MODE_FWD) {
+                sy = info.y + tdy;
+                sx = info.z + tdx;
+                if (p.pad_mode == 1) {
+                    sy = sy < 0 ? -sy : sy;
+                    sx = sx < 0 ? -sx : sx;
+                    sy = sy >= p.SH ? 2 * (p.SH - 1) - sy : sy;
+                    sx = sx >= p.SW ? 2 * (p.SW - 1) - sx : sx;
+                }
+            } else {
+                int ty = info.y - tdy;
+                int tx = info.z - tdx;
+                if (p.stride == 1) {
+                    sy = ty; sx = tx;
+                } else {
+                    sy = ty / p.stride;
+                    sx = tx / p.stride;
+                    ok = ok && (ty >= 0) && (tx >= 0) && (sy * p.stride == ty) && (sx * p.stride == tx);
+                }
+            }
+            ok = ok && ((unsigned)sy < (unsigned)p.SH) && ((unsigned)sx < (unsigned)p.SW);
+            if (ok) {
+                const float* g = p.src + ((size_t)(info.x + sy * p.SW + sx) * p.Cs + ci);
+                if constexpr (VEC == 4) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra[ps][e] = v[e];
+                } else {
+                    ra[ps][0] = *g;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) ra[ps][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) {
+            const int n = n0 + r0 + ps * RPP;
+            if (kvalid && n < p.Ng) {
+                const float* g = p.wgt + ((size_t)n * p.Ktot + k);
+                if constexpr (VEC == 4) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[ps][e] = v[e];
+                } else {
+                    rb[ps][0] = *g;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) rb[ps][e] = 0.f;
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * LDK;
+        float* b = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            float* d = a + (r0 + ps * RPP) * LDK + kq * VEC;
+            if constexpr (VEC == 4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ra[ps][e];
+                *reinterpret_cast<f32x4*>(d) = v;
+            } else {
+                *d = ra[ps][0];
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) {
+            float* d = b + (r0 + ps * RPP) * LDK + kq * VEC;
+            if constexpr (VEC == 4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rb[ps][e];
+                *reinterpret_cast<f32x4*>(d) = v;
+            } else {
+                *d = rb[ps][0];
+            }
+        }
+    };
+
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int row_w = wm * TM * 32;
+    const int col_w = wn * TN * 32;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (p.Ktot + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* a = As + buf * BM * LDK + (row_w + li) * LDK + lh * 4;
+        const float* b = Bs + buf * BN * LDK + (col_w + li) * LDK + lh * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + col_w + j * 32 + li;
+        if (n >= p.Ng) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.M) p.dst[(size_t)m * p.Ng + n] = sscg_act(acc[i][j][e] + bv, p.act, p.slope);
+            }
+        }
+    }
+}
+
+template <int MODE, int WM, int WN, int TM, int TN, int VEC>
+int launch_kc(const KcParams& p0, hipStream_t st) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    KcParams p = p0;
+    p.tiles_n = cdiv(p.Ng, BN);
+    int tiles_m = cdiv(p.M, BM);
+    size_t smem = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (size_t)BM * 16 + (size_t)p.R * p.S * 4;
+    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+// Tile choice: biggest tile that still gives the chip ~2 workgroups per CU; narrow-N tile for
+// heads with a handful of output channels.
+template <int MODE, int VEC>
+int dispatch_kc(const KcParams& p, hipStream_t st, int force_cfg) {
+    auto wgs = [&](int bm, int bn) { return (long)cdiv(p.M, bm) * cdiv(p.Ng, bn); };
+    int cfg = force_cfg;
+    if (cfg < 0) {
+        if (p.Ng <= 32) cfg = 4;
+        else if (wgs(128, 128) >= 512) cfg = 0;
+        else if (p.Ng <= 64 && wgs(128, 64) >= 384) cfg = 1;
+        else if (wgs(64, 128) >= 512) cfg = 2;
+        else if (wgs(128, 64) >= 512) cfg = 1;
+        else cfg = 3;
+    }
+    switch (cfg) {
+        case 0: return launch_kc<MODE, 2, 2, 2, 2, VEC>(p, st);
+        case 1: return launch_kc<MODE, 2, 2, 2, 1, VEC>(p, st);
+        case 2: return launch_kc<MODE, 2, 2, 1, 2, VEC>(p, st);
+        case 3: return launch_kc<MODE, 2, 2, 1, 1, VEC>(p, st);
+        case 4: return launch_kc<MODE, 4, 1, 1, 1, VEC>(p, st);
+        default: return SSCG_ERR_BAD_ARG;
+    }
+}
+
+}  // namespace
+
+int sscg_force_conv_cfg = -1;  // test/tuning hook (sscg_debug_set_conv_cfg)
+
+extern "C" int sscg_debug_set_conv_cfg(int cfg) {
+    sscg_force_conv_cfg = cfg;
+    return SSCG_OK;
+}
+
+static int check_desc(const sscg_conv_desc* d) {
+    if (!d) return SSCG_ERR_BAD_ARG;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0) return SSCG_ERR_BAD_ARG;
+    if (d->stride <= 0 || d->dil <= 0 || d->pad < 0) return SSCG_ERR_BAD_ARG;
+    int P = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
+    int Q = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
+    if (P != d->P || Q != d->Q) return SSCG_ERR_BAD_ARG;
+    if (d->pad_mode == 1 && (d->pad >= d->H || d->pad >= d->W)) return SSCG_ERR_BAD_ARG;
+    if ((long)d->N * d->H * d->W * (long)d->C >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
+    if ((long)d->N * d->P * d->Q * (long)d->K >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
+    return SSCG_OK;
+}
+
+extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const float* w, const float* bias,
+                               float* y, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y) return SSCG_ERR_BAD_ARG;
+    KcParams p;
+    p.src = x; p.wgt = w; p.bias = bias; p.dst = y;
+    p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Cs = d->C; p.Ktot = d->R * d->S * d->C;
+    p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope; p.tiles_n = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->C % 4 == 0) return dispatch_kc<MODE_FWD, 4>(p, st, sscg_force_conv_cfg);
+    return dispatch_kc<MODE_FWD, 1>(p, st, sscg_force_conv_cfg);
+}
+
+// Data gradient (and ConvTranspose2d forward): dx[n][iy][ix][c] = sum_{ky,kx,k} dy[n][oy][ox][k] * wt[c][ky][kx][k]
+// with oy*stride = iy + pad - ky*dil.  `wt` is the weight re-laid as [C][R][S][K] (sscg_weight_krsc_to_crsk).
+// Zero padding only: reflection padding is used by the reference exclusively inside the frozen
+// generators (arch/generators.py:73,84,89 via model.py:225-228), which never see a backward pass;
+// the Python layer materialises the pad for any other caller.
+extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const float* wt, const float* bias,
+                                 float* dx, int act, float slope, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dy || !wt || !dx) return SSCG_ERR_BAD_ARG;
+    if (d->pad_mode != 0) return SSCG_ERR_UNSUPPORTED;
+    KcParams p;
+    p.src = dy; p.wgt = wt; p.bias = bias; p.dst = dx;
+    p.M = d->N * d->H * d->W; p.Ng = d->C; p.Cs = d->K; p.Ktot = d->R * d->S * d->K;
+    p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.pad_mode = 0; p.act = act; p.slope = slope; p.tiles_n = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->K % 4 == 0) return dispatch_kc<MODE_DGRAD, 4>(p, st, sscg_force_conv_cfg);
+    return dispatch_kc<MODE_DGRAD, 1>(p, st, sscg_force_conv_cfg);
+}
+
+// [K][RS][C] -> [C][RS][K] (weights are a few MB; one pass per optimiser step per conv that needs dgrad)
+__global__ void krsc_to_crsk_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int RS, int C) {
+    __shared__ float t[32][33];
+    const int rs = blockIdx.z;
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int k = k0 + r, c = c0 + tx;
+        t[r][tx] = (k < K && c < C) ? w[((size_t)k * RS + rs) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int c = c0 + r, k = k0 + tx;
+        if (k < K && c < C) wt[((size_t)c * RS + rs) * K + k] = t[tx][r];
+    }
+}
+
+extern "C" int sscg_weight_krsc_to_crsk(const float* w, float* wt, int K, int RS, int C, void* stream) {
+    if (!w || !wt || K <= 0 || RS <= 0 || C <= 0) return SSCG_ERR_BAD_ARG;
+    dim3 grid(cdiv(C, 32), cdiv(K, 32), RS);
+    hipLaunchKernelGGL(krsc_to_crsk_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, K, RS, C);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}

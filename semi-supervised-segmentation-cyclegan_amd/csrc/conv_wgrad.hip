@@ -1,0 +1,349 @@
+// Weight gradient of Conv2d for NHWC fp32 tensors on gfx950 matrix cores.
+//
+//   dW[k][ky][kx][c] = sum_{n,oy,ox} dy[n][oy][ox][k] * x[n][oy*s - pad + ky*dil][ox*s - pad + kx*dil][c]
+//
+// (autograd of the convolutions at arch/generators.py:325-336,373,388 and arch/discriminators.py:70-75
+//  that model.py:472,539 triggers via gen_loss.backward() / discriminator_loss.backward().)
+//
+// GEMM view: D[m][n] = sum_p A[p][m] * B[p][n],  m = output channel k, n = (tap, c), p = output pixel.
+// Both operands are contiguous along their M/N index in HBM (channels last), strided along the
+// reduction index p ("MC" operands): the LDS image is [p][m] / [p][n]; fragment reads are
+// ds_read_b32 with lane -> consecutive m (conflict free), lane half -> p parity.
+// The reduction (N*P*Q pixels) is long and the output (K x R*S*C) small, so the pixel range is split
+// across workgroups; partial tiles go to a caller-provided workspace and a second kernel reduces them
+// in a fixed order (deterministic: no atomics).
+#include "common.h"
+#include "sscg_internal.h"
+
+namespace {
+
+constexpr int BKP = 32;  // pixels per k-step
+
+struct WgParams {
+    const float* __restrict__ x;
+    const float* __restrict__ dy;
+    float* __restrict__ out;  // dw (splits == 1) or workspace [splits][Kc][Ng]
+    int Kc;                   // output channels (GEMM M)
+    int Ng;                   // R*S*C (GEMM N)
+    int C;
+    int H, W, P, Q;
+    int S;                    // kernel width (tap decode)
+    int stride, pad, dil, pad_mode;
+    int npix;                 // N*P*Q
+    int chunk;                // pixels per split (multiple of BKP)
+    int tiles_n;
+    float beta;               // applied only when splits == 1
+    FastDiv div_pq, div_q;
+};
+
+template <int WM, int WN, int TM, int TN, int VA, int VB>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int LDA = BM + 4;
+    constexpr int LDB = BN + 4;
+    constexpr int CA = BM / VA;          // threads per A row
+    constexpr int CB = BN / VB;
+    constexpr int RA = 256 / CA;         // rows per pass
+    constexpr int RB = 256 / CB;
+    constexpr int PA = BKP / RA;
+    constexpr int PB = BKP / RB;
+    static_assert(256 % CA == 0 && 256 % CB == 0 && BKP % RA == 0 && BKP % RB == 0, "loader geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* As = reinterpret_cast<float*>(smem_raw);  // [2][BKP][LDA]
+    float* Bs = As + 2 * BKP * LDA;                  // [2][BKP][LDB]
+
+    const int tid = threadIdx.x;
+    const int tile_n = blockIdx.x % p.tiles_n;
+    const int tile_m = blockIdx.x / p.tiles_n;
+    const int split = blockIdx.y;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int p_begin = split * p.chunk;
+    const int p_end = min(p.npix, p_begin + p.chunk);
+
+    // A loader: fixed column group per thread
+    const int ca = tid % CA, ra0 = tid / CA;
+    const int ma = m0 + ca * VA;
+    const bool a_col_ok = ma < p.Kc;
+    // B loader: fixed column group -> fixed (tap, c)
+    const int cb = tid % CB, rb0 = tid / CB;
+    const int nb = n0 + cb * VB;
+    const bool b_col_ok = nb < p.Ng;
+    int tdy = 0, tdx = 0, cch = 0;
+    if (b_col_ok) {
+        int tap = nb / p.C;
+        cch = nb - tap * p.C;
+        int ky = tap / p.S;
+        int kx = tap - ky * p.S;
+        tdy = ky * p.dil - p.pad;
+        tdx = kx * p.dil - p.pad;
+    }
+
+    float ra[PA][VA];
+    float rb[PB][VB];
+
+    auto load_tile = [&](int pt) {
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            const int pix = pt + ra0 + ps * RA;
+            if (a_col_ok && pix < p_end) {
+                const float* g = p.dy + ((size_t)pix * p.Kc + ma);
+                if constexpr (VA == 4) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra[ps][e] = v[e];
+                } else {
+                    ra[ps][0] = *g;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VA; ++e) ra[ps][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) {
+            const int pix = pt + rb0 + ps * RB;
+            bool ok = b_col_ok && pix < p_end;
+            int img = 0, sy = 0, sx = 0;
+            if (ok) {
+                img = fd_div(pix, p.div_pq);
+                int rem = pix - img * (p.P * p.Q);
+                int oy = fd_div(rem, p.div_q);
+                int ox = rem - oy * p.Q;
+                sy = oy * p.stride + tdy;
+                sx = ox * p.stride + tdx;
+                if (p.pad_mode == 1) {
+                    sy = sy < 0 ? -sy : sy;
+                    sx = sx < 0 ? -sx : sx;
+                    sy = sy >= p.H ? 2 * (p.H - 1) - sy : sy;
+                    sx = sx >= p.W ? 2 * (p.W - 1) - sx : sx;
+                }
+                ok = ((unsigned)sy < (unsigned)p.H) && ((unsigned)sx < (unsigned)p.W);
+            }
+            if (ok) {
+                const float* g = p.x + ((size_t)((img * p.H + sy) * p.W + sx) * p.C + cch);
+                if constexpr (VB == 4) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[ps][e] = v[e];
+                } else {
+                    rb[ps][0] = *g;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VB; ++e) rb[ps][e] = 0.f;
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BKP * LDA;
+        float* b = Bs + buf * BKP * LDB;
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            float* d = a + (ra0 + ps * RA) * LDA + ca * VA;
+            if constexpr (VA == 4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ra[ps][e];
+                *reinterpret_cast<f32x4*>(d) = v;
+            } else {
+                *d = ra[ps][0];
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) {
+            float* d = b + (rb0 + ps * RB) * LDB + cb * VB;
+            if constexpr (VB == 4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rb[ps][e];
+                *reinterpret_cast<f32x4*>(d) = v;
+            } else {
+                *d = rb[ps][0];
+            }
+        }
+    };
+
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int row_w = wm * TM * 32;
+    const int col_w = wn * TN * 32;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nsteps = (p_end - p_begin + BKP - 1) / BKP;
+    if (nsteps > 0) {
+        load_tile(p_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nsteps; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nsteps) load_tile(p_begin + (it + 1) * BKP);
+        const float* a = As + buf * BKP * LDA + lh * LDA + row_w + li;
+        const float* b = Bs + buf * BKP * LDB + lh * LDB + col_w + li;
+#pragma unroll
+        for (int kp = 0; kp < BKP / 2; ++kp) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = a[kp * 2 * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = b[kp * 2 * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < nsteps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = p.out + (size_t)split * p.Kc * p.Ng;
+    const bool direct = (gridDim.y == 1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + col_w + j * 32 + li;
+        if (n >= p.Ng) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.Kc) {
+                    size_t o = (size_t)m * p.Ng + n;
+                    float v = acc[i][j][e];
+                    if (direct && p.beta != 0.f) v += p.beta * out[o];
+                    out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// dw[i] = beta * dw[i] + sum_s ws[s][i]  (fixed order)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n, int splits, float beta) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + i];
+    dw[i] = (beta != 0.f) ? beta * dw[i] + s : s;
+}
+
+struct WgPlan {
+    int cfg;
+    int bm, bn;
+    int splits;
+    int chunk;
+};
+
+WgPlan plan_wgrad(const sscg_conv_desc* d) {
+    WgPlan pl;
+    const int Kc = d->K;
+    const int Ng = d->R * d->S * d->C;
+    if (Kc <= 32) { pl.cfg = 2; pl.bm = 32; pl.bn = 128; }
+    else if (Ng <= 32 || d->C < 32) { pl.cfg = 3; pl.bm = 128; pl.bn = 32; }
+    else if (Kc <= 64 || Ng <= 64) { pl.cfg = 1; pl.bm = 64; pl.bn = 64; }
+    else { pl.cfg = 0; pl.bm = 128; pl.bn = 128; }
+    const long npix = (long)d->N * d->P * d->Q;
+    const long tiles = (long)cdiv(Kc, pl.bm) * cdiv(Ng, pl.bn);
+    long steps = cdiv(npix, BKP);
+    long want = cdiv(768, tiles);
+    long splits = want < 1 ? 1 : want;
+    // keep at least 4 k-steps per split
+    long max_splits = steps / 4 < 1 ? 1 : steps / 4;
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 64) splits = 64;
+    long steps_per = cdiv(steps, splits);
+    pl.chunk = (int)(steps_per * BKP);
+    pl.splits = cdiv(npix, pl.chunk);
+    return pl;
+}
+
+template <int WM, int WN, int TM, int TN, int VA, int VB>
+int launch_wg(WgParams p, int splits, hipStream_t st) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    p.tiles_n = cdiv(p.Ng, BN);
+    int tiles_m = cdiv(p.Kc, BM);
+    size_t smem = (size_t)(2 * BKP * (BM + 4) + 2 * BKP * (BN + 4)) * sizeof(float);
+    auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VA, VB>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, splits), dim3(256), smem, st, p);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+template <int VA, int VB>
+int dispatch_wg(const WgParams& p, const WgPlan& pl, hipStream_t st) {
+    switch (pl.cfg) {
+        case 0: return launch_wg<2, 2, 2, 2, VA, VB>(p, pl.splits, st);
+        case 1: return launch_wg<2, 2, 1, 1, VA, VB>(p, pl.splits, st);
+        case 2: return launch_wg<1, 4, 1, 1, VA, VB>(p, pl.splits, st);
+        case 3: return launch_wg<4, 1, 1, 1, VA, VB>(p, pl.splits, st);
+        default: return SSCG_ERR_BAD_ARG;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t sscg_conv2d_wgrad_workspace(const sscg_conv_desc* d) {
+    if (!d) return 0;
+    WgPlan pl = plan_wgrad(d);
+    if (pl.splits <= 1) return 0;
+    return (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float);
+}
+
+// dw = beta * dw + wgrad(x, dy);  dw is [K][R][S][C].  ws must hold sscg_conv2d_wgrad_workspace(d) bytes.
+extern "C" int sscg_conv2d_wgrad(const sscg_conv_desc* d, const float* x, const float* dy, float* dw, float beta,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    if (!d || !x || !dy || !dw) return SSCG_ERR_BAD_ARG;
+    if (d->N <= 0 || d->C <= 0 || d->K <= 0) return SSCG_ERR_BAD_ARG;
+    if ((long)d->N * d->H * d->W * (long)d->C >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
+    if ((long)d->N * d->P * d->Q * (long)d->K >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
+    WgPlan pl = plan_wgrad(d);
+    size_t need = pl.splits > 1 ? (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float) : 0;
+    if (need > 0 && (!ws || ws_bytes < need)) return SSCG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    WgParams p;
+    p.x = x; p.dy = dy;
+    p.out = pl.splits > 1 ? reinterpret_cast<float*>(ws) : dw;
+    p.Kc = d->K; p.Ng = d->R * d->S * d->C; p.C = d->C;
+    p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.S = d->S;
+    p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.pad_mode = d->pad_mode;
+    p.npix = d->N * d->P * d->Q; p.chunk = pl.chunk; p.tiles_n = 0;
+    p.beta = pl.splits > 1 ? 0.f : beta;
+    p.div_pq = make_fastdiv(d->P * d->Q);
+    p.div_q = make_fastdiv(d->Q);
+    const bool va4 = (d->K % 4 == 0), vb4 = (d->C % 4 == 0);
+    int rc;
+    if (va4 && vb4) rc = dispatch_wg<4, 4>(p, pl, st);
+    else if (va4) rc = dispatch_wg<4, 1>(p, pl, st);
+    else if (vb4) rc = dispatch_wg<1, 4>(p, pl, st);
+    else rc = dispatch_wg<1, 1>(p, pl, st);
+    if (rc) return rc;
+    if (pl.splits > 1) {
+        size_t n = (size_t)d->K * p.Ng;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(ws), dw, n, pl.splits, beta);
+        SSCG_LAUNCH_CHECK();
+    }
+    return SSCG_OK;
+}
+

@@ -1,0 +1,473 @@
+// InstanceNorm / BatchNorm (training statistics) + activation + residual, forward and backward, and
+// the column-sum used for bias gradients.  All HBM-bound: float4 over the channel axis, fp64
+// accumulation of per-channel sums (two-stage, fixed order => deterministic).
+//
+// Reference semantics: nn.InstanceNorm2d(affine=False, track_running_stats=False) (arch/ops.py:11),
+// nn.BatchNorm2d in train mode with frozen affine (arch/generators.py:326-337,390,417) or trainable
+// affine (arch/ops.py:9), followed by nn.ReLU / nn.LeakyReLU(0.2) (arch/ops.py:44,50,57) and, in the
+// DeepLab Bottleneck, `out += residual; relu` (arch/generators.py:362-363).
+//
+// The tensor is viewed as [G][L][C] (see sscg.h).
+#include "common.h"
+#include "sscg_internal.h"
+
+namespace {
+
+enum { RM_SUM = 0, RM_STATS = 1, RM_BWD = 2 };
+
+struct RedParams {
+    const float* __restrict__ x;     // SUM/STATS: input; BWD: x (pre-norm)
+    const float* __restrict__ dy;    // BWD
+    const float* __restrict__ y;     // BWD: forward output (activation mask)
+    const float* __restrict__ mean;  // BWD [G][C]
+    const float* __restrict__ rstd;  // BWD [G][C]
+    double* __restrict__ part;       // [G][chunks][C][2]
+    long L;
+    int C;
+    int chunks;
+    long rows_per_chunk;
+    int act;
+    float slope;
+};
+
+__device__ __forceinline__ float act_grad(float dy, float y, int act, float slope) {
+    if (act == SSCG_ACT_RELU) return y > 0.f ? dy : 0.f;
+    if (act == SSCG_ACT_LRELU) return y > 0.f ? dy : dy * slope;
+    if (act == SSCG_ACT_TANH) return dy * (1.f - y * y);
+    return dy;
+}
+
+// block = 256 threads = RW row-lanes x CW column groups (CW power of two <= 256), VEC channels per group
+template <int MODE, int VEC>
+__global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* sm = reinterpret_cast<double*>(smem_raw);  // [256][VEC][2]
+    const int tid = threadIdx.x;
+    const int RW = 256 / CW;
+    const int col = tid % CW;
+    const int rl = tid / CW;
+    const int chunk = blockIdx.x;
+    const int g = blockIdx.y;
+    const int c = (blockIdx.z * CW + col) * VEC;
+    const bool cok = c < p.C;
+
+    double s0[VEC], s1[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s0[e] = 0.0; s1[e] = 0.0; }
+
+    float mu[VEC], rs[VEC];
+    if (MODE == RM_BWD && cok) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { mu[e] = p.mean[(size_t)g * p.C + c + e]; rs[e] = p.rstd[(size_t)g * p.C + c + e]; }
+    }
+
+    if (cok) {
+        const long r_begin = (long)chunk * p.rows_per_chunk;
+        const long r_end = min(p.L, r_begin + p.rows_per_chunk);
+        const size_t base = (size_t)g * p.L * p.C + c;
+        for (long r = r_begin + rl; r < r_end; r += RW) {
+            const size_t o = base + (size_t)r * p.C;
+            float xv[VEC];
+            if constexpr (VEC == 4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(p.x + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[e] = t[e];
+            } else {
+                xv[0] = p.x[o];
+            }
+            if (MODE == RM_SUM) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s0[e] += (double)xv[e];
+            } else if (MODE == RM_STATS) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { double d = (double)xv[e]; s0[e] += d; s1[e] += d * d; }
+            } else {
+                float dv[VEC], yv[VEC];
+                const bool has_y = p.act != SSCG_ACT_NONE;  // y may be NULL without an activation
+                if constexpr (VEC == 4) {
+                    f32x4 t = *reinterpret_cast<const f32x4*>(p.dy + o);
+                    f32x4 u = {0.f, 0.f, 0.f, 0.f};
+                    if (has_y) u = *reinterpret_cast<const f32x4*>(p.y + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { dv[e] = t[e]; yv[e] = u[e]; }
+                } else {
+                    dv[0] = p.dy[o]; yv[0] = has_y ? p.y[o] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float gg = act_grad(dv[e], yv[e], p.act, p.slope);
+                    float xh = (xv[e] - mu[e]) * rs[e];
+                    s0[e] += (double)gg;
+                    s1[e] += (double)gg * (double)xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sm[(tid * VEC + e) * 2] = s0[e]; sm[(tid * VEC + e) * 2 + 1] = s1[e]; }
+    __syncthreads();
+    if (rl == 0 && cok) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            double a = 0.0, b = 0.0;
+            for (int r = 0; r < RW; ++r) {
+                a += sm[((r * CW + col) * VEC + e) * 2];
+                b += sm[((r * CW + col) * VEC + e) * 2 + 1];
+            }
+            if (c + e < p.C) {
+                size_t o = (((size_t)g * p.chunks + chunk) * p.C + c + e) * 2;
+                p.part[o] = a;
+                p.part[o + 1] = b;
+            }
+        }
+    }
+}
+
+struct RedPlan {
+    int vec, CW, slabs, chunks;
+    long rows_per_chunk;
+};
+
+RedPlan plan_reduce(int G, long L, int C) {
+    RedPlan pl;
+    pl.vec = (C % 4 == 0) ? 4 : 1;
+    int groups = C / pl.vec;
+    int cw = 1;
+    while (cw < groups && cw < 256) cw <<= 1;
+    pl.CW = cw;
+    pl.slabs = cdiv(groups, cw);
+    int rw = 256 / cw;
+    long budget = 2048 / ((long)G * pl.slabs);
+    if (budget < 1) budget = 1;
+    long by_rows = cdiv(L, (long)rw * 8);  // at least ~8 rows per thread
+    if (by_rows < 1) by_rows = 1;
+    long chunks = by_rows < budget ? by_rows : budget;
+    pl.rows_per_chunk = cdiv(L, chunks);
+    pl.chunks = cdiv(L, pl.rows_per_chunk);
+    return pl;
+}
+
+size_t part_bytes(int G, long L, int C) {
+    RedPlan pl = plan_reduce(G, L, C);
+    return (size_t)G * pl.chunks * C * 2 * sizeof(double);
+}
+
+template <int MODE>
+int launch_reduce(RedParams p, int G, hipStream_t st) {
+    RedPlan pl = plan_reduce(G, p.L, p.C);
+    p.chunks = pl.chunks;
+    p.rows_per_chunk = pl.rows_per_chunk;
+    dim3 grid(pl.chunks, G, pl.slabs);
+    size_t smem = (size_t)256 * pl.vec * 2 * sizeof(double);
+    if (pl.vec == 4)
+        hipLaunchKernelGGL((col_reduce_kernel<MODE, 4>), grid, dim3(256), smem, st, p, pl.CW);
+    else
+        hipLaunchKernelGGL((col_reduce_kernel<MODE, 1>), grid, dim3(256), smem, st, p, pl.CW);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+__global__ void finalize_sum_kernel(const double* __restrict__ part, float* __restrict__ out, int C, int chunks, float beta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += part[((size_t)k * C + c) * 2];
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
+}
+
+__global__ void finalize_stats_kernel(const double* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
+                                      float* __restrict__ rmean, float* __restrict__ rvar, int G, int C, int chunks,
+                                      long L, float eps, float momentum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    int g = i / C, c = i - g * C;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        size_t o = (((size_t)g * chunks + k) * C + c) * 2;
+        s += part[o];
+        ss += part[o + 1];
+    }
+    double m = s / (double)L;
+    double var = ss / (double)L - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        double unb = L > 1 ? var * (double)L / (double)(L - 1) : var;
+        rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
+        rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+    }
+}
+
+// c1 = sum_g / L, c2 = sum_g_xhat / L  per (g, c);  dgamma/dbeta += sums (over g)
+__global__ void finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ coef, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int G, int C, int chunks, long L) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double tg = 0.0, tb = 0.0;
+    for (int g = 0; g < G; ++g) {
+        double s = 0.0, sx = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            size_t o = (((size_t)g * chunks + k) * C + c) * 2;
+            s += part[o];
+            sx += part[o + 1];
+        }
+        coef[((size_t)g * C + c) * 2] = (float)(s / (double)L);
+        coef[((size_t)g * C + c) * 2 + 1] = (float)(sx / (double)L);
+        tb += s;
+        tg += sx;
+    }
+    if (dgamma) dgamma[c] += (float)tg;
+    if (dbeta) dbeta[c] += (float)tb;
+}
+
+struct ApplyParams {
+    const float* __restrict__ x;
+    const float* __restrict__ mean;
+    const float* __restrict__ rstd;
+    const float* __restrict__ gamma;
+    const float* __restrict__ beta;
+    const float* __restrict__ res;
+    float* __restrict__ y;
+    long L;
+    int C;
+    int act;
+    float slope;
+    uint32_t total;  // elements / VEC  (< 2^31)
+    FastDiv div_cg;  // by C/VEC
+    FastDiv div_l;   // by L
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void norm_apply_kernel(ApplyParams p) {
+    const int CG = p.C / VEC;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.total; i += gridDim.x * 256) {
+        const int row = fd_div((int)i, p.div_cg);
+        const int c = ((int)i - row * CG) * VEC;
+        const int g = fd_div(row, p.div_l);
+        const size_t o = (size_t)i * VEC;
+        float xv[VEC], rv[VEC];
+        if constexpr (VEC == 4) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(p.x + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = t[e];
+            if (p.res) {
+                f32x4 u = *reinterpret_cast<const f32x4*>(p.res + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[e] = u[e];
+            }
+        } else {
+            xv[0] = p.x[o];
+            if (p.res) rv[0] = p.res[o];
+        }
+        float out[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const size_t s = (size_t)g * p.C + c + e;
+            float v = (xv[e] - p.mean[s]) * p.rstd[s];
+            if (p.gamma) v = v * p.gamma[c + e] + p.beta[c + e];
+            if (p.res) v += rv[e];
+            out[e] = sscg_act(v, p.act, p.slope);
+        }
+        if constexpr (VEC == 4) {
+            f32x4 t = {out[0], out[1], out[2], out[3]};
+            *reinterpret_cast<f32x4*>(p.y + o) = t;
+        } else {
+            p.y[o] = out[0];
+        }
+    }
+}
+
+struct BwdApplyParams {
+    const float* __restrict__ dy;
+    const float* __restrict__ x;
+    const float* __restrict__ y;
+    const float* __restrict__ mean;
+    const float* __restrict__ rstd;
+    const float* __restrict__ gamma;
+    const float* __restrict__ coef;  // [G][C][2] or null when stats are constants
+    float* __restrict__ dx;
+    float* __restrict__ dres;
+    long L;
+    int C;
+    int act;
+    float slope;
+    uint32_t total;
+    FastDiv div_cg;
+    FastDiv div_l;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdApplyParams p) {
+    const int CG = p.C / VEC;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.total; i += gridDim.x * 256) {
+        const int row = fd_div((int)i, p.div_cg);
+        const int c = ((int)i - row * CG) * VEC;
+        const int g = fd_div(row, p.div_l);
+        const size_t o = (size_t)i * VEC;
+        float dv[VEC], xv[VEC], yv[VEC];
+        if constexpr (VEC == 4) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(p.dy + o);
+            f32x4 b = *reinterpret_cast<const f32x4*>(p.x + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dv[e] = a[e]; xv[e] = b[e]; }
+            if (p.act != SSCG_ACT_NONE) {
+                f32x4 u = *reinterpret_cast<const f32x4*>(p.y + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[e] = u[e];
+            }
+        } else {
+            dv[0] = p.dy[o]; xv[0] = p.x[o];
+            if (p.act != SSCG_ACT_NONE) yv[0] = p.y[o];
+        }
+        float gx[VEC], gr[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const size_t s = (size_t)g * p.C + c + e;
+            float gg = p.act != SSCG_ACT_NONE ? act_grad(dv[e], yv[e], p.act, p.slope) : dv[e];
+            gr[e] = gg;
+            float rs = p.rstd[s];
+            float gam = p.gamma ? p.gamma[c + e] : 1.f;
+            float v = gg;
+            if (p.coef) {
+                float xh = (xv[e] - p.mean[s]) * rs;
+                v = gg - p.coef[s * 2] - xh * p.coef[s * 2 + 1];
+            }
+            gx[e] = v * rs * gam;
+        }
+        if constexpr (VEC == 4) {
+            f32x4 t = {gx[0], gx[1], gx[2], gx[3]};
+            *reinterpret_cast<f32x4*>(p.dx + o) = t;
+            if (p.dres) {
+                f32x4 u = {gr[0], gr[1], gr[2], gr[3]};
+                *reinterpret_cast<f32x4*>(p.dres + o) = u;
+            }
+        } else {
+            p.dx[o] = gx[0];
+            if (p.dres) p.dres[o] = gr[0];
+        }
+    }
+}
+
+__global__ void rstd_from_var_kernel(const float* __restrict__ var, float* __restrict__ rstd, int n, float eps) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rstd[i] = (float)(1.0 / sqrt((double)var[i] + (double)eps));
+}
+
+inline int ew_grid(size_t total) {
+    size_t b = (total + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" size_t sscg_colsum_workspace(int64_t rows, int cols) { return part_bytes(1, rows, cols); }
+
+extern "C" int sscg_colsum(const float* x, float* out, int64_t rows, int cols, float beta, void* ws, size_t ws_bytes,
+                           void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) return SSCG_ERR_BAD_ARG;
+    if (!ws || ws_bytes < part_bytes(1, rows, cols)) return SSCG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    RedParams p = {};
+    p.x = x; p.part = reinterpret_cast<double*>(ws); p.L = rows; p.C = cols;
+    int rc = launch_reduce<RM_SUM>(p, 1, st);
+    if (rc) return rc;
+    RedPlan pl = plan_reduce(1, rows, cols);
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, p.part, out, cols, pl.chunks, beta);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" size_t sscg_norm_stats_workspace(int G, int64_t L, int C) { return part_bytes(G, L, C); }
+
+extern "C" int sscg_norm_stats(const float* x, int G, int64_t L, int C, float eps, float* mean, float* rstd,
+                               float* running_mean, float* running_var, float momentum, void* ws, size_t ws_bytes,
+                               void* stream) {
+    if (!x || !mean || !rstd || G <= 0 || L <= 0 || C <= 0) return SSCG_ERR_BAD_ARG;
+    if ((running_mean != nullptr) != (running_var != nullptr)) return SSCG_ERR_BAD_ARG;
+    if (running_mean && G != 1) return SSCG_ERR_BAD_ARG;
+    if (!ws || ws_bytes < part_bytes(G, L, C)) return SSCG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    RedParams p = {};
+    p.x = x; p.part = reinterpret_cast<double*>(ws); p.L = L; p.C = C;
+    int rc = launch_reduce<RM_STATS>(p, G, st);
+    if (rc) return rc;
+    RedPlan pl = plan_reduce(G, L, C);
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3(cdiv((long)G * C, 256)), dim3(256), 0, st, p.part, mean, rstd,
+                       running_mean, running_var, G, C, pl.chunks, (long)L, eps, momentum);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_norm_apply(const float* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const float* residual, float* y, int G, int64_t L, int C, int act,
+                               float slope, void* stream) {
+    if (!x || !mean || !rstd || !y || G <= 0 || L <= 0 || C <= 0) return SSCG_ERR_BAD_ARG;
+    if ((gamma != nullptr) != (beta != nullptr)) return SSCG_ERR_BAD_ARG;
+    ApplyParams p = {};
+    p.x = x; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.res = residual; p.y = y;
+    p.L = L; p.C = C; p.act = act; p.slope = slope;
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    if ((size_t)G * L * C / vec >= ((size_t)1 << 31)) return SSCG_ERR_UNSUPPORTED;
+    p.total = (uint32_t)((size_t)G * L * C / vec);
+    p.div_cg = make_fastdiv(C / vec);
+    p.div_l = make_fastdiv((int)L);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec == 4)
+        hipLaunchKernelGGL(norm_apply_kernel<4>, dim3(ew_grid(p.total)), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL(norm_apply_kernel<1>, dim3(ew_grid(p.total)), dim3(256), 0, st, p);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_rstd_from_var(const float* var, float* rstd, int n, float eps, void* stream) {
+    if (!var || !rstd || n <= 0) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(rstd_from_var_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, var, rstd, n, eps);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" size_t sscg_norm_bwd_workspace(int G, int64_t L, int C) {
+    return part_bytes(G, L, C) + (size_t)G * C * 2 * sizeof(float);
+}
+
+extern "C" int sscg_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd,
+                             const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int G, int64_t L,
+                             int C, int act, float slope, int stats_grad, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !mean || !rstd || !dx || G <= 0 || L <= 0 || C <= 0) return SSCG_ERR_BAD_ARG;
+    if (act != SSCG_ACT_NONE && !y) return SSCG_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool need_red = stats_grad || dgamma || dbeta;
+    float* coef = nullptr;
+    if (need_red) {
+        if (!ws || ws_bytes < sscg_norm_bwd_workspace(G, L, C)) return SSCG_ERR_WORKSPACE;
+        RedParams p = {};
+        p.x = x; p.dy = dy; p.y = y; p.mean = mean; p.rstd = rstd;
+        p.part = reinterpret_cast<double*>(ws); p.L = L; p.C = C; p.act = act; p.slope = slope;
+        int rc = launch_reduce<RM_BWD>(p, G, st);
+        if (rc) return rc;
+        RedPlan pl = plan_reduce(G, L, C);
+        coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + part_bytes(G, L, C));
+        hipLaunchKernelGGL(finalize_bwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, p.part, coef, dgamma, dbeta, G, C,
+                           pl.chunks, (long)L);
+        SSCG_LAUNCH_CHECK();
+    }
+    BwdApplyParams q = {};
+    q.dy = dy; q.x = x; q.y = y; q.mean = mean; q.rstd = rstd; q.gamma = gamma;
+    q.coef = stats_grad ? coef : nullptr;
+    q.dx = dx; q.dres = dres; q.L = L; q.C = C; q.act = act; q.slope = slope;
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    if ((size_t)G * L * C / vec >= ((size_t)1 << 31)) return SSCG_ERR_UNSUPPORTED;
+    q.total = (uint32_t)((size_t)G * L * C / vec);
+    q.div_cg = make_fastdiv(C / vec);
+    q.div_l = make_fastdiv((int)L);
+    if (vec == 4)
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, dim3(ew_grid(q.total)), dim3(256), 0, st, q);
+    else
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(ew_grid(q.total)), dim3(256), 0, st, q);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}

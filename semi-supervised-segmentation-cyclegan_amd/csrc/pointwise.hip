@@ -1,0 +1,316 @@
+// HBM-bound pointwise / pooling / resize / layout kernels (NHWC fp32).  Reference call sites are
+// listed per entry point in include/sscg.h.
+#include "common.h"
+#include "sscg_internal.h"
+
+namespace {
+
+inline int ew_blocks(size_t n) {
+    size_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act, float slope) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = sscg_act(x[i], act, slope);
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, size_t n,
+                               int act, float slope) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float g = dy[i], v = y[i];
+        if (act == SSCG_ACT_RELU) g = v > 0.f ? g : 0.f;
+        else if (act == SSCG_ACT_LRELU) g = v > 0.f ? g : g * slope;
+        else if (act == SSCG_ACT_TANH) g = g * (1.f - v * v);
+        dx[i] = g;
+    }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = a[i] + b[i];
+}
+
+__global__ void fill_kernel(float* __restrict__ x, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = v;
+}
+
+__device__ __forceinline__ uint32_t mix64to32(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float p, float scale,
+                               uint64_t seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t r = mix64to32(seed * 0x2545f4914f6cdd1dull + (uint64_t)i);
+        float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+        y[i] = u >= p ? x[i] * scale : 0.f;
+    }
+}
+
+// one thread per (n, oy, ox, c)
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int N,
+                                   int H, int W, int C, int P, int Q) {
+    size_t total = (size_t)N * P * Q * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c = (int)(i % C);
+        size_t t = i / C;
+        int ox = (int)(t % Q); t /= Q;
+        int oy = (int)(t % P);
+        int n = (int)(t / P);
+        float best = -INFINITY;
+        int bi = 0;
+        bool first = true;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                float v = x[((size_t)(n * H + iy) * W + ix) * C + c];
+                if (first || v > best) { best = v; bi = ky * 3 + kx; first = false; }
+            }
+        }
+        y[i] = best;
+        idx[i] = (uint8_t)bi;
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                   int N, int H, int W, int C, int P, int Q) {
+    size_t total = (size_t)N * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c = (int)(i % C);
+        size_t t = i / C;
+        int ix = (int)(t % W); t /= W;
+        int iy = (int)(t % H);
+        int n = (int)(t / H);
+        float s = 0.f;
+        int oy_lo = iy / 2, oy_hi = (iy + 1) / 2;  // oy*2-1 <= iy <= oy*2+1
+        int ox_lo = ix / 2, ox_hi = (ix + 1) / 2;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (oy >= P) continue;
+            int ky = iy - (oy * 2 - 1);
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ox >= Q) continue;
+                int kx = ix - (ox * 2 - 1);
+                size_t o = ((size_t)(n * P + oy) * Q + ox) * C + c;
+                if (idx[o] == ky * 3 + kx) s += dy[o];
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+// bilinear, align_corners=True (torch upsample_bilinear2d arithmetic: src = scale * dst in fp32)
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+                                    int OH, int OW, float sh, float sw) {
+    size_t total = (size_t)N * OH * OW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c = (int)(i % C);
+        size_t t = i / C;
+        int ox = (int)(t % OW); t /= OW;
+        int oy = (int)(t % OH);
+        int n = (int)(t / OH);
+        float fy = sh * oy, fx = sw * ox;
+        int y0 = (int)fy, x0 = (int)fx;
+        int yp = y0 < H - 1 ? 1 : 0, xp = x0 < W - 1 ? 1 : 0;
+        float ly = fy - y0, lx = fx - x0;
+        float hy = 1.f - ly, hx = 1.f - lx;
+        const float* b = x + (size_t)n * H * W * C + c;
+        float v00 = b[((size_t)y0 * W + x0) * C], v01 = b[((size_t)y0 * W + x0 + xp) * C];
+        float v10 = b[((size_t)(y0 + yp) * W + x0) * C], v11 = b[((size_t)(y0 + yp) * W + x0 + xp) * C];
+        y[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+}
+
+// gather form of the adjoint: one thread per (n, iy, ix, c) sums the output pixels that touch it
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C,
+                                    int OH, int OW, float sh, float sw, float inv_sh, float inv_sw) {
+    size_t total = (size_t)N * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c = (int)(i % C);
+        size_t t = i / C;
+        int ix = (int)(t % W); t /= W;
+        int iy = (int)(t % H);
+        int n = (int)(t / H);
+        int oy_lo = (int)floorf((iy - 1) * inv_sh) - 1, oy_hi = (int)ceilf((iy + 1) * inv_sh) + 1;
+        int ox_lo = (int)floorf((ix - 1) * inv_sw) - 1, ox_hi = (int)ceilf((ix + 1) * inv_sw) + 1;
+        oy_lo = max(oy_lo, 0); ox_lo = max(ox_lo, 0);
+        oy_hi = min(oy_hi, OH - 1); ox_hi = min(ox_hi, OW - 1);
+        float s = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            float fy = sh * oy;
+            int y0 = (int)fy;
+            int yp = y0 < H - 1 ? 1 : 0;
+            float ly = fy - y0;
+            float wy = 0.f;
+            if (y0 == iy) wy += 1.f - ly;
+            if (y0 + yp == iy) wy += ly;
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                float fx = sw * ox;
+                int x0 = (int)fx;
+                int xp = x0 < W - 1 ? 1 : 0;
+                float lx = fx - x0;
+                float wx = 0.f;
+                if (x0 == ix) wx += 1.f - lx;
+                if (x0 + xp == ix) wx += lx;
+                if (wx == 0.f) continue;
+                s += wy * wx * dy[((size_t)(n * OH + oy) * OW + ox) * C + c];
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+__global__ void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int pad) {
+    int OH = H + 2 * pad, OW = W + 2 * pad;
+    size_t total = (size_t)N * OH * OW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c = (int)(i % C);
+        size_t t = i / C;
+        int ox = (int)(t % OW); t /= OW;
+        int oy = (int)(t % OH);
+        int n = (int)(t / OH);
+        int sy = oy - pad, sx = ox - pad;
+        sy = sy < 0 ? -sy : sy; sx = sx < 0 ? -sx : sx;
+        sy = sy >= H ? 2 * (H - 1) - sy : sy;
+        sx = sx >= W ? 2 * (W - 1) - sx : sx;
+        y[i] = x[((size_t)(n * H + sy) * W + sx) * C + c];
+    }
+}
+
+// per image: in [R][Cc] -> out [Cc][R]   (32x32 LDS tiles)
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+    __shared__ float t[32][33];
+    const float* src = in + (size_t)blockIdx.z * R * Cc;
+    float* dst = out + (size_t)blockIdx.z * R * Cc;
+    int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        int rr = r0 + r, cc = c0 + tx;
+        t[r][tx] = (rr < R && cc < Cc) ? src[(size_t)rr * Cc + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int cc = c0 + r, rr = r0 + tx;
+        if (rr < R && cc < Cc) dst[(size_t)cc * R + rr] = t[tx][r];
+    }
+}
+
+}  // namespace
+
+extern "C" int sscg_abi_version(void) { return SSCG_ABI_VERSION; }
+
+extern "C" int sscg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream) {
+    if (!x || !y || n <= 0) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n, act, slope);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, void* stream) {
+    if (!dy || !y || !dx || n <= 0) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (size_t)n, act, slope);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+    if (!a || !b || !y || n <= 0) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (size_t)n);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_fill(float* x, int64_t n, float v, void* stream) {
+    if (!x || n <= 0) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, v);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n, p,
+                       1.f / (1.f - p), seed);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, int P, int Q,
+                                     void* stream) {
+    if (!x || !y || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0) return SSCG_ERR_BAD_ARG;
+    if ((P - 1) * 2 - 1 >= H || (Q - 1) * 2 - 1 >= W) return SSCG_ERR_BAD_ARG;
+    size_t total = (size_t)N * P * Q * C;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W, C, P, Q);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, int P,
+                                     int Q, void* stream) {
+    if (!dy || !idx || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0) return SSCG_ERR_BAD_ARG;
+    size_t total = (size_t)N * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C, P, Q);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_upsample_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
+                                          void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return SSCG_ERR_BAD_ARG;
+    float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    size_t total = (size_t)N * OH * OW * C;
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, OH, OW, sh, sw);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_upsample_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW,
+                                          void* stream) {
+    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return SSCG_ERR_BAD_ARG;
+    float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    // sh == 0 (single source row) => every output row touches row 0: scan the full range
+    float inv_sh = sh > 0.f ? 1.f / sh : (float)OH;
+    float inv_sw = sw > 0.f ? 1.f / sw : (float)OW;
+    size_t total = (size_t)N * H * W * C;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C, OH, OW,
+                       sh, sw, inv_sh, inv_sw);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_reflect_pad(const float* x, float* y, int N, int H, int W, int C, int pad, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || pad >= H || pad >= W) return SSCG_ERR_BAD_ARG;
+    size_t total = (size_t)N * (H + 2 * pad) * (W + 2 * pad) * C;
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, pad);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SSCG_ERR_BAD_ARG;
+    int R = C, Cc = H * W;  // [C][HW] -> [HW][C]
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cc, 32), cdiv(R, 32), N), dim3(256), 0, (hipStream_t)stream, x, y, R, Cc);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SSCG_ERR_BAD_ARG;
+    int R = H * W, Cc = C;  // [HW][C] -> [C][HW]
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cc, 32), cdiv(R, 32), N), dim3(256), 0, (hipStream_t)stream, x, y, R, Cc);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}

@@ -1,0 +1,711 @@
+"""Host-side operators: torch tensors in, libsscg.so kernels underneath.
+
+Two layers:
+  * raw ops (`conv2d_fwd`, `norm_stats`, ...) - thin wrappers over the C ABI (include/sscg.h) that
+    allocate outputs through torch's caching allocator and launch on torch's current HIP stream;
+  * `torch.autograd.Function`s (`Conv2dFn`, `NormActFn`, ...) that give those kernels the semantics
+    of the stock torch.nn modules the reference composes (arch/ops.py:40-57, model.py:268-273).
+
+Tensors keep the reference's logical NCHW shapes; physically they are channels-last (NHWC), which is
+what every kernel assumes.  There is no fallback: a non-HIP tensor raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZEROS, PAD_REFLECT, ConvDesc, check, lib
+
+CL = torch.channels_last
+
+
+# ----------------------------------------------------------------------------- plumbing
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_hip(t):
+    if not t.is_cuda:
+        raise _lib.SscgError("sscg kernels run on the MI355X only: got a %s tensor (no CPU fallback)" % t.device)
+    if t.dtype != torch.float32:
+        raise _lib.SscgError("fp32 tensor expected, got %s" % t.dtype)
+
+
+class _Workspace:
+    """One growable scratch buffer per device (stream-ordered reuse on torch's current stream)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 16)
+        b = self.buf.get(device)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+            self.buf[device] = b
+        return b
+
+
+_WS = _Workspace()
+
+
+def empty_nhwc(n, c, h, w, device, dtype=torch.float32):
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=CL)
+
+
+def to_nhwc(x):
+    """Logical NCHW tensor -> channels-last memory (HIP transpose kernel when a copy is needed)."""
+    _need_hip(x)
+    if x.dim() != 4:
+        raise _lib.SscgError("4-D tensor expected")
+    if x.is_contiguous(memory_format=CL):
+        return x
+    if not x.is_contiguous():
+        x = x.contiguous()
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, h, w, x.device)
+    check(lib.sscg_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), n, c, h, w, _stream()), "sscg_nchw_to_nhwc")
+    return y
+
+
+def to_nchw(x):
+    """channels-last tensor -> standard contiguous NCHW memory."""
+    _need_hip(x)
+    if x.is_contiguous():
+        return x
+    x = to_nhwc(x)
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h, w), dtype=x.dtype, device=x.device)
+    check(lib.sscg_nhwc_to_nchw(x.data_ptr(), y.data_ptr(), n, c, h, w, _stream()), "sscg_nhwc_to_nchw")
+    return y
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def make_desc(xshape, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0):
+    n, c, h, w = xshape
+    k, c2, r, s = wshape
+    if c != c2:
+        raise _lib.SscgError("conv channel mismatch: input %d vs weight %d" % (c, c2))
+    d = ConvDesc()
+    d.N, d.H, d.W, d.C = n, h, w, c
+    d.K, d.R, d.S = k, r, s
+    d.P, d.Q = conv_out_size(h, r, stride, pad, dil), conv_out_size(w, s, stride, pad, dil)
+    d.stride, d.pad, d.dil = stride, pad, dil
+    d.pad_mode, d.act, d.slope = pad_mode, act, slope
+    return d
+
+
+# ----------------------------------------------------------------------------- raw ops
+def conv2d_fwd(x, w, bias, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0):
+    d = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, act, slope)
+    y = empty_nhwc(d.N, d.K, d.P, d.Q, x.device)
+    check(lib.sscg_conv2d_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _stream()), "sscg_conv2d_fwd")
+    return y
+
+
+def weight_transposed(w):
+    """[K][R][S][C] -> [C][R][S][K] (the operand layout of sscg_conv2d_dgrad)."""
+    k, c, r, s = w.shape
+    wt = torch.empty((c, k, r, s), dtype=w.dtype, device=w.device, memory_format=CL)
+    check(lib.sscg_weight_krsc_to_crsk(w.data_ptr(), wt.data_ptr(), k, r * s, c, _stream()), "sscg_weight_krsc_to_crsk")
+    return wt
+
+
+def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0):
+    d = make_desc(xshape, wshape, stride, pad, dil)
+    dx = empty_nhwc(d.N, d.C, d.H, d.W, dy.device)
+    check(lib.sscg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wt.data_ptr(), _ptr(bias), dx.data_ptr(), act, slope, _stream()),
+          "sscg_conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(x, dy, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, out=None, accumulate=False):
+    d = make_desc(x.shape, wshape, stride, pad, dil, pad_mode)
+    if out is None:
+        k, c, r, s = wshape
+        out = torch.empty((k, c, r, s), dtype=x.dtype, device=x.device, memory_format=CL)
+        accumulate = False
+    nb = lib.sscg_conv2d_wgrad_workspace(C.byref(d))
+    ws = _WS.get(nb, x.device)
+    check(lib.sscg_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), out.data_ptr(), 1.0 if accumulate else 0.0,
+                                ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_wgrad")
+    return out
+
+
+def colsum(x2d_rows, cols, x, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+        accumulate = False
+    nb = lib.sscg_colsum_workspace(x2d_rows, cols)
+    ws = _WS.get(nb, x.device)
+    check(lib.sscg_colsum(x.data_ptr(), out.data_ptr(), x2d_rows, cols, 1.0 if accumulate else 0.0, ws.data_ptr(),
+                          ws.numel(), _stream()), "sscg_colsum")
+    return out
+
+
+def _glc(x, per_sample):
+    n, c, h, w = x.shape
+    return (n, h * w, c) if per_sample else (1, n * h * w, c)
+
+
+def norm_stats(x, per_sample, eps=1e-5, running_mean=None, running_var=None, momentum=0.1):
+    g, l, c = _glc(x, per_sample)
+    mean = torch.empty((g, c), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((g, c), dtype=torch.float32, device=x.device)
+    nb = lib.sscg_norm_stats_workspace(g, l, c)
+    ws = _WS.get(nb, x.device)
+    check(lib.sscg_norm_stats(x.data_ptr(), g, l, c, eps, mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean),
+                              _ptr(running_var), momentum, ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_stats")
+    return mean, rstd
+
+
+def norm_apply(x, mean, rstd, gamma, beta, residual, per_sample, act=ACT_NONE, slope=0.0):
+    g, l, c = _glc(x, per_sample)
+    y = torch.empty_like(x, memory_format=CL)
+    check(lib.sscg_norm_apply(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta), _ptr(residual),
+                              y.data_ptr(), g, l, c, act, slope, _stream()), "sscg_norm_apply")
+    return y
+
+
+def norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad=True, want_dres=False, dgamma=None,
+             dbeta=None):
+    g, l, c = _glc(x, per_sample)
+    dx = torch.empty_like(x, memory_format=CL)
+    dres = torch.empty_like(x, memory_format=CL) if want_dres else None
+    nb = lib.sscg_norm_bwd_workspace(g, l, c)
+    ws = _WS.get(nb, x.device)
+    check(lib.sscg_norm_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
+                            dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), g, l, c, act, slope,
+                            1 if stats_grad else 0, ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_bwd")
+    return dx, dres
+
+
+def rstd_from_var(var, eps):
+    out = torch.empty_like(var)
+    check(lib.sscg_rstd_from_var(var.data_ptr(), out.data_ptr(), var.numel(), eps, _stream()), "sscg_rstd_from_var")
+    return out
+
+
+def act_fwd(x, act, slope=0.0):
+    y = torch.empty_like(x, memory_format=torch.preserve_format)
+    check(lib.sscg_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), act, slope, _stream()), "sscg_act_fwd")
+    return y
+
+
+def act_bwd(dy, y, act, slope=0.0):
+    dx = torch.empty_like(y, memory_format=torch.preserve_format)
+    check(lib.sscg_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), act, slope, _stream()), "sscg_act_bwd")
+    return dx
+
+
+def add(a, b):
+    y = torch.empty_like(a, memory_format=torch.preserve_format)
+    check(lib.sscg_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "sscg_add")
+    return y
+
+
+def fill_(x, v):
+    check(lib.sscg_fill(x.data_ptr(), x.numel(), float(v), _stream()), "sscg_fill")
+    return x
+
+
+def dropout(x, p, seed):
+    y = torch.empty_like(x, memory_format=torch.preserve_format)
+    check(lib.sscg_dropout(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _stream()), "sscg_dropout")
+    return y
+
+
+def pool_out_size(h):
+    """MaxPool2d(3, 2, 1, ceil_mode=True) output size (torch rule: last window must start inside input+left pad)."""
+    o = -((-(h + 2 - 3)) // 2) + 1
+    if (o - 1) * 2 >= h + 1:
+        o -= 1
+    return o
+
+
+def maxpool_fwd(x):
+    n, c, h, w = x.shape
+    p, q = pool_out_size(h), pool_out_size(w)
+    y = empty_nhwc(n, c, p, q, x.device)
+    idx = torch.empty((n, c, p, q), dtype=torch.uint8, device=x.device, memory_format=CL)
+    check(lib.sscg_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), n, h, w, c, p, q, _stream()),
+          "sscg_maxpool3x3s2_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, xshape):
+    n, c, h, w = xshape
+    p, q = dy.shape[2], dy.shape[3]
+    dx = empty_nhwc(n, c, h, w, dy.device)
+    check(lib.sscg_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), n, h, w, c, p, q, _stream()),
+          "sscg_maxpool3x3s2_bwd")
+    return dx
+
+
+def upsample_fwd(x, oh, ow):
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, oh, ow, x.device)
+    check(lib.sscg_upsample_bilinear_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, oh, ow, _stream()), "sscg_upsample_bilinear_fwd")
+    return y
+
+
+def upsample_bwd(dy, h, w):
+    n, c, oh, ow = dy.shape
+    dx = empty_nhwc(n, c, h, w, dy.device)
+    check(lib.sscg_upsample_bilinear_bwd(dy.data_ptr(), dx.data_ptr(), n, h, w, c, oh, ow, _stream()), "sscg_upsample_bilinear_bwd")
+    return dx
+
+
+def reflect_pad(x, pad):
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, h + 2 * pad, w + 2 * pad, x.device)
+    check(lib.sscg_reflect_pad(x.data_ptr(), y.data_ptr(), n, h, w, c, pad, _stream()), "sscg_reflect_pad")
+    return y
+
+
+def softmax_fwd(x):
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=CL)
+    check(lib.sscg_softmax_fwd(x.data_ptr(), y.data_ptr(), n * h * w, c, _stream()), "sscg_softmax_fwd")
+    return y
+
+
+def softmax_bwd(dy, y):
+    n, c, h, w = y.shape
+    dx = torch.empty_like(y, memory_format=CL)
+    check(lib.sscg_softmax_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), n * h * w, c, _stream()), "sscg_softmax_bwd")
+    return dx
+
+
+def argmax_onehot(x, want_index=False):
+    """`x.max(1)[1]` + make_one_hot in one pass (model.py:435-437).  Returns (onehot NHWC, index [N,H,W] or None)."""
+    x = to_nhwc(x)
+    n, c, h, w = x.shape
+    oh = torch.empty_like(x, memory_format=CL)
+    idx = torch.empty((n, h, w), dtype=torch.int64, device=x.device) if want_index else None
+    check(lib.sscg_argmax_onehot(x.data_ptr(), oh.data_ptr(), _ptr(idx), n * h * w, c, _stream()), "sscg_argmax_onehot")
+    return oh, idx
+
+
+def argmax_index(x):
+    x = to_nhwc(x)
+    n, c, h, w = x.shape
+    idx = torch.empty((n, h, w), dtype=torch.int64, device=x.device)
+    check(lib.sscg_argmax_onehot(x.data_ptr(), None, idx.data_ptr(), n * h * w, c, _stream()), "sscg_argmax_onehot")
+    return idx
+
+
+def label_onehot(labels, num_classes):
+    """utils.make_one_hot (utils.py:314-350): labels int64 [N,1,H,W] -> fp32 one-hot [N,C,H,W] (NHWC memory)."""
+    if not labels.is_cuda or labels.dtype != torch.int64:
+        raise _lib.SscgError("int64 HIP label tensor expected")
+    labels = labels.contiguous()
+    n, _, h, w = labels.shape
+    oh = empty_nhwc(n, num_classes, h, w, labels.device)
+    check(lib.sscg_label_onehot(labels.data_ptr(), oh.data_ptr(), n * h * w, num_classes, _stream()), "sscg_label_onehot")
+    return oh
+
+
+def _scalar(device):
+    return torch.empty((), dtype=torch.float32, device=device)
+
+
+def _loss_ws(device):
+    return _WS.get(lib.sscg_loss_workspace(0), device)
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    check(lib.sscg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                             step, grad_scale, _stream()), "sscg_adam_step")
+
+
+# ----------------------------------------------------------------------------- autograd functions
+_WT_CACHE = {}
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Called by the optimiser after it rewrote parameters: invalidates cached transposed weights."""
+    _WEIGHT_EPOCH[0] += 1
+    _WT_CACHE.clear()
+
+
+def _cached_wt(w):
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _WT_CACHE.get(key)
+    if ent is None or ent[0] != w._version:
+        ent = (w._version, weight_transposed(w))
+        _WT_CACHE[key] = ent
+    return ent[1]
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d (+ folded nn.ReflectionPad2d, + fused activation when no norm layer follows)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil, pad_mode, act, slope):
+        x = to_nhwc(x)
+        y = conv2d_fwd(x, w, bias, stride, pad, dil, pad_mode, act, slope)
+        ctx.cfg = (stride, pad, dil, pad_mode, act, slope)
+        ctx.has_bias = bias is not None
+        ctx.wref = w
+        ctx.bref = bias
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, dil, pad_mode, act, slope = ctx.cfg
+        dy = to_nhwc(dy)
+        if act != ACT_NONE:
+            dy = act_bwd(dy, y, act, slope)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if pad_mode == PAD_REFLECT:
+                raise _lib.SscgError("input gradient through a reflection-padded conv: use ReflectPadFn + pad=0 conv")
+            dx = conv2d_dgrad(dy, _cached_wt(w), x.shape, w.shape, stride, pad, dil)
+        if ctx.needs_input_grad[1]:
+            acc = getattr(ctx.wref, "_sscg_grad", None)
+            if acc is not None:
+                conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode, out=acc, accumulate=True)
+            else:
+                dw = conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            n, k, p, q = dy.shape
+            acc = getattr(ctx.bref, "_sscg_grad", None)
+            if acc is not None:
+                colsum(n * p * q, k, dy, out=acc, accumulate=True)
+            else:
+                db = colsum(n * p * q, k, dy)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+class ConvTranspose2dFn(torch.autograd.Function):
+    """nn.ConvTranspose2d (arch/ops.py:55-56) as the data-gradient of the mirrored convolution.
+
+    `w` is the torch ConvTranspose2d weight, logical [Cin, Cout, R, S], channels-last memory
+    [Cin][R][S][Cout] - i.e. the [K][R][S][C] weight of a conv Cout->Cin."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, out_pad, act, slope):
+        x = to_nhwc(x)
+        n, cin, h, wd = x.shape
+        cin2, cout, r, s = w.shape
+        oh = (h - 1) * stride - 2 * pad + (r - 1) + out_pad + 1
+        ow = (wd - 1) * stride - 2 * pad + (s - 1) + out_pad + 1
+        # mirrored conv: input [n, cout, oh, ow] -> output [n, cin, h, wd]
+        if conv_out_size(oh, r, stride, pad, 1) != h or conv_out_size(ow, s, stride, pad, 1) != wd:
+            raise _lib.SscgError("unsupported ConvTranspose2d geometry")
+        wt = _cached_wt(w)  # [Cout][R][S][Cin]
+        y = conv2d_dgrad(x, wt, (n, cout, oh, ow), (cin, cout, r, s), stride, pad, 1, bias, act, slope)
+        ctx.cfg = (stride, pad, act, slope)
+        ctx.has_bias = bias is not None
+        ctx.wref, ctx.bref = w, bias
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, slope = ctx.cfg
+        dy = to_nhwc(dy)
+        if act != ACT_NONE:
+            dy = act_bwd(dy, y, act, slope)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # gradient wrt x = forward of the mirrored conv applied to dy
+            dx = conv2d_fwd(dy, w, None, stride, pad, 1)
+        if ctx.needs_input_grad[1]:
+            # mirrored conv has input dy (as "x") and output-gradient x (as "dy")
+            acc = getattr(ctx.wref, "_sscg_grad", None)
+            if acc is not None:
+                conv2d_wgrad(dy, x, w.shape, stride, pad, 1, out=acc, accumulate=True)
+            else:
+                dw = conv2d_wgrad(dy, x, w.shape, stride, pad, 1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            n, k, p, q = dy.shape
+            acc = getattr(ctx.bref, "_sscg_grad", None)
+            if acc is not None:
+                colsum(n * p * q, k, dy, out=acc, accumulate=True)
+            else:
+                db = colsum(n * p * q, k, dy)
+        return dx, dw, db, None, None, None, None, None
+
+
+class NormActFn(torch.autograd.Function):
+    """InstanceNorm2d / BatchNorm2d (+ residual add) + activation, one statistics pass + one apply pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, per_sample, training, momentum, eps, act, slope):
+        x = to_nhwc(x)
+        if residual is not None:
+            residual = to_nhwc(residual)
+        use_batch_stats = training or running_mean is None
+        if use_batch_stats:
+            upd = training and running_mean is not None and not per_sample
+            mean, rstd = norm_stats(x, per_sample, eps, running_mean if upd else None, running_var if upd else None, momentum)
+        else:
+            mean = running_mean.view(1, -1)
+            rstd = rstd_from_var(running_var, eps).view(1, -1)
+        y = norm_apply(x, mean, rstd, gamma, beta, residual, per_sample, act, slope)
+        ctx.cfg = (per_sample, act, slope, use_batch_stats, residual is not None)
+        ctx.gref, ctx.betaref = gamma, beta
+        ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd, gamma = ctx.saved_tensors
+        per_sample, act, slope, stats_grad, has_res = ctx.cfg
+        dy = to_nhwc(dy)
+        want_g = gamma is not None and ctx.needs_input_grad[1]
+        dgamma = dbeta = None
+        ret_g = ret_b = None
+        if want_g:
+            dgamma = getattr(ctx.gref, "_sscg_grad", None)
+            dbeta = getattr(ctx.betaref, "_sscg_grad", None)
+            if dgamma is None or dbeta is None:
+                dgamma = torch.empty_like(gamma)
+                dbeta = torch.empty_like(gamma)
+                fill_(dgamma, 0.0)
+                fill_(dbeta, 0.0)
+                ret_g, ret_b = dgamma, dbeta
+        dx, dres = norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad,
+                            want_dres=has_res and ctx.needs_input_grad[3], dgamma=dgamma, dbeta=dbeta)
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        return dx, ret_g, ret_b, dres, None, None, None, None, None, None, None, None
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        _need_hip(x)
+        if not (x.is_contiguous() or x.is_contiguous(memory_format=CL)):
+            x = x.contiguous()
+        y = act_fwd(x, act, slope)
+        ctx.cfg = (act, slope)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        act, slope = ctx.cfg
+        if dy.stride() != y.stride():
+            dy = to_nhwc(dy) if y.is_contiguous(memory_format=CL) else dy.contiguous()
+        return act_bwd(dy, y, act, slope), None, None
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_nhwc(a), to_nhwc(b)
+        return add(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(0.5) in training mode.  The keep-mask is a pure function of (seed, element index)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = to_nhwc(x)
+        ctx.cfg = (p, seed)
+        return dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.cfg
+        return dropout(to_nhwc(dy), p, seed), None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x)
+        y, idx = maxpool_fwd(x)
+        ctx.xshape = tuple(x.shape)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return maxpool_bwd(to_nhwc(dy), idx, ctx.xshape)
+
+
+class UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        x = to_nhwc(x)
+        ctx.hw = (x.shape[2], x.shape[3])
+        return upsample_fwd(x, oh, ow)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return upsample_bwd(to_nhwc(dy), *ctx.hw), None, None
+
+
+class SoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = softmax_fwd(to_nhwc(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return softmax_bwd(to_nhwc(dy), y)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss()(logits [N,C,H,W], labels [N,H,W]) - mean over N*H*W."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = to_nhwc(logits)
+        labels = labels.contiguous()
+        n, c, h, w = logits.shape
+        if labels.numel() != n * h * w or labels.dtype != torch.int64:
+            raise _lib.SscgError("labels must be int64 with N*H*W elements")
+        loss = _scalar(logits.device)
+        ws = _loss_ws(logits.device)
+        check(lib.sscg_ce_fwd(logits.data_ptr(), labels.data_ptr(), n * h * w, c, loss.data_ptr(), ws.data_ptr(), ws.numel(),
+                              _stream()), "sscg_ce_fwd")
+        ctx.save_for_backward(logits, labels)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels = ctx.saved_tensors
+        n, c, h, w = logits.shape
+        dx = torch.empty_like(logits, memory_format=CL)
+        check(lib.sscg_ce_bwd(logits.data_ptr(), labels.data_ptr(), n * h * w, c, g.data_ptr(), 1.0, dx.data_ptr(), _stream()),
+              "sscg_ce_bwd")
+        return dx, None
+
+
+class MSEConstFn(torch.autograd.Function):
+    """nn.MSELoss()(x, full_like(x, target)) - the LSGAN terms."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        _need_hip(x)
+        if not (x.is_contiguous() or x.is_contiguous(memory_format=CL)):
+            x = x.contiguous()
+        loss = _scalar(x.device)
+        ws = _loss_ws(x.device)
+        check(lib.sscg_mse_const_fwd(x.data_ptr(), x.numel(), target, loss.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+              "sscg_mse_const_fwd")
+        ctx.target = target
+        ctx.save_for_backward(x)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x, memory_format=torch.preserve_format)
+        check(lib.sscg_mse_const_bwd(x.data_ptr(), x.numel(), ctx.target, g.data_ptr(), 1.0, dx.data_ptr(), _stream()),
+              "sscg_mse_const_bwd")
+        return dx, None
+
+
+class L1Fn(torch.autograd.Function):
+    """nn.L1Loss()(a, b); gradient flows to `a` only (b is data in the reference, model.py:461)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_nhwc(a), to_nhwc(b)
+        loss = _scalar(a.device)
+        ws = _loss_ws(a.device)
+        check(lib.sscg_l1_fwd(a.data_ptr(), b.data_ptr(), a.numel(), loss.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+              "sscg_l1_fwd")
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a, memory_format=CL)
+        check(lib.sscg_l1_bwd(a.data_ptr(), b.data_ptr(), a.numel(), g.data_ptr(), 1.0, da.data_ptr(), _stream()), "sscg_l1_bwd")
+        return da, None
+
+
+class WeightedSumFn(torch.autograd.Function):
+    """sum_i w_i * term_i over 0-dim device scalars (gen_loss, discriminator_loss)."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        n = len(terms)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in terms])
+        ws = (C.c_float * n)(*[float(w) for w in weights])
+        out = _scalar(terms[0].device)
+        check(lib.sscg_weighted_sum(ptrs, ws, n, out.data_ptr(), _stream()), "sscg_weighted_sum")
+        ctx.weights = [float(w) for w in weights]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = []
+        for w in ctx.weights:
+            gi = _scalar(g.device)
+            ptrs = (C.c_void_p * 1)(g.data_ptr())
+            ws = (C.c_float * 1)(w)
+            check(lib.sscg_weighted_sum(ptrs, ws, 1, gi.data_ptr(), _stream()), "sscg_weighted_sum")
+            grads.append(gi)
+        return (None, *grads)
+
+
+# functional spellings
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0):
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil, pad_mode, act, slope)
+
+
+def conv_transpose2d(x, w, bias=None, stride=1, pad=0, out_pad=0, act=ACT_NONE, slope=0.0):
+    return ConvTranspose2dFn.apply(x, w, bias, stride, pad, out_pad, act, slope)
+
+
+def instance_norm_act(x, act=ACT_NONE, slope=0.0, residual=None, eps=1e-5):
+    return NormActFn.apply(x, None, None, residual, None, None, True, True, 0.0, eps, act, slope)
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
+                   residual=None):
+    return NormActFn.apply(x, gamma, beta, residual, running_mean, running_var, False, training, momentum, eps, act, slope)
+
+
+def upsample_bilinear(x, size):
+    return UpsampleFn.apply(x, int(size[0]), int(size[1]))
+
+
+def softmax2d(x):
+    return SoftmaxFn.apply(x)
+
+
+def cross_entropy(logits, labels):
+    return CrossEntropyFn.apply(logits, labels)
+
+
+def mse_const(x, target):
+    return MSEConstFn.apply(x, float(target))
+
+
+def l1_loss(a, b):
+    return L1Fn.apply(a, b)
+
+
+def weighted_sum(terms, weights):
+    return WeightedSumFn.apply(list(weights), *terms)

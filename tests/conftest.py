@@ -1,0 +1,38 @@
+"""Test configuration: registers the `gpu` marker and exposes the package (its directory name contains
+hyphens, so it is imported through importlib)."""
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PKG_NAME = "semi-supervised-segmentation-cyclegan_amd"
+
+
+def load_pkg():
+    return importlib.import_module(PKG_NAME)
+
+
+def load_sub(name):
+    return importlib.import_module(PKG_NAME + "." + name)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def F():
+    return load_sub("functional")
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

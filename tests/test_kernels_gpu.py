@@ -1,0 +1,338 @@
+"""Kernel-level parity: every HIP kernel (through the C ABI) against the torch CPU op the reference
+calls at that site, evaluated in fp64.  Tolerances are relative to the largest reference magnitude."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+CL = torch.channels_last
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def gpu(t, dev):
+    return t.float().to(dev).contiguous(memory_format=CL) if t.dim() == 4 else t.float().to(dev)
+
+
+# (N, C, H, W, K, R, stride, pad, dil, reflect, bias, act)
+CONV_CASES = [
+    (2, 256, 33, 33, 256, 3, 1, 2, 2, 0, 0, 0),    # DeepLab layer3 conv2 (generators.py:331, dilation 2)
+    (2, 512, 17, 17, 512, 3, 1, 4, 4, 0, 0, 0),    # layer4 conv2
+    (2, 64, 33, 33, 64, 3, 1, 1, 1, 0, 0, 0),      # layer1 conv2
+    (2, 3, 64, 64, 64, 7, 2, 3, 1, 0, 0, 0),       # conv1 (3-channel image)
+    (2, 21, 64, 64, 64, 7, 2, 3, 1, 0, 0, 0),      # conv1 (21-channel one-hot)
+    (2, 2048, 9, 9, 21, 3, 1, 6, 6, 0, 1, 0),      # classifier, dilation 6, bias
+    (2, 2048, 9, 9, 3, 3, 1, 12, 12, 0, 1, 0),     # classifier, dilation 12 (pad > feature map)
+    (2, 256, 33, 33, 512, 1, 2, 0, 1, 0, 0, 0),    # 1x1 stride-2 downsample
+    (2, 1024, 17, 17, 256, 1, 1, 0, 1, 0, 0, 0),   # 1x1 bottleneck
+    (2, 64, 32, 32, 128, 3, 2, 1, 1, 0, 1, 0),     # ResnetGenerator down conv
+    (2, 256, 16, 16, 256, 3, 1, 1, 1, 1, 1, 0),    # ResidualBlock conv, reflection pad 1
+    (2, 21, 32, 32, 64, 7, 1, 3, 1, 1, 1, 0),      # ResnetGenerator stem, reflection pad 3
+    (2, 64, 32, 32, 3, 7, 1, 3, 1, 1, 1, 3),       # ResnetGenerator head + tanh
+    (2, 3, 32, 32, 64, 1, 1, 0, 1, 0, 1, 2),       # PixelDiscriminator conv1 + LeakyReLU
+    (2, 128, 32, 32, 1, 1, 1, 0, 1, 0, 1, 0),      # PixelDiscriminator conv3
+    (2, 21, 32, 32, 64, 4, 2, 1, 1, 0, 1, 2),      # PatchGAN conv1
+    (2, 128, 16, 16, 256, 4, 2, 1, 1, 0, 1, 0),    # PatchGAN conv3
+    (2, 256, 9, 9, 512, 4, 1, 1, 1, 0, 1, 0),      # PatchGAN conv4 (stride 1)
+    (1, 20, 17, 19, 36, 3, 1, 1, 1, 0, 1, 1),      # ragged everything + relu
+]
+
+
+def ref_conv(x, w, b, stride, pad, dil, reflect, act):
+    if reflect:
+        x = TF.pad(x, (pad, pad, pad, pad), mode="reflect")
+        pad = 0
+    y = TF.conv2d(x, w, b, stride, pad, dil)
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = TF.leaky_relu(y, 0.2)
+    elif act == 3:
+        y = torch.tanh(y)
+    return y
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, F, dev):
+    N, C, H, W, K, R, stride, pad, dil, reflect, bias, act = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(K, C, R, R, generator=g, dtype=torch.float64) * 0.05
+    b = torch.randn(K, generator=g, dtype=torch.float64) if bias else None
+    xr = x.clone().requires_grad_(not reflect)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = ref_conv(xr, wr, br, stride, pad, dil, reflect, act)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+
+    xg = gpu(x, dev).requires_grad_(not reflect)
+    wg = gpu(w, dev).requires_grad_(True)
+    bg = gpu(b, dev).requires_grad_(True) if bias else None
+    yg = F.conv2d(xg, wg, bg, stride, pad, dil, 1 if reflect else 0, act, 0.2)
+    assert tuple(yg.shape) == tuple(yr.shape)
+    assert rel_err(yg, yr) < 2e-5
+    yg.backward(gpu(gy, dev))
+    assert rel_err(wg.grad, wr.grad) < 5e-5
+    if bias:
+        assert rel_err(bg.grad, br.grad) < 2e-5
+    if not reflect:
+        assert rel_err(xg.grad, xr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+def test_conv_all_tile_configs(cfg, F, dev):
+    lib = F.lib
+    g = torch.Generator().manual_seed(cfg)
+    x = torch.randn(2, 64, 21, 23, generator=g, dtype=torch.float64)
+    w = torch.randn(96, 64, 3, 3, generator=g, dtype=torch.float64) * 0.05
+    yr = TF.conv2d(x, w, None, 1, 1, 1)
+    try:
+        lib.sscg_debug_set_conv_cfg(cfg)
+        yg = F.conv2d_fwd(gpu(x, dev), gpu(w, dev), None, 1, 1, 1)
+        gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+        wt = F.weight_transposed(gpu(w, dev))
+        dx = F.conv2d_dgrad(gpu(gy, dev), wt, x.shape, w.shape, 1, 1, 1)
+    finally:
+        lib.sscg_debug_set_conv_cfg(-1)
+    assert rel_err(yg, yr) < 2e-5
+    dxr = torch.autograd.grad(TF.conv2d(x.requires_grad_(True), w, None, 1, 1, 1), x, gy)[0]
+    assert rel_err(dx, dxr) < 2e-5
+
+
+def test_conv_mfma_layout_asymmetric(F, dev):
+    """A = identity-like probe with an asymmetric weight catches transposed fragment layouts."""
+    C = K = 64
+    x = torch.zeros(1, C, 8, 8, dtype=torch.float64)
+    for c in range(C):
+        x[0, c, c % 8, (c // 8) % 8] = 1.0 + c
+    w = torch.arange(K * C, dtype=torch.float64).reshape(K, C, 1, 1) / (K * C)
+    yr = TF.conv2d(x, w)
+    yg = F.conv2d_fwd(gpu(x, dev), gpu(w, dev), None)
+    assert rel_err(yg, yr) < 1e-6
+
+
+@pytest.mark.parametrize("geom", [(2, 256, 16, 16, 128, 1), (2, 128, 16, 16, 64, 1), (1, 64, 9, 11, 24, 0)])
+def test_conv_transpose(geom, F, dev):
+    N, Cin, H, W, Cout, bias = geom
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Cin, Cout, 3, 3, generator=g, dtype=torch.float64) * 0.05
+    b = torch.randn(Cout, generator=g, dtype=torch.float64) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = TF.conv_transpose2d(xr, wr, br, 2, 1, 1)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xg, wg = gpu(x, dev).requires_grad_(True), gpu(w, dev).requires_grad_(True)
+    bg = gpu(b, dev).requires_grad_(True) if bias else None
+    yg = F.conv_transpose2d(xg, wg, bg, 2, 1, 1)
+    assert tuple(yg.shape) == tuple(yr.shape)
+    assert rel_err(yg, yr) < 2e-5
+    yg.backward(gpu(gy, dev))
+    assert rel_err(xg.grad, xr.grad) < 2e-5
+    assert rel_err(wg.grad, wr.grad) < 5e-5
+    if bias:
+        assert rel_err(bg.grad, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("per_sample", [True, False])
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(2, 64, 17, 19), (3, 256, 9, 9), (2, 2048, 5, 5), (2, 20, 8, 8)])
+def test_norm_act(per_sample, act, shape, F, dev):
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(shape, generator=g, dtype=torch.float64) * 2 + 0.7
+    res = torch.randn(shape, generator=g, dtype=torch.float64)
+    gamma = torch.randn(C, generator=g, dtype=torch.float64) * 0.1 + 1
+    beta = torch.randn(C, generator=g, dtype=torch.float64) * 0.1
+    rm0 = torch.randn(C, generator=g, dtype=torch.float64) * 0.1
+    rv0 = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    gr, btr = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    if per_sample:
+        yr = TF.instance_norm(xr, eps=1e-5) + rr
+    else:
+        yr = TF.batch_norm(xr, rm, rv, gr, btr, True, 0.1, 1e-5) + rr
+    if act == 1:
+        yr = torch.relu(yr)
+    elif act == 2:
+        yr = TF.leaky_relu(yr, 0.2)
+    gy = torch.randn(shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+
+    xg, rg = gpu(x, dev).requires_grad_(True), gpu(res, dev).requires_grad_(True)
+    if per_sample:
+        yg = F.instance_norm_act(xg, act, 0.2, residual=rg)
+    else:
+        gg, bg = gpu(gamma, dev).requires_grad_(True), gpu(beta, dev).requires_grad_(True)
+        rmg, rvg = gpu(rm0, dev), gpu(rv0, dev)
+        yg = F.batch_norm_act(xg, gg, bg, rmg, rvg, True, 0.1, 1e-5, act, 0.2, residual=rg)
+    assert rel_err(yg, yr) < 1e-5
+    yg.backward(gpu(gy, dev))
+    assert rel_err(xg.grad, xr.grad) < 2e-5
+    assert rel_err(rg.grad, rr.grad) < 1e-6
+    if not per_sample:
+        assert rel_err(gg.grad, gr.grad) < 1e-5
+        assert rel_err(bg.grad, btr.grad) < 1e-5
+        assert rel_err(rmg, rm) < 1e-6
+        assert rel_err(rvg, rv) < 1e-6
+
+
+def test_bn_eval_and_frozen_affine(F, dev):
+    shape = (2, 64, 9, 9)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g, dtype=torch.float64)
+    gamma = torch.randn(64, generator=g, dtype=torch.float64) * 0.1 + 1
+    beta = torch.randn(64, generator=g, dtype=torch.float64) * 0.1
+    rm = (torch.randn(64, generator=g) * 0.1).double()   # fp32-representable: compared bit-exactly below
+    rv = (torch.rand(64, generator=g) + 0.5).double()
+    xr = x.clone().requires_grad_(True)
+    yr = torch.relu(TF.batch_norm(xr, rm.clone(), rv.clone(), gamma, beta, False, 0.1, 1e-5))
+    gy = torch.randn(shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xg = gpu(x, dev).requires_grad_(True)
+    rmg, rvg = gpu(rm, dev), gpu(rv, dev)
+    yg = F.batch_norm_act(xg, gpu(gamma, dev), gpu(beta, dev), rmg, rvg, False, 0.1, 1e-5, 1, 0.0)
+    assert rel_err(yg, yr) < 1e-5
+    yg.backward(gpu(gy, dev))
+    assert rel_err(xg.grad, xr.grad) < 1e-5
+    assert rel_err(rmg, rm) == 0.0  # eval mode must not touch running stats
+
+
+@pytest.mark.parametrize("hw", [(128, 128), (64, 64), (33, 65), (9, 10)])
+def test_maxpool(hw, F, dev):
+    g = torch.Generator().manual_seed(3)
+    x = torch.relu(torch.randn(2, 64, *hw, generator=g)).double()  # fp32-representable, many ties at 0
+    xr = x.clone().requires_grad_(True)
+    yr = TF.max_pool2d(xr, 3, 2, 1, ceil_mode=True)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xg = gpu(x, dev).requires_grad_(True)
+    yg = F.MaxPoolFn.apply(xg)
+    assert tuple(yg.shape) == tuple(yr.shape)
+    assert rel_err(yg, yr) == 0.0
+    yg.backward(gpu(gy, dev))
+    assert rel_err(xg.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("geom", [(2, 21, 33, 33, 256, 256), (2, 3, 9, 9, 64, 64), (1, 4, 17, 17, 128, 128),
+                                  (2, 20, 5, 9, 32, 64), (1, 3, 1, 1, 8, 8)])
+def test_upsample(geom, F, dev):
+    N, C, H, W, OH, OW = geom
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    yr = TF.interpolate(xr, size=(OH, OW), mode="bilinear", align_corners=True)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xg = gpu(x, dev).requires_grad_(True)
+    yg = F.upsample_bilinear(xg, (OH, OW))
+    assert rel_err(yg, yr) < 1e-5   # fp32 interpolation weights (torch computes them in fp32 too)
+    yg.backward(gpu(gy, dev))
+    assert rel_err(xg.grad, xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("C", [21, 20, 4])
+def test_softmax_ce_losses(C, F, dev):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, C, 32, 32, generator=g, dtype=torch.float64) * 3
+    lab = torch.randint(0, C, (2, 32, 32), generator=g)
+    xr = x.clone().requires_grad_(True)
+    sr = torch.softmax(xr, 1)
+    gy = torch.randn(x.shape, generator=g, dtype=torch.float64)
+    sr.backward(gy)
+    xg = gpu(x, dev).requires_grad_(True)
+    sg = F.softmax2d(xg)
+    assert rel_err(sg, sr) < 1e-6
+    sg.backward(gpu(gy, dev))
+    assert rel_err(xg.grad, xr.grad) < 1e-5
+
+    xr2 = x.clone().requires_grad_(True)
+    lr_ = TF.cross_entropy(xr2, lab)
+    (lr_ * 0.37).backward()
+    xg2 = gpu(x, dev).requires_grad_(True)
+    lg = F.cross_entropy(xg2, lab.to(dev))
+    assert rel_err(lg, lr_) < 1e-6
+    F.weighted_sum([lg], [0.37]).backward()
+    assert rel_err(xg2.grad, xr2.grad) < 1e-5
+
+
+def test_mse_l1_weighted(F, dev):
+    g = torch.Generator().manual_seed(8)
+    a = torch.randn(2, 3, 32, 32, generator=g, dtype=torch.float64)
+    b = torch.randn(2, 3, 32, 32, generator=g, dtype=torch.float64)
+    d = torch.randn(2, 1, 32, 32, generator=g, dtype=torch.float64)
+    ar, dr = a.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    l1r = (ar - b).abs().mean()
+    m1r = ((dr - 1.0) ** 2).mean()
+    m0r = (dr ** 2).mean()
+    tot_r = 1.0 * l1r + 0.5 * m1r + 2.0 * m0r
+    tot_r.backward()
+    ag, dg = gpu(a, dev).requires_grad_(True), gpu(d, dev).requires_grad_(True)
+    l1g = F.l1_loss(ag, gpu(b, dev))
+    m1g = F.mse_const(dg, 1.0)
+    m0g = F.mse_const(dg, 0.0)
+    tot = F.weighted_sum([l1g, m1g, m0g], [1.0, 0.5, 2.0])
+    for u, v in ((l1g, l1r), (m1g, m1r), (m0g, m0r), (tot, tot_r)):
+        assert rel_err(u, v) < 1e-6
+    tot.backward()
+    assert rel_err(ag.grad, ar.grad) < 1e-6
+    assert rel_err(dg.grad, dr.grad) < 1e-6
+
+
+def test_argmax_onehot_bit_exact(F, dev):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 21, 32, 32, generator=g)
+    x[:, 5] = x[:, 3]  # forced ties: the lower index must win (torch.max(dim) rule)
+    x[0, :, 0, 0] = 1.0
+    idx_r = x.max(1)[1]
+    oh_r = torch.zeros_like(x).scatter_(1, idx_r.unsqueeze(1), 1.0)
+    oh_g, idx_g = F.argmax_onehot(gpu(x, dev), want_index=True)
+    assert torch.equal(idx_g.cpu(), idx_r)
+    assert torch.equal(oh_g.cpu().contiguous(), oh_r)
+    lab = torch.randint(0, 21, (2, 1, 32, 32), generator=g)
+    oh2 = F.label_onehot(lab.to(dev), 21)
+    assert torch.equal(oh2.cpu().contiguous(), torch.zeros(2, 21, 32, 32).scatter_(1, lab, 1.0))
+
+
+def test_adam_matches_torch(F, dev):
+    g = torch.Generator().manual_seed(10)
+    p0 = torch.randn(10007, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=2e-4, betas=(0.5, 0.999))
+    pg = p0.clone().to(dev)
+    m = torch.zeros_like(pg)
+    v = torch.zeros_like(pg)
+    for step in range(1, 4):
+        gr = torch.randn(10007, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        F.adam_step(pg, gr.to(dev), m, v, 2e-4, 0.5, 0.999, 1e-8, step)
+    assert rel_err(pg, pr) < 1e-6
+    assert rel_err(m, opt.state[pr]["exp_avg"]) < 1e-6
+    assert rel_err(v, opt.state[pr]["exp_avg_sq"]) < 1e-6
+
+
+def test_layout_roundtrip_and_dropout(F, dev):
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 21, 17, 19, generator=g).to(dev)
+    y = F.to_nhwc(x)
+    assert y.is_contiguous(memory_format=CL) and torch.equal(y.cpu(), x.cpu())
+    z = F.to_nchw(y)
+    assert z.is_contiguous() and torch.equal(z.cpu(), x.cpu())
+    big = torch.ones(4, 64, 32, 32, device=dev).contiguous(memory_format=CL)
+    d1 = F.dropout(big, 0.5, 1234)
+    d2 = F.dropout(big, 0.5, 1234)
+    assert torch.equal(d1, d2)
+    keep = (d1 != 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.01
+    assert set(d1.unique().cpu().tolist()) == {0.0, 2.0}
+    rp = F.reflect_pad(y, 3)
+    assert torch.equal(rp.cpu().contiguous(), TF.pad(x.cpu(), (3, 3, 3, 3), mode="reflect"))
