@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""Throughput of the hot path: full G+D training steps of the semi-supervised CycleGAN on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]: VOC2012 21-class, 256x256, semisupervised_cycleGAN, batch 8 per GPU, fp32,
+random-init weights (the reference's N(0,0.02) init), synthetic image/label batches already resident in HBM.
+One step = one iteration of /root/reference model.py:370-552 as written (all seven networks, both optimisers).
+Weak scaling: every rank runs batch 8; `value` = N * 8 * K / (max-over-ranks wall time of K steps).
+
+Besides the contract line this prints, in the same JSON object:
+  roofline     - the implicit-GEMM conv kernels measured live with HIP events on the launch stream during one
+                 extra (untimed) step: algorithmic FLOP / kernel time against the fp32 MFMA peak (157.3 TFLOP/s);
+  cpu_baseline - oracle/ (the CPU restatement of the reference) timed on this box's host cores on a bounded
+                 sample (rank 0, N = 1 only).
+"""
+import argparse
+import contextlib
+import importlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "semi-supervised-segmentation-cyclegan_amd"
+
+PEAK_F32_MFMA_TFLOPS = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+STEP_TFLOP_PER_PAIR = 1.983             # conv FLOP of one as-written step per labeled/unlabeled pair @VOC 256x256
+C, H, W, B = 21, 256, 256, 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--batch", type=int, default=B)
+    a = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    md = importlib.import_module(PKG + ".model")
+    F = importlib.import_module(PKG + ".functional")
+    par = importlib.import_module(PKG + ".parallel")
+    data = importlib.import_module(PKG + ".data")
+    from oracle import fixtures as FX   # only make_args (namespace of CLI defaults) and, below, the CPU baseline
+
+    dp = par.DataParallel() if world > 1 else None
+    rank = dp.rank if dp else 0
+    local = dp.local_rank if dp else 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    bsz = a.batch
+
+    args = FX.make_args(dataset="voc2012", crop_height=H, crop_width=W, batch_size=bsz, gpu_ids=[local], no_dropout=False,
+                        checkpoint_dir="/tmp/sscg_bench_ckpt_%d" % rank, as_written=True, epochs=400, decay_epoch=100)
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = md.semisuper_cycleGAN(args, data_parallel=dp)
+
+    # synthetic batches, resident in HBM before the clock starts (rank-offset seeds)
+    nb = a.warmup + a.steps + 1
+    lab = list(data.SyntheticLoader(bsz, C, H, W, nb, 1 + 1000 * rank, device=dev))
+    unl = list(data.SyntheticLoader(bsz, C, H, W, nb, 2 + 1000 * rank, device=dev))
+
+    def run(i):
+        return model.step(lab[i][0], lab[i][1], unl[i][0])
+
+    for i in range(a.warmup):
+        run(i)
+    if dp:
+        dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, a.warmup + a.steps):
+        losses = run(i)
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    dt = time.perf_counter() - t0
+    dt = par.max_over_ranks(dt)
+    finite = all(bool(torch.isfinite(v)) for v in losses.values())
+
+    value = world * bsz * a.steps / dt
+    out = {
+        "metric": "training images/sec (G+D step) at 256x256", "value": round(value, 4), "unit": "img/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "VOC2012 21-class 256x256 semisupervised_cycleGAN as-written G+D step, batch=%d per GPU, fp32" % bsz,
+                   "global_batch": world * bsz, "image_unit": "one labeled + one unlabeled 256x256 image", "parallelism": "dp%d" % world,
+                   "losses_finite": finite},
+        "step_conv_tflops": round(world * bsz * STEP_TFLOP_PER_PAIR * a.steps / dt, 2),
+        "step_frac_of_f32_mfma_peak": round(bsz * STEP_TFLOP_PER_PAIR * a.steps / dt / PEAK_F32_MFMA_TFLOPS, 4),
+    }
+
+    if rank == 0 and not a.no_roofline:
+        with F.ConvProfile() as prof:
+            run(a.warmup + a.steps)
+        summ = prof.summary()
+        kc = {"flops": 0.0, "ms": 0.0, "launches": 0}
+        for kind in ("fwd", "dgrad"):
+            if kind in summ:
+                for f in kc:
+                    kc[f] += summ[kind][f]
+        tf = kc["flops"] / (kc["ms"] * 1e-3) / 1e12 if kc["ms"] > 0 else 0.0
+        out["roofline"] = {
+            "kernel": "conv_kc_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": kc["launches"], "avg_launch_us": round(1e3 * kc["ms"] / max(kc["launches"], 1), 2),
+            "flop_per_launch_avg": round(kc["flops"] / max(kc["launches"], 1)),
+            "conv_ms_per_step": {k: round(v["ms"], 2) for k, v in summ.items()},
+            "conv_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in summ.items() if v["ms"] > 0},
+        }
+        # the 3x3 family north_star singles out (3x3 convs only)
+        f3 = m3 = 0.0
+        for kind, v in summ.items():
+            for key, (n, fl, ms) in v["shapes"].items():
+                if " r3 " in key:
+                    f3 += fl
+                    m3 += ms
+        if m3 > 0:
+            out["roofline"]["conv3x3_tflops"] = round(f3 / (m3 * 1e-3) / 1e12, 2)
+            out["roofline"]["conv3x3_frac"] = round(f3 / (m3 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+        if os.environ.get("SSCG_BENCH_SHAPES"):
+            rows = []
+            for kind, v in summ.items():
+                for key, (n, fl, ms) in v["shapes"].items():
+                    rows.append((ms, kind, key, n, fl / (ms * 1e-3) / 1e12))
+            rows.sort(reverse=True)
+            with open(os.environ["SSCG_BENCH_SHAPES"], "w") as f:
+                for ms, kind, key, n, tfl in rows:
+                    f.write("%8.3f ms  %-5s %-40s x%-3d %6.1f TF/s\n" % (ms, kind, key, n, tfl))
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline():
+    """oracle/ = CPU restatement of the reference step (validated bit-exact against the reference's losses by
+    tools/gen_golden.py), timed on this box's host cores: one step at the bench geometry with batch 2."""
+    import numpy as np
+    import torch
+    from oracle import fixtures as FX
+    from oracle import step as ostep
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    bs = 2
+    sds = FX.semisup_state_dicts(C, torch.float32, "bench")
+    o = ostep.SemiSupOracle(C, sds, crop=(H, W))
+    l_img, l_gt, unl_img = FX.step_batch("bench", 0, C, H, W, bs)
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    o.step(l_img, l_gt, unl_img)
+    dt = time.perf_counter() - t0
+    return {"value": round(bs / dt, 4), "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": "1 full G+D step (no warm-up), VOC 21-class 256x256, batch 2, torch %s CPU fp32, %d threads of %d host cores"
+                      % (torch.__version__, threads, cores), "seconds": round(dt, 2)}
+
+
+if __name__ == "__main__":
+    main()

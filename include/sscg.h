@@ -115,6 +115,7 @@ int sscg_upsample_bilinear_fwd(const float* x, float* y, int N, int H, int W, in
 int sscg_upsample_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, void* stream);
 /* nn.ReflectionPad2d as a materialised copy (only for callers that cannot fold it) */
 int sscg_reflect_pad(const float* x, float* y, int N, int H, int W, int C, int pad, void* stream);
+int sscg_reflect_pad_bwd(const float* dy, float* dx, int N, int H, int W, int C, int pad, void* stream);
 /* layout plumbing at the NCHW boundary of the reference's module interface */
 int sscg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
 int sscg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);

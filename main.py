@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Command line of the reference (main.py:10-87) driving the MI355X build: same flags, same defaults, same
+dispatch on --training / --model.  Extra flags (never change a reference default): --synthetic_steps,
+--as_written.  Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N main.py ...`
+(one process per MI355X; gradients all-reduced with RCCL)."""
+import importlib
+import os
+import sys
+from argparse import ArgumentParser
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+PKG = "semi-supervised-segmentation-cyclegan_amd"
+
+# (flag, type, default) - verbatim from the reference, including its quirks: `type=bool` flags are true for
+# ANY non-empty string and the loss weights are type=int with float defaults
+FLAGS = [
+    ("epochs", int, 400), ("decay_epoch", int, 100), ("batch_size", int, 2), ("lr", float, .0002), ("gpu_ids", str, "0"),
+    ("crop_height", int, None), ("crop_width", int, None), ("lamda_img", int, 0.5), ("lamda_gt", int, 0.1),
+    ("lamda_perceptual", int, 0), ("lab_CE_weight", int, 1), ("lab_MSE_weight", int, 1), ("lab_perceptual_weight", int, 0),
+    ("adversarial_weight", int, 1.0), ("discriminator_weight", int, 1.0), ("training", bool, False), ("testing", bool, False),
+    ("validation", bool, False), ("model", str, "supervised_model"), ("results_dir", str, "./results"),
+    ("validation_dir", str, "./val_results"), ("checkpoint_dir", str, "./checkpoints/semisupervised_cycleGAN"),
+    ("ngf", int, 64), ("ndf", int, 64), ("gen_net", str, "deeplab"), ("dis_net", str, "fc_disc"),
+]
+DEFAULT_CROP = {"voc2012": (320, 320), "acdc": (256, 256), "cityscapes": (512, 1024)}   # main.py:60-67
+
+
+def get_args(argv=None):
+    parser = ArgumentParser(description="cycleGAN PyTorch (MI355X-native build)")
+    for name, typ, default in FLAGS:
+        parser.add_argument("--" + name, type=typ, default=default)
+    parser.add_argument("--dataset", type=str, choices=["voc2012", "cityscapes", "acdc"], default="voc2012")
+    parser.add_argument("--norm", type=str, default="instance", help="instance normalization or batch normalization")
+    parser.add_argument("--no_dropout", action="store_true", help="no dropout for the generator")
+    # build-only additions
+    parser.add_argument("--synthetic_steps", type=int, default=8, help="iterations per epoch of the synthetic loaders")
+    parser.add_argument("--as_written", type=int, default=1, help="1: also run the forwards whose outputs the reference never uses")
+    return parser.parse_args(argv)
+
+
+def main(argv=None):
+    args = get_args(argv)
+    args.gpu_ids = [int(s) for s in args.gpu_ids.split(",") if int(s) >= 0]
+    args.as_written = bool(args.as_written)
+    if args.crop_height is None and args.crop_width is None:
+        args.crop_height, args.crop_width = DEFAULT_CROP[args.dataset]
+    md = importlib.import_module(PKG + ".model")
+    dp = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        par = importlib.import_module(PKG + ".parallel")
+        dp = par.DataParallel()
+        args.gpu_ids = [dp.local_rank]
+    if args.training:
+        if args.model == "semisupervised_cycleGAN":
+            print("Training semi-supervised cycleGAN")
+            md.semisuper_cycleGAN(args, data_parallel=dp).train(args)
+        if args.model == "supervised_model":
+            print("Training base model")
+            md.supervised_model(args).train(args)
+    if args.testing or args.validation:
+        raise SystemExit("testing.py / validation.py (PNG-dumping inference scripts) are outside the hot path (SURVEY section 2)")
+
+
+if __name__ == "__main__":
+    main()

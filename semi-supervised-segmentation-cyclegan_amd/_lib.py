@@ -60,6 +60,7 @@ SIGNATURES = {
     "sscg_upsample_bilinear_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sscg_upsample_bilinear_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sscg_reflect_pad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "sscg_reflect_pad_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "sscg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "sscg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "sscg_softmax_fwd": (_i, [_p, _p, _i64, _i, _p]),

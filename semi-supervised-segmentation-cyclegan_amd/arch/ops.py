@@ -1,0 +1,333 @@
+"""Operator surface of the reference's arch/ops.py:7-80, backed by libsscg.so.
+
+Same factory names, argument order and state_dict keys (`0.weight`, `0.bias`, `1.*` inside a
+conv_norm_* block; `res_block.{1.0,3|4}.*` inside a ResidualBlock), so checkpoints interchange with the
+reference.  What differs is the execution: a block is evaluated as fused HIP launches
+(conv [+bias] -> one statistics pass -> normalise+activation[+residual]), ReflectionPad2d is folded into
+the conv's tile loader, and every tensor is channels-last in memory.
+"""
+import functools
+
+import torch
+from torch import nn
+
+from .. import functional as F
+from .._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PAD_REFLECT, PAD_ZEROS, SscgError
+
+CL = torch.channels_last
+
+
+# ----------------------------------------------------------------------------- leaf modules
+class Conv2d(nn.Module):
+    """nn.Conv2d twin (square kernels, as everywhere in the reference); weight is channels-last."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = kernel_size, stride, padding, dilation
+        w = torch.empty(out_channels, in_channels, kernel_size, kernel_size).contiguous(memory_format=CL)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        with torch.no_grad():
+            self.weight.copy_(torch.empty(w.shape).normal_(0.0, 0.02))
+
+    def forward(self, x, reflect=0, act=ACT_NONE, slope=0.0):
+        if reflect:
+            if self.padding != 0:
+                raise SscgError("reflection padding folds only into an unpadded conv")
+            if torch.is_grad_enabled() and x.requires_grad:
+                # the frozen generators are the reference's only reflect users (model.py:225-228); a training
+                # caller gets a materialised pad whose adjoint is a separate kernel
+                x = ReflectPadFn.apply(x, reflect)
+                return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, PAD_ZEROS, act, slope)
+            return F.conv2d(x, self.weight, self.bias, self.stride, reflect, self.dilation, PAD_REFLECT, act, slope)
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, PAD_ZEROS, act, slope)
+
+    def extra_repr(self):
+        return "%d, %d, k=%d, s=%d, p=%d, d=%d" % (self.in_channels, self.out_channels, self.kernel_size, self.stride,
+                                                  self.padding, self.dilation)
+
+
+class ReflectPadFn(torch.autograd.Function):
+    """Materialised nn.ReflectionPad2d with its adjoint (scatter-add expressed through the upsampling-free path:
+    gradient of a pad is a sum of mirrored slices; evaluated with the weight-free identity conv kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        x = F.to_nhwc(x)
+        ctx.pad = pad
+        ctx.shape = tuple(x.shape)
+        return F.reflect_pad(x, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return F.reflect_pad_bwd(F.to_nhwc(dy), ctx.pad), None
+
+
+class ConvTranspose2d(nn.Module):
+    """nn.ConvTranspose2d twin; weight logical [Cin, Cout, k, k], channels-last memory."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.output_padding = kernel_size, stride, padding, output_padding
+        w = torch.empty(in_channels, out_channels, kernel_size, kernel_size).contiguous(memory_format=CL)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        with torch.no_grad():
+            self.weight.copy_(torch.empty(w.shape).normal_(0.0, 0.02))
+
+    def forward(self, x, act=ACT_NONE, slope=0.0):
+        return F.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope)
+
+
+class InstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(affine=False, track_running_stats=False) (arch/ops.py:11): no state."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+
+    def forward(self, x, act=ACT_NONE, slope=0.0, residual=None):
+        return F.instance_norm_act(x, act, slope, residual, self.eps)
+
+
+class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d twin (affine, running statistics).  `num_batches_tracked` is counted on the host and
+    written to its buffer when the state dict is taken, so a forward launches no bookkeeping kernel."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending = 0
+        self._register_state_dict_hook(BatchNorm2d._flush_hook)
+
+    @staticmethod
+    def _flush_hook(module, state_dict, prefix, local_metadata):
+        if module._pending:
+            module.num_batches_tracked += module._pending
+            module._pending = 0
+            state_dict[prefix + "num_batches_tracked"] = module.num_batches_tracked
+        return state_dict
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pending = 0
+        return super()._load_from_state_dict(*a, **k)
+
+    def batches_tracked(self):
+        return int(self.num_batches_tracked) + self._pending
+
+    def forward(self, x, act=ACT_NONE, slope=0.0, residual=None):
+        if self.training:
+            self._pending += 1
+        return F.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                self.momentum, self.eps, act, slope, residual)
+
+
+class _Act(nn.Module):
+    code, slope = ACT_NONE, 0.0
+
+    def forward(self, x):
+        return F.ActFn.apply(x, self.code, self.slope)
+
+
+class ReLU(_Act):
+    code = ACT_RELU
+
+    def __init__(self, inplace=False):
+        super().__init__()
+
+
+class LeakyReLU(_Act):
+    code = ACT_LRELU
+
+    def __init__(self, negative_slope=0.01, inplace=False):
+        super().__init__()
+        self.slope = negative_slope
+
+
+class Tanh(_Act):
+    code = ACT_TANH
+
+
+class Dropout(nn.Module):
+    """nn.Dropout: counter-hash mask (seed advances per call; torch's Philox stream cannot be matched, so
+    parity runs use --no_dropout, SURVEY section 7 'hard parts')."""
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+        self._calls = 0
+        self.seed = 0x5eed
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        self._calls += 1
+        return F.DropoutFn.apply(x, self.p, (self.seed << 20) + self._calls)
+
+
+class ReflectionPad2d(nn.Module):
+    def __init__(self, padding):
+        super().__init__()
+        self.padding = padding
+
+    def forward(self, x):
+        return ReflectPadFn.apply(x, self.padding)
+
+
+# ----------------------------------------------------------------------------- fusing container
+def _is_norm(m):
+    return isinstance(m, (InstanceNorm2d, BatchNorm2d))
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential whose forward folds [ReflectionPad2d] Conv [Norm] [Activation] [+residual] runs into fused launches."""
+
+    def forward(self, x, reflect=0):
+        mods = list(self)
+        i, n = 0, len(mods)
+        while i < n:
+            m = mods[i]
+            if isinstance(m, ReflectionPad2d) and i + 1 < n and isinstance(mods[i + 1], (Conv2d, FusedSequential)):
+                reflect = m.padding
+                i += 1
+                continue
+            if isinstance(m, FusedSequential):
+                x = m(x, reflect=reflect)
+                reflect = 0
+                i += 1
+                continue
+            if isinstance(m, (Conv2d, ConvTranspose2d)):
+                nxt = mods[i + 1] if i + 1 < n else None
+                nx2 = mods[i + 2] if i + 2 < n else None
+                if _is_norm(nxt):
+                    x = m(x, reflect=reflect) if isinstance(m, Conv2d) else m(x)
+                    if isinstance(nx2, _Act):
+                        x = nxt(x, nx2.code, nx2.slope)
+                        i += 3
+                    else:
+                        x = nxt(x)
+                        i += 2
+                elif isinstance(nxt, _Act):
+                    x = m(x, reflect, nxt.code, nxt.slope) if isinstance(m, Conv2d) else m(x, nxt.code, nxt.slope)
+                    i += 2
+                else:
+                    x = m(x, reflect=reflect) if isinstance(m, Conv2d) else m(x)
+                    i += 1
+                reflect = 0
+                continue
+            if reflect:
+                raise SscgError("dangling ReflectionPad2d before %s" % type(m).__name__)
+            x = m(x)
+            i += 1
+        return x
+
+
+# ----------------------------------------------------------------------------- reference factories
+class NormLayer:
+    """What get_norm_layer returns: call it with a channel count to get the norm module.
+    (.func mirrors functools.partial so reference-style `norm_layer.func == nn.InstanceNorm2d` tests keep working.)"""
+
+    def __init__(self, kind):
+        self.kind = kind
+        self.func = nn.InstanceNorm2d if kind == "instance" else nn.BatchNorm2d
+
+    def __call__(self, num_features):
+        return InstanceNorm2d(num_features) if self.kind == "instance" else BatchNorm2d(num_features)
+
+
+def as_norm_layer(norm_layer):
+    """Accept this package's NormLayer, torch's nn.BatchNorm2d / nn.InstanceNorm2d classes, or a functools.partial of them."""
+    if isinstance(norm_layer, NormLayer):
+        return norm_layer
+    f = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
+    if f in (nn.InstanceNorm2d, InstanceNorm2d):
+        return NormLayer("instance")
+    if f in (nn.BatchNorm2d, BatchNorm2d):
+        return NormLayer("batch")
+    raise NotImplementedError("normalization layer [%s] is not found" % norm_layer)
+
+
+def get_norm_layer(norm_type="instance"):
+    if norm_type not in ("batch", "instance"):
+        raise NotImplementedError("normalization layer [%s] is not found" % norm_type)
+    return NormLayer(norm_type)
+
+
+def init_weights(net, init_type="normal", gain=0.02):
+    """arch/ops.py:16-28: Conv/Linear weights ~ N(0, gain), biases 0; BatchNorm2d weight ~ N(1, gain), bias 0."""
+    def visit(m):
+        cls = m.__class__.__name__
+        w = getattr(m, "weight", None)
+        if w is not None and (cls.find("Conv") != -1 or cls.find("Linear") != -1):
+            with torch.no_grad():
+                w.copy_(torch.empty(w.shape).normal_(0.0, gain))
+                if getattr(m, "bias", None) is not None:
+                    m.bias.zero_()
+        elif cls.find("BatchNorm2d") != -1:
+            with torch.no_grad():
+                m.weight.copy_(torch.empty(m.weight.shape).normal_(1.0, gain))
+                m.bias.zero_()
+
+    print("Network initialized with weights sampled from N(0,0.02).")
+    net.apply(visit)
+
+
+def init_network(net, gpu_ids=[]):
+    init_weights(net)   # drawn on the host (reproducible across devices), then moved
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        net.cuda(gpu_ids[0])
+    return net
+
+
+def conv_norm_lrelu(in_dim, out_dim, kernel_size, stride=1, padding=0, norm_layer=nn.BatchNorm2d, bias=False):
+    return FusedSequential(Conv2d(in_dim, out_dim, kernel_size, stride, padding, bias=bias),
+                           as_norm_layer(norm_layer)(out_dim), LeakyReLU(0.2, True))
+
+
+def conv_norm_relu(in_dim, out_dim, kernel_size, stride=1, padding=0, norm_layer=nn.BatchNorm2d, bias=False):
+    return FusedSequential(Conv2d(in_dim, out_dim, kernel_size, stride, padding, bias=bias),
+                           as_norm_layer(norm_layer)(out_dim), ReLU(True))
+
+
+def dconv_norm_relu(in_dim, out_dim, kernel_size, stride=1, padding=0, output_padding=0, norm_layer=nn.BatchNorm2d, bias=False):
+    return FusedSequential(ConvTranspose2d(in_dim, out_dim, kernel_size, stride, padding, output_padding, bias=bias),
+                           as_norm_layer(norm_layer)(out_dim), ReLU(True))
+
+
+class ResidualBlock(nn.Module):
+    """arch/ops.py:59-74: x + [RefPad1, conv3x3, norm, ReLU, (Dropout .5), RefPad1, conv3x3, norm](x).
+    The skip connection is added inside the second normalise pass."""
+
+    def __init__(self, dim, norm_layer, use_dropout, use_bias):
+        super().__init__()
+        nl = as_norm_layer(norm_layer)
+        blk = [ReflectionPad2d(1), conv_norm_relu(dim, dim, kernel_size=3, norm_layer=nl, bias=use_bias)]
+        if use_dropout:
+            blk += [Dropout(0.5)]
+        blk += [ReflectionPad2d(1), Conv2d(dim, dim, 3, padding=0, bias=use_bias), nl(dim)]
+        self.res_block = FusedSequential(*blk)
+
+    def forward(self, x):
+        mods = list(self.res_block)
+        h = mods[1](x, reflect=1)
+        k = 2
+        if isinstance(mods[k], Dropout):
+            h = mods[k](h)
+            k += 1
+        conv, norm = mods[k + 1], mods[k + 2]
+        h = conv(h, reflect=1)
+        return norm(h, ACT_NONE, 0.0, residual=x)
+
+
+def set_grad(nets, requires_grad=False):
+    for net in nets:
+        for param in net.parameters():
+            param.requires_grad = requires_grad

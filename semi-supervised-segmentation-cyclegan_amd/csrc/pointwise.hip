@@ -188,6 +188,30 @@ __global__ void reflect_pad_kernel(const float* __restrict__ x, float* __restric
     }
 }
 
+// adjoint of reflect_pad in gather form: every source pixel sums the (up to 3 x 3) padded positions that mirror onto it
+__global__ void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C, int pad) {
+    int OH = H + 2 * pad, OW = W + 2 * pad;
+    size_t total = (size_t)N * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c = (int)(i % C);
+        size_t t = i / C;
+        int ix = (int)(t % W); t /= W;
+        int iy = (int)(t % H);
+        int n = (int)(t / H);
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = iy + pad;
+        if (iy >= 1 && iy <= pad) ys[ny++] = pad - iy;
+        if (iy <= H - 2 && iy >= H - 1 - pad) ys[ny++] = 2 * (H - 1) - iy + pad;
+        xs[nx++] = ix + pad;
+        if (ix >= 1 && ix <= pad) xs[nx++] = pad - ix;
+        if (ix <= W - 2 && ix >= W - 1 - pad) xs[nx++] = 2 * (W - 1) - ix + pad;
+        float s = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) s += dy[((size_t)(n * OH + ys[a]) * OW + xs[b]) * C + c];
+        dx[i] = s;
+    }
+}
+
 // per image: in [R][Cc] -> out [Cc][R]   (32x32 LDS tiles)
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
     __shared__ float t[32][33];
@@ -295,6 +319,14 @@ extern "C" int sscg_reflect_pad(const float* x, float* y, int N, int H, int W, i
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || pad >= H || pad >= W) return SSCG_ERR_BAD_ARG;
     size_t total = (size_t)N * (H + 2 * pad) * (W + 2 * pad) * C;
     hipLaunchKernelGGL(reflect_pad_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, pad);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_reflect_pad_bwd(const float* dy, float* dx, int N, int H, int W, int C, int pad, void* stream) {
+    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || pad >= H || pad >= W) return SSCG_ERR_BAD_ARG;
+    size_t total = (size_t)N * H * W * C;
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C, pad);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

@@ -102,11 +102,59 @@ def make_desc(xshape, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, act=ACT_NONE
     return d
 
 
+# ----------------------------------------------------------------------------- per-kernel timing hook (bench.py)
+class ConvProfile:
+    """Collects (kind, algorithmic flops, HIP-event pair) for every conv launch while active.  Events are
+    recorded on torch's current stream - the stream the kernels are launched on."""
+
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        ConvProfile.active = self
+        return self
+
+    def __exit__(self, *a):
+        ConvProfile.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, flops, key, e0, e1 in self.records:
+            s = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0, "shapes": {}})
+            ms = e0.elapsed_time(e1)
+            s["launches"] += 1
+            s["flops"] += flops
+            s["ms"] += ms
+            sh = s["shapes"].setdefault(key, [0, 0.0, 0.0])
+            sh[0] += 1
+            sh[1] += flops
+            sh[2] += ms
+        return out
+
+
+def _timed(kind, d, fn):
+    prof = ConvProfile.active
+    if prof is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    flops = 2.0 * d.N * d.P * d.Q * d.K * d.R * d.S * d.C
+    key = "%dx%dx%d c%d k%d r%d s%d p%d d%d" % (d.N, d.H, d.W, d.C, d.K, d.R, d.stride, d.pad, d.dil)
+    prof.records.append((kind, flops, key, e0, e1))
+    return r
+
+
 # ----------------------------------------------------------------------------- raw ops
 def conv2d_fwd(x, w, bias, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0):
     d = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, act, slope)
     y = empty_nhwc(d.N, d.K, d.P, d.Q, x.device)
-    check(lib.sscg_conv2d_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _stream()), "sscg_conv2d_fwd")
+    _timed("fwd", d, lambda: check(lib.sscg_conv2d_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _stream()),
+                                   "sscg_conv2d_fwd"))
     return y
 
 
@@ -121,8 +169,8 @@ def weight_transposed(w):
 def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0):
     d = make_desc(xshape, wshape, stride, pad, dil)
     dx = empty_nhwc(d.N, d.C, d.H, d.W, dy.device)
-    check(lib.sscg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wt.data_ptr(), _ptr(bias), dx.data_ptr(), act, slope, _stream()),
-          "sscg_conv2d_dgrad")
+    _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wt.data_ptr(), _ptr(bias), dx.data_ptr(),
+                                                           act, slope, _stream()), "sscg_conv2d_dgrad"))
     return dx
 
 
@@ -134,8 +182,9 @@ def conv2d_wgrad(x, dy, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, out=None, 
         accumulate = False
     nb = lib.sscg_conv2d_wgrad_workspace(C.byref(d))
     ws = _WS.get(nb, x.device)
-    check(lib.sscg_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), out.data_ptr(), 1.0 if accumulate else 0.0,
-                                ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_wgrad")
+    _timed("wgrad", d, lambda: check(lib.sscg_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), out.data_ptr(),
+                                                           1.0 if accumulate else 0.0, ws.data_ptr(), ws.numel(), _stream()),
+                                     "sscg_conv2d_wgrad"))
     return out
 
 
@@ -270,6 +319,14 @@ def reflect_pad(x, pad):
     return y
 
 
+def reflect_pad_bwd(dy, pad):
+    n, c, oh, ow = dy.shape
+    dx = empty_nhwc(n, c, oh - 2 * pad, ow - 2 * pad, dy.device)
+    check(lib.sscg_reflect_pad_bwd(dy.data_ptr(), dx.data_ptr(), n, oh - 2 * pad, ow - 2 * pad, c, pad, _stream()),
+          "sscg_reflect_pad_bwd")
+    return dx
+
+
 def softmax_fwd(x):
     n, c, h, w = x.shape
     y = torch.empty_like(x, memory_format=CL)
@@ -327,23 +384,35 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
 
 
 # ----------------------------------------------------------------------------- autograd functions
-_WT_CACHE = {}
 _WEIGHT_EPOCH = [0]
 
 
 def bump_weight_epoch():
     """Called by the optimiser after it rewrote parameters: invalidates cached transposed weights."""
     _WEIGHT_EPOCH[0] += 1
-    _WT_CACHE.clear()
+
 
 
 def _cached_wt(w):
-    key = (w.data_ptr(), tuple(w.shape))
-    ent = _WT_CACHE.get(key)
-    if ent is None or ent[0] != w._version:
-        ent = (w._version, weight_transposed(w))
-        _WT_CACHE[key] = ent
+    """Transposed copy of a weight, cached ON the tensor object (dies with it; a recycled address can never
+    alias).  Valid while neither torch (`_version`) nor our optimiser (`_WEIGHT_EPOCH`) has rewritten it."""
+    tag = (w._version, _WEIGHT_EPOCH[0], w.data_ptr())
+    ent = getattr(w, "_sscg_wt", None)
+    if ent is None or ent[0] != tag:
+        ent = (tag, weight_transposed(w))
+        try:
+            w._sscg_wt = ent
+        except AttributeError:
+            pass
     return ent[1]
+
+
+def _acc_target(param):
+    """Gradient arena slice of a parameter owned by optim.FusedAdam (None for a stock optimiser)."""
+    acc = getattr(param, "_sscg_grad", None)
+    if acc is not None:
+        param._sscg_touched = True
+    return acc
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -371,16 +440,16 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if pad_mode == PAD_REFLECT:
                 raise _lib.SscgError("input gradient through a reflection-padded conv: use ReflectPadFn + pad=0 conv")
-            dx = conv2d_dgrad(dy, _cached_wt(w), x.shape, w.shape, stride, pad, dil)
+            dx = conv2d_dgrad(dy, _cached_wt(ctx.wref), x.shape, w.shape, stride, pad, dil)
         if ctx.needs_input_grad[1]:
-            acc = getattr(ctx.wref, "_sscg_grad", None)
+            acc = _acc_target(ctx.wref)
             if acc is not None:
                 conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode, out=acc, accumulate=True)
             else:
                 dw = conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             n, k, p, q = dy.shape
-            acc = getattr(ctx.bref, "_sscg_grad", None)
+            acc = _acc_target(ctx.bref)
             if acc is not None:
                 colsum(n * p * q, k, dy, out=acc, accumulate=True)
             else:
@@ -425,14 +494,14 @@ class ConvTranspose2dFn(torch.autograd.Function):
             dx = conv2d_fwd(dy, w, None, stride, pad, 1)
         if ctx.needs_input_grad[1]:
             # mirrored conv has input dy (as "x") and output-gradient x (as "dy")
-            acc = getattr(ctx.wref, "_sscg_grad", None)
+            acc = _acc_target(ctx.wref)
             if acc is not None:
                 conv2d_wgrad(dy, x, w.shape, stride, pad, 1, out=acc, accumulate=True)
             else:
                 dw = conv2d_wgrad(dy, x, w.shape, stride, pad, 1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             n, k, p, q = dy.shape
-            acc = getattr(ctx.bref, "_sscg_grad", None)
+            acc = _acc_target(ctx.bref)
             if acc is not None:
                 colsum(n * p * q, k, dy, out=acc, accumulate=True)
             else:
@@ -470,8 +539,8 @@ class NormActFn(torch.autograd.Function):
         dgamma = dbeta = None
         ret_g = ret_b = None
         if want_g:
-            dgamma = getattr(ctx.gref, "_sscg_grad", None)
-            dbeta = getattr(ctx.betaref, "_sscg_grad", None)
+            dgamma = _acc_target(ctx.gref)
+            dbeta = _acc_target(ctx.betaref)
             if dgamma is None or dbeta is None:
                 dgamma = torch.empty_like(gamma)
                 dbeta = torch.empty_like(gamma)

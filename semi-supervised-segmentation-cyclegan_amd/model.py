@@ -1,0 +1,278 @@
+"""Training drivers of the reference (model.py) on the MI355X kernels.
+
+`semisuper_cycleGAN` mirrors /root/reference model.py:202-662 - same constructor argument (`args` from
+main.py), same networks / losses / optimisers / checkpoint keys - but factors the 350-line `train` method
+into `step(l_img, l_gt, unl_img)` (one iteration of model.py:370-552) plus a thin epoch loop.  Differences
+that are deliberate and MI355X-first:
+  * every tensor of the step stays in HBM: the image pools hold device tensors (the reference round-trips
+    three activation batches through numpy per step, model.py:490-495) and the nine losses are device
+    scalars that are only read back when they are logged;
+  * forwards whose outputs the reference never uses (model.py:409) run without an autograd graph;
+  * gradients accumulate into flat arenas (optim.FusedAdam) that RCCL all-reduces in one piece per
+    optimiser under data parallelism (parallel.py).
+`supervised_model` mirrors model.py:33-199 (BASELINE config 1)."""
+import itertools
+import os
+
+import numpy as np
+import torch
+
+from . import functional as F
+from . import utils
+from .arch import define_Dis, define_Gen, set_grad
+from .optim import FusedAdam
+from .utils import CLASSES, make_one_hot
+
+LOSS_KEYS = ("img_dis_loss", "gt_dis_loss", "cycle_img_dis_loss", "img_gen_loss", "gt_gen_loss", "img_cycle_loss",
+             "gt_cycle_loss", "lab_loss_CE", "lab_loss_MSE")
+
+
+class semisuper_cycleGAN(object):
+    def __init__(self, args, data_parallel=None):
+        self.args = args
+        self.n_channels = CLASSES[args.dataset]                     # model.py:205-210
+        C, ids = self.n_channels, args.gpu_ids
+        drop = not args.no_dropout
+        # construction order = the reference's (model.py:215-230)
+        self.Gis = define_Gen(input_nc=C, output_nc=3, ngf=args.ngf, netG='deeplab', norm=args.norm, use_dropout=drop, gpu_ids=ids)
+        self.Gsi = define_Gen(input_nc=3, output_nc=C, ngf=args.ngf, netG='deeplab', norm=args.norm, use_dropout=drop, gpu_ids=ids)
+        self.Di = define_Dis(input_nc=3, ndf=args.ndf, netD='pixel', n_layers_D=3, norm=args.norm, gpu_ids=ids)
+        self.Ds = define_Dis(input_nc=C, ndf=args.ndf, netD='pixel', n_layers_D=3, norm=args.norm, gpu_ids=ids)
+        self.old_Gis = define_Gen(input_nc=C, output_nc=3, ngf=args.ngf, netG='resnet_9blocks', norm=args.norm, use_dropout=drop, gpu_ids=ids)
+        self.old_Gsi = define_Gen(input_nc=3, output_nc=C, ngf=args.ngf, netG='resnet_9blocks_softmax', norm=args.norm, use_dropout=drop, gpu_ids=ids)
+        self.old_Di = define_Dis(input_nc=3, ndf=args.ndf, netD='pixel', n_layers_D=3, norm=args.norm, gpu_ids=ids)
+        if args.dataset == 'voc2012':                               # model.py:251-257
+            try:
+                ck = utils.load_checkpoint('./ckpt_for_Arnab_loss.ckpt')
+                self.old_Gis.load_state_dict(ck['Gis'])
+                self.old_Gsi.load_state_dict(ck['Gsi'])
+            except Exception:
+                print('**There is an error in loading the ckpt_for_Arnab_loss**')
+        utils.print_networks([self.Gis, self.Gsi, self.Di, self.Ds], ['Gis', 'Gsi', 'Di', 'Ds'])
+
+        self.crop = (args.crop_height, args.crop_width)             # nn.Upsample(..., align_corners=True), model.py:268
+        self.running_metrics_val = utils.runningScore(C, args.dataset)
+        self.as_written = getattr(args, "as_written", True)         # keep the reference's unused forwards
+        self.dp = data_parallel
+
+        self.g_optimizer = FusedAdam(itertools.chain(self.Gis.parameters(), self.Gsi.parameters()), lr=args.lr, betas=(0.5, 0.999))
+        self.d_optimizer = FusedAdam(itertools.chain(self.Di.parameters(), self.Ds.parameters()), lr=args.lr, betas=(0.5, 0.999))
+        if self.dp is not None:
+            self.dp.attach(self.g_optimizer, self.d_optimizer, [self.Gis, self.Gsi, self.Di, self.Ds, self.old_Gis, self.old_Gsi, self.old_Di])
+        lam = utils.LambdaLR(args.epochs, 0, args.decay_epoch).step
+        self.g_lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.g_optimizer, lr_lambda=lam)
+        self.d_lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.d_optimizer, lr_lambda=lam)
+
+        self.pools = [utils.Sample_from_Pool() for _ in range(3)]   # new_img_fake / img_fake / gt_fake, model.py:350-352
+
+        if not os.path.isdir(args.checkpoint_dir):
+            os.makedirs(args.checkpoint_dir, exist_ok=True)
+        try:                                                        # model.py:298-311
+            ck = utils.load_checkpoint('%s/latest_semisuper_cycleGAN.ckpt' % (args.checkpoint_dir))
+            self.start_epoch = ck['epoch']
+            for k in ('Di', 'Ds', 'Gis', 'Gsi'):
+                getattr(self, k).load_state_dict(ck[k])
+            self.d_optimizer.load_state_dict(ck['d_optimizer'])
+            self.g_optimizer.load_state_dict(ck['g_optimizer'])
+            self.best_iou = ck['best_iou']
+        except Exception:
+            print(' [*] No checkpoint!')
+            self.start_epoch = 0
+            self.best_iou = -100
+
+    # ------------------------------------------------------------------------------------------ one iteration
+    def interp(self, x):
+        return F.upsample_bilinear(x, self.crop)
+
+    def step(self, l_img, l_gt, unl_img):
+        """One G step + one D step (model.py:376-542).  Returns the nine losses as 0-dim device tensors."""
+        a, C = self.args, self.n_channels
+        # ---- generators (model.py:376-474)
+        set_grad([self.Di, self.Ds, self.old_Di], False)
+        set_grad([self.old_Gsi, self.old_Gis], False)
+        self.g_optimizer.zero_grad()
+        labels = l_gt.reshape(l_gt.shape[0], l_gt.shape[2], l_gt.shape[3])          # l_gt.squeeze(1)
+        onehot_gt = make_one_hot(l_gt, a.dataset, a.gpu_ids)
+        fake_img = self.interp(self.Gis(onehot_gt))                                  # :385,390
+        fake_gt = self.interp(self.Gsi(unl_img))                                     # :386,391
+        lab_gt = self.interp(self.Gsi(l_img))                                        # :387,392
+        lab_loss_CE = F.cross_entropy(lab_gt, labels)                                # :398
+        lab_gt = F.softmax2d(lab_gt)                                                 # :401
+        fake_gt = F.softmax2d(fake_gt)                                               # :402
+        recon_img = self.interp(self.Gis(fake_gt))                                   # :408,413
+        with torch.no_grad():
+            self.Gis(lab_gt.detach())      # :409 - output unused by the reference, but it advances Gis' BN running stats
+        recon_gt = self.interp(self.Gsi(fake_img))                                   # :410,415
+        with torch.no_grad():
+            resnet_fake_gt = F.softmax2d(self.old_Gsi(unl_img))                      # :418,421
+            resnet_recon_img = self.old_Gis(resnet_fake_gt)                          # :422
+            if self.as_written:                                                      # :419-420,423: results never used
+                self.old_Gis(F.softmax2d(self.old_Gsi(l_img)))
+        fake_img_dis = self.Di(fake_img)                                             # :431
+        resnet_fake_img_dis = self.old_Di(recon_img)                                 # :432
+        fake_gt_onehot, _ = F.argmax_onehot(fake_gt.detach())                        # :435-437 (no gradient path)
+        fake_gt_dis = self.Ds(fake_gt_onehot)                                        # :438
+        img_gen_loss = F.mse_const(fake_img_dis, 1.0)                                # :445
+        gt_gen_loss = F.mse_const(fake_gt_dis, 1.0)                                  # :446
+        img_cycle_loss = F.mse_const(resnet_fake_img_dis, 1.0)                       # :452
+        gt_cycle_loss = F.cross_entropy(recon_gt, labels)                            # :455
+        lab_loss_MSE = F.l1_loss(fake_img, l_img)                                    # :461
+        # :464-468  gen_loss = CE_w*CE + MSE_w*L1 + adv_w*(img_gen + gt_gen) + img_cycle + lamda_gt*gt_cycle
+        gen_loss = F.weighted_sum(
+            [lab_loss_CE, lab_loss_MSE, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss],
+            [a.lab_CE_weight, a.lab_MSE_weight, a.adversarial_weight, a.adversarial_weight, 1.0, a.lamda_gt])
+        gen_loss.backward()                                                          # :472
+        if self.dp is not None:
+            self.dp.sync_grads(self.g_optimizer)
+        self.g_optimizer.step()                                                      # :474
+
+        # ---- discriminators (model.py:477-542)
+        set_grad([self.Di, self.Ds], True)
+        set_grad([self.old_Di], self.as_written)   # old_Di is in no optimiser: its wgrad only exists in the as-written graph
+        self.d_optimizer.zero_grad()
+        recon_img_p = self.pools[0]([recon_img.detach()])[0]                         # :490
+        fake_img_p = self.pools[1]([fake_img.detach()])[0]                           # :491
+        fake_gt_p = self.pools[2]([fake_gt.detach()])[0]                             # :493
+        unl_img_dis = self.Di(unl_img)                                               # :499
+        fake_img_dis = self.Di(fake_img_p)                                           # :500
+        resnet_recon_img_dis = self.old_Di(resnet_recon_img)                         # :501
+        resnet_fake_img_dis = self.old_Di(recon_img_p)                               # :502
+        real_gt_dis = self.Ds(onehot_gt)                                             # :506-507
+        fake_gt_onehot, _ = F.argmax_onehot(fake_gt_p)                               # :509-511
+        fake_gt_dis = self.Ds(fake_gt_onehot)                                        # :512
+        r_i, f_i = F.mse_const(unl_img_dis, 1.0), F.mse_const(fake_img_dis, 0.0)     # :521-522
+        r_g, f_g = F.mse_const(real_gt_dis, 1.0), F.mse_const(fake_gt_dis, 0.0)      # :523-524
+        r_c, f_c = F.mse_const(resnet_recon_img_dis, 1.0), F.mse_const(resnet_fake_img_dis, 0.0)  # :527-528
+        img_dis_loss = F.weighted_sum([r_i, f_i], [0.5, 0.5])                        # :531
+        gt_dis_loss = F.weighted_sum([r_g, f_g], [0.5, 0.5])                         # :532
+        cycle_img_dis_loss = F.weighted_sum([r_c, f_c], [1.0, 1.0])                  # :534
+        dis_loss = F.weighted_sum([img_dis_loss, gt_dis_loss, cycle_img_dis_loss],
+                                  [a.discriminator_weight, a.discriminator_weight, 1.0])  # :538
+        dis_loss.backward()                                                          # :539
+        if self.dp is not None:
+            self.dp.sync_grads(self.d_optimizer)
+        self.d_optimizer.step()                                                      # :542
+        vals = (img_dis_loss, gt_dis_loss, cycle_img_dis_loss, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss,
+                lab_loss_CE, lab_loss_MSE)
+        return {k: v.detach() for k, v in zip(LOSS_KEYS, vals)}
+
+    # ------------------------------------------------------------------------------------------ evaluation (model.py:555-574)
+    @torch.no_grad()
+    def evaluate(self, val_loader):
+        self.Gsi.eval()
+        self.Gis.eval()
+        self.running_metrics_val.reset()
+        for val_img, val_gt, _ in val_loader:
+            val_img, val_gt = utils.cuda([val_img, val_gt], self.args.gpu_ids)
+            outputs = F.softmax2d(self.interp(self.Gsi(val_img)))
+            pred = F.argmax_index(outputs).cpu().numpy()
+            self.running_metrics_val.update(val_gt.squeeze(1).cpu().numpy(), pred)
+        score, class_iou = self.running_metrics_val.get_scores()
+        self.Gsi.train()
+        self.Gis.train()
+        return score["Mean IoU : \t"], class_iou
+
+    # ------------------------------------------------------------------------------------------ epoch loop
+    def train(self, args, loaders=None, max_steps=None, log_every=1, writer=None):
+        """Epoch loop of model.py:359-660.  `loaders` = (labeled, unlabeled, val) iterables yielding the
+        reference's dataset tuples (img f32[B,3,H,W], gt i64[B,1,H,W], name); None builds synthetic ones
+        (the real datasets / transforms of data_utils are outside this build's scope)."""
+        if loaders is None:
+            from .data import synthetic_loaders
+            loaders = synthetic_loaders(args, self.n_channels)
+        labeled_loader, unlabeled_loader, val_loader = loaders
+        rank0 = self.dp is None or self.dp.rank == 0
+        done = 0
+        history = []
+        for epoch in range(self.start_epoch, args.epochs):
+            if rank0:
+                print('learning rate = %.7f' % self.g_optimizer.param_groups[0]['lr'])
+            self.Gsi.train()
+            self.Gis.train()
+            n_it = min(len(labeled_loader), len(unlabeled_loader))
+            for i, ((l_img, l_gt, _), (unl_img, _, _)) in enumerate(zip(labeled_loader, unlabeled_loader)):
+                l_img, unl_img, l_gt = utils.cuda([l_img, unl_img, l_gt], args.gpu_ids)
+                losses = self.step(l_img, l_gt, unl_img)
+                done += 1
+                if (i % log_every == 0) and rank0:
+                    vals = torch.stack([losses[k] for k in LOSS_KEYS]).cpu().tolist()   # the only host sync of the step
+                    rec = dict(zip(LOSS_KEYS, vals))
+                    history.append(rec)
+                    print("Epoch: (%3d) (%5d/%5d) | Dis Loss:%.2e | Unlab Gen Loss:%.2e | Lab Gen loss:%.2e" % (
+                        epoch, i + 1, n_it, rec["img_dis_loss"] + rec["gt_dis_loss"],
+                        args.adversarial_weight * (rec["img_gen_loss"] + rec["gt_gen_loss"]) + rec["img_cycle_loss"] + rec["gt_cycle_loss"] * args.lamda_gt,
+                        args.lab_CE_weight * rec["lab_loss_CE"] + args.lab_MSE_weight * rec["lab_loss_MSE"]))
+                    if writer is not None:
+                        it = len(labeled_loader) * epoch + i
+                        writer.add_scalars('Dis Loss', {k: rec[k] for k in LOSS_KEYS[0:3]}, it)
+                        writer.add_scalars('Unlabelled Loss', {k: rec[k] for k in LOSS_KEYS[3:7]}, it)
+                        writer.add_scalars('Labelled Loss', {k: rec[k] for k in LOSS_KEYS[7:9]}, it)
+                if max_steps is not None and done >= max_steps:
+                    return history
+            if val_loader is not None:
+                miou, class_iou = self.evaluate(val_loader)
+                if rank0:
+                    print("The mIoU for the epoch is: ", miou)
+                if miou >= self.best_iou and rank0:                                 # model.py:641-655
+                    self.best_iou = miou
+                    utils.save_checkpoint({'epoch': epoch + 1, 'Di': self.Di.state_dict(), 'Ds': self.Ds.state_dict(),
+                                           'Gis': self.Gis.state_dict(), 'Gsi': self.Gsi.state_dict(),
+                                           'd_optimizer': self.d_optimizer.state_dict(), 'g_optimizer': self.g_optimizer.state_dict(),
+                                           'best_iou': self.best_iou, 'class_iou': class_iou},
+                                          '%s/latest_semisuper_cycleGAN.ckpt' % (args.checkpoint_dir))
+            self.g_lr_scheduler.step()                                              # model.py:659-660
+            self.d_lr_scheduler.step()
+        return history
+
+
+class supervised_model(object):
+    """DeepLab Gsi + CrossEntropy + Adam(0.9, 0.999) (model.py:33-199; BASELINE config 1)."""
+
+    def __init__(self, args):
+        self.args = args
+        self.n_channels = CLASSES[args.dataset]
+        self.Gsi = define_Gen(input_nc=3, output_nc=self.n_channels, ngf=args.ngf, netG='deeplab', norm=args.norm,
+                              use_dropout=not args.no_dropout, gpu_ids=args.gpu_ids)
+        utils.print_networks([self.Gsi], ['Gsi'])
+        self.crop = (args.crop_height, args.crop_width)
+        self.gsi_optimizer = FusedAdam(self.Gsi.parameters(), lr=args.lr, betas=(0.9, 0.999))   # model.py:69
+        self.running_metrics_val = utils.runningScore(self.n_channels, args.dataset)
+        if not os.path.isdir(args.checkpoint_dir):
+            os.makedirs(args.checkpoint_dir, exist_ok=True)
+        try:
+            ck = utils.load_checkpoint('%s/latest_supervised_model.ckpt' % (args.checkpoint_dir))
+            self.start_epoch = ck['epoch']
+            self.Gsi.load_state_dict(ck['Gsi'])
+            self.gsi_optimizer.load_state_dict(ck['gsi_optimizer'])
+            self.best_iou = ck['best_iou']
+        except Exception:
+            print(' [*] No checkpoint!')
+            self.start_epoch = 0
+            self.best_iou = -100
+
+    def step(self, l_img, l_gt):
+        """model.py:120-143."""
+        self.gsi_optimizer.zero_grad()
+        out = F.upsample_bilinear(self.Gsi(l_img), self.crop)
+        loss = F.cross_entropy(out, l_gt.reshape(l_gt.shape[0], l_gt.shape[2], l_gt.shape[3]))
+        loss.backward()
+        self.gsi_optimizer.step()
+        return loss.detach()
+
+    def train(self, args, loaders=None, max_steps=None):
+        if loaders is None:
+            from .data import synthetic_loaders
+            loaders = synthetic_loaders(args, self.n_channels)
+        labeled_loader = loaders[0]
+        history, done = [], 0
+        for epoch in range(self.start_epoch, args.epochs):
+            self.Gsi.train()
+            for i, (l_img, l_gt, _) in enumerate(labeled_loader):
+                l_img, l_gt = utils.cuda([l_img, l_gt], args.gpu_ids)
+                loss = float(self.step(l_img, l_gt))
+                history.append(loss)
+                print("Epoch: (%3d) (%5d/%5d) | Crossentropy Loss:%.2e" % (epoch, i + 1, len(labeled_loader), loss))
+                done += 1
+                if max_steps is not None and done >= max_steps:
+                    return history
+        return history

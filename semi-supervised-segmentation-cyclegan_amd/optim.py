@@ -1,0 +1,99 @@
+"""Flat-arena Adam for the two optimisers of the step (model.py:286-287: Adam(lr, betas=(0.5, 0.999)) over
+chain(Gis, Gsi) and chain(Di, Ds)).
+
+MI355X-first layout: all trainable parameters of an optimiser live in ONE contiguous fp32 arena, with
+matching arenas for the gradient and both moments.  Consequences:
+  * `step()` is a single fused HIP launch over ~86 M elements (HBM-bound, 7 streams);
+  * `zero_grad()` is one fill;
+  * the data-parallel exchange is an RCCL all-reduce of one buffer (parallel.py), not one per tensor;
+  * weight-gradient kernels accumulate straight into the arena (`param._sscg_grad`), so autograd never
+    materialises or adds per-parameter gradient tensors.
+`state_dict()` keeps torch.optim.Adam's format (per-parameter `step`, `exp_avg`, `exp_avg_sq`) for the
+parameters that have received a gradient, so checkpoints interchange with the reference."""
+import torch
+
+from . import functional as F
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.world_size = 1
+        self._steps = 0
+        self._build()
+
+    def _build(self):
+        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if not ps:
+            raise ValueError("FusedAdam: no trainable parameters")
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise F._lib.SscgError("FusedAdam needs parameters on the MI355X (call net.cuda() / pass gpu_ids first)")
+        total = sum(p.numel() for p in ps)
+        self.arena = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.empty(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.empty(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.empty(total, dtype=torch.float32, device=dev)
+        for t in (self.grad, self.exp_avg, self.exp_avg_sq):
+            F.fill_(t, 0.0)
+        self.trainable = ps
+        self.slices = {}
+        off = 0
+        for p in ps:
+            n = p.numel()
+            self.slices[p] = (off, n)
+            self._view(self.arena, p, off).copy_(p.data)     # one-time gather (torch copy: start-up plumbing)
+            p.data = self._view(self.arena, p, off)
+            g = self._view(self.grad, p, off)
+            p._sscg_grad = g
+            p._sscg_touched = False
+            p.grad = g
+            off += n
+
+    @staticmethod
+    def _view(flat, p, off):
+        """View of flat[off : off+numel] with p's logical shape and (dense) strides."""
+        return torch.as_strided(flat, p.shape, p.stride(), off)
+
+    def zero_grad(self, set_to_none=False):
+        F.fill_(self.grad, 0.0)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self._steps += 1
+        F.adam_step(self.arena, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                    self._steps, 1.0 / self.world_size)
+        F.bump_weight_epoch()
+
+    def mark_touched(self):
+        """Parameters whose gradient slice is non-zero have taken part in a backward pass (host check, used lazily by state_dict)."""
+        for p in self.trainable:
+            if not p._sscg_touched:
+                off, n = self.slices[p]
+                p._sscg_touched = bool(self.grad[off:off + n].abs().max().item() > 0) or p._sscg_touched
+
+    def state_dict(self):
+        # materialise torch.optim.Adam-style per-parameter state (views into the arenas) for touched params
+        self.mark_touched()
+        self.state.clear()
+        if self._steps > 0:
+            for p in self.trainable:
+                if p._sscg_touched:
+                    off, _ = self.slices[p]
+                    self.state[p] = {"step": torch.tensor(float(self._steps)), "exp_avg": self._view(self.exp_avg, p, off),
+                                     "exp_avg_sq": self._view(self.exp_avg_sq, p, off)}
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = 0
+        for p, st in list(self.state.items()):
+            if p in self.slices:
+                off, _ = self.slices[p]
+                self._view(self.exp_avg, p, off).copy_(st["exp_avg"])
+                self._view(self.exp_avg_sq, p, off).copy_(st["exp_avg_sq"])
+                p._sscg_touched = True
+                steps = max(steps, int(float(st["step"])))
+        self._steps = steps

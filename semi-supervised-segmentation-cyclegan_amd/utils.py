@@ -1,0 +1,108 @@
+"""Hot-path helpers of the reference's utils.py (make_one_hot :314, Sample_from_Pool :278, cuda :221,
+LambdaLR :434, runningScore :357, checkpoint I/O :265-273), re-expressed for a device-resident step:
+nothing here moves activations to the host."""
+import numpy as np
+import torch
+
+from . import functional as F
+
+CLASSES = {"voc2012": 21, "cityscapes": 20, "acdc": 4}   # model.py:205-210, utils.py:335-342
+
+
+def cuda(xs, gpu_id):
+    """utils.cuda (utils.py:221-227): move a tensor / list of tensors to gpu_id[0] when a GPU exists."""
+    if torch.cuda.is_available() and len(gpu_id) > 0:
+        dev = torch.device("cuda", int(gpu_id[0]))
+        if not isinstance(xs, (list, tuple)):
+            return xs.to(dev, non_blocking=True)
+        return [x.to(dev, non_blocking=True) for x in xs]
+    return xs
+
+
+def make_one_hot(labels, dataname, gpu_id=None):
+    """Integer labels [N,1,H,W] -> fp32 one-hot [N,C,H,W] (utils.py:314-350), one HIP pass."""
+    assert dataname in CLASSES, "dataset name should be one of the following: 'voc2012',given {}".format(dataname)
+    return F.label_onehot(labels.long(), CLASSES[dataname])
+
+
+class Sample_from_Pool(object):
+    """History pool of Shrivastava et al. (utils.py:278-299): `max_elements` slots; once full, with p=0.5 a
+    random stored item is returned and replaced.  Items stay on the device (the reference round-trips three
+    activation batches through numpy every step, model.py:490-495); the host RNG calls (np.random.ranf /
+    randint) are the reference's, so a seeded run makes the same decisions."""
+
+    def __init__(self, max_elements=50):
+        self.max_elements = max_elements
+        self.cur_elements = 0
+        self.items = []
+
+    def __call__(self, in_items):
+        out = []
+        for item in in_items:
+            if self.cur_elements < self.max_elements:
+                self.items.append(item)
+                self.cur_elements += 1
+                out.append(item)
+            elif np.random.ranf() > 0.5:
+                idx = np.random.randint(0, self.max_elements)
+                out.append(self.items[idx])
+                self.items[idx] = item
+            else:
+                out.append(item)
+        return out
+
+
+class LambdaLR():
+    """Linear decay to zero after `decay_epoch` (utils.py:434-441)."""
+
+    def __init__(self, epochs, offset, decay_epoch):
+        self.epochs, self.offset, self.decay_epoch = epochs, offset, decay_epoch
+
+    def step(self, epoch):
+        return 1.0 - max(0, epoch + self.offset - self.decay_epoch) / (self.epochs - self.decay_epoch)
+
+
+class runningScore(object):
+    """Confusion-matrix mIoU (utils.py:357-412).  VOC ignores class 0, Cityscapes the last class, ACDC none."""
+
+    def __init__(self, n_classes, dataset):
+        self.n_classes, self.dataset = n_classes, dataset
+        self.confusion_matrix = np.zeros((n_classes, n_classes))
+
+    def update(self, label_trues, label_preds):
+        n = self.n_classes
+        for lt, lp in zip(label_trues, label_preds):
+            lt, lp = np.asarray(lt).ravel(), np.asarray(lp).ravel()
+            keep = (lt >= 0) & (lt < n)
+            self.confusion_matrix += np.bincount(n * lt[keep].astype(int) + lp[keep], minlength=n * n).reshape(n, n)
+
+    def get_scores(self):
+        h, n = self.confusion_matrix, self.n_classes
+        with np.errstate(divide="ignore", invalid="ignore"):
+            acc = np.diag(h).sum() / h.sum()
+            acc_cls = np.nanmean(np.diag(h) / h.sum(axis=1))
+            sub = h[1:, 1:] if self.dataset == "voc2012" else (h[:n - 1, :n - 1] if self.dataset == "cityscapes" else h)
+            iu = np.diag(sub) / (sub.sum(axis=1) + sub.sum(axis=0) - np.diag(sub))
+        cls_iu = dict(zip(range(len(iu)), iu))
+        return {"Overall Acc: \t": acc, "Mean Acc : \t": acc_cls, "Mean IoU : \t": np.nanmean(iu)}, cls_iu
+
+    def reset(self):
+        self.confusion_matrix = np.zeros((self.n_classes, self.n_classes))
+
+
+def save_checkpoint(state, save_path):
+    torch.save(state, save_path)
+
+
+def load_checkpoint(ckpt_path, map_location="cpu"):
+    ckpt = torch.load(ckpt_path, map_location=map_location)
+    print(" [*] Loading checkpoint from %s succeed!" % ckpt_path)
+    return ckpt
+
+
+def print_networks(nets, names):
+    print("------------Number of Parameters---------------")
+    for net, name in zip(nets, names):
+        n = sum(p.numel() for p in net.parameters())
+        print("[Network %s] Total number of parameters : %.3f M" % (name, n / 1e6))
+    print("-----------------------------------------------")
