@@ -167,58 +167,85 @@ int launch_reduce(RedParams p, int G, hipStream_t st) {
     return SSCG_OK;
 }
 
-__global__ void finalize_sum_kernel(const double* __restrict__ part, float* __restrict__ out, int C, int chunks, float beta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int k = 0; k < chunks; ++k) s += part[((size_t)k * C + c) * 2];
-    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
+// Second stage of the column reductions.  A block owns 16 channels; its 256 threads are 16 channels x 16
+// chunk-lanes, each lane strides the chunk axis, lanes are combined through LDS in a fixed order.
+__device__ __forceinline__ void chunk_sum16(const double* __restrict__ part, int g, int chunks, int C, int c, bool cok,
+                                            double* sm, double& s0, double& s1) {
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    double a = 0.0, b = 0.0;
+    if (cok) {
+        for (int k = kl; k < chunks; k += 16) {
+            size_t o = (((size_t)g * chunks + k) * C + c) * 2;
+            a += part[o];
+            b += part[o + 1];
+        }
+    }
+    __syncthreads();  // sm reuse across calls
+    sm[(kl * 16 + cl) * 2] = a;
+    sm[(kl * 16 + cl) * 2 + 1] = b;
+    __syncthreads();
+    s0 = 0.0; s1 = 0.0;
+    if (kl == 0) {
+        for (int r = 0; r < 16; ++r) { s0 += sm[(r * 16 + cl) * 2]; s1 += sm[(r * 16 + cl) * 2 + 1]; }
+    }
 }
 
-__global__ void finalize_stats_kernel(const double* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
-                                      float* __restrict__ rmean, float* __restrict__ rvar, int G, int C, int chunks,
-                                      long L, float eps, float momentum) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G * C) return;
-    int g = i / C, c = i - g * C;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        size_t o = (((size_t)g * chunks + k) * C + c) * 2;
-        s += part[o];
-        ss += part[o + 1];
-    }
-    double m = s / (double)L;
-    double var = ss / (double)L - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[i] = (float)m;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-    if (rmean) {
-        double unb = L > 1 ? var * (double)L / (double)(L - 1) : var;
-        rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
-        rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+__global__ __launch_bounds__(256) void finalize_sum_kernel(const double* __restrict__ part, float* __restrict__ out, int C,
+                                                            int chunks, float beta) {
+    __shared__ double sm[512];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool cok = c < C;
+    double s, unused;
+    chunk_sum16(part, 0, chunks, C, c, cok, sm, s, unused);
+    if ((threadIdx.x >> 4) == 0 && cok) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
+}
+
+__global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __restrict__ part, float* __restrict__ mean,
+                                                              float* __restrict__ rstd, float* __restrict__ rmean,
+                                                              float* __restrict__ rvar, int G, int C, int chunks, long L,
+                                                              float eps, float momentum) {
+    __shared__ double sm[512];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int g = blockIdx.y;
+    const bool cok = c < C;
+    double s, ss;
+    chunk_sum16(part, g, chunks, C, c, cok, sm, s, ss);
+    if ((threadIdx.x >> 4) == 0 && cok) {
+        const int i = g * C + c;
+        double m = s / (double)L;
+        double var = ss / (double)L - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[i] = (float)m;
+        rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) {
+            double unb = L > 1 ? var * (double)L / (double)(L - 1) : var;
+            rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
+            rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+        }
     }
 }
 
 // c1 = sum_g / L, c2 = sum_g_xhat / L  per (g, c);  dgamma/dbeta += sums (over g)
-__global__ void finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ coef, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, int G, int C, int chunks, long L) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ coef,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C,
+                                                            int chunks, long L) {
+    __shared__ double sm[512];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool cok = c < C;
+    const bool lead = (threadIdx.x >> 4) == 0 && cok;
     double tg = 0.0, tb = 0.0;
     for (int g = 0; g < G; ++g) {
-        double s = 0.0, sx = 0.0;
-        for (int k = 0; k < chunks; ++k) {
-            size_t o = (((size_t)g * chunks + k) * C + c) * 2;
-            s += part[o];
-            sx += part[o + 1];
+        double s, sx;
+        chunk_sum16(part, g, chunks, C, c, cok, sm, s, sx);
+        if (lead) {
+            coef[((size_t)g * C + c) * 2] = (float)(s / (double)L);
+            coef[((size_t)g * C + c) * 2 + 1] = (float)(sx / (double)L);
+            tb += s;
+            tg += sx;
         }
-        coef[((size_t)g * C + c) * 2] = (float)(s / (double)L);
-        coef[((size_t)g * C + c) * 2 + 1] = (float)(sx / (double)L);
-        tb += s;
-        tg += sx;
     }
-    if (dgamma) dgamma[c] += (float)tg;
-    if (dbeta) dbeta[c] += (float)tb;
+    if (lead && dgamma) dgamma[c] += (float)tg;
+    if (lead && dbeta) dbeta[c] += (float)tb;
 }
 
 struct ApplyParams {
@@ -375,7 +402,7 @@ extern "C" int sscg_colsum(const float* x, float* out, int64_t rows, int cols, f
     int rc = launch_reduce<RM_SUM>(p, 1, st);
     if (rc) return rc;
     RedPlan pl = plan_reduce(1, rows, cols);
-    hipLaunchKernelGGL(finalize_sum_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, p.part, out, cols, pl.chunks, beta);
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, st, p.part, out, cols, pl.chunks, beta);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -395,7 +422,7 @@ extern "C" int sscg_norm_stats(const float* x, int G, int64_t L, int C, float ep
     int rc = launch_reduce<RM_STATS>(p, G, st);
     if (rc) return rc;
     RedPlan pl = plan_reduce(G, L, C);
-    hipLaunchKernelGGL(finalize_stats_kernel, dim3(cdiv((long)G * C, 256)), dim3(256), 0, st, p.part, mean, rstd,
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3(cdiv(C, 16), G), dim3(256), 0, st, p.part, mean, rstd,
                        running_mean, running_var, G, C, pl.chunks, (long)L, eps, momentum);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
@@ -451,7 +478,7 @@ extern "C" int sscg_norm_bwd(const float* dy, const float* x, const float* y, co
         if (rc) return rc;
         RedPlan pl = plan_reduce(G, L, C);
         coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + part_bytes(G, L, C));
-        hipLaunchKernelGGL(finalize_bwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, p.part, coef, dgamma, dbeta, G, C,
+        hipLaunchKernelGGL(finalize_bwd_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, p.part, coef, dgamma, dbeta, G, C,
                            pl.chunks, (long)L);
         SSCG_LAUNCH_CHECK();
     }
