@@ -1,0 +1,119 @@
+"""Host-side logic of the drop-in layer (no GPU): CLI flags, state-dict ABI, pool / LR schedule / mIoU helpers."""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from conftest import ROOT, load_sub
+from oracle import fixtures as FX
+from oracle import nets
+
+META = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "meta.json")))
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def test_cli_flags_and_defaults_match_reference():
+    sys.path.insert(0, ROOT)
+    import main
+    a = main.get_args([])
+    # defaults of /root/reference main.py:12-44
+    want = dict(epochs=400, decay_epoch=100, batch_size=2, lr=.0002, gpu_ids="0", crop_height=None, crop_width=None, lamda_img=0.5,
+                lamda_gt=0.1, lamda_perceptual=0, lab_CE_weight=1, lab_MSE_weight=1, lab_perceptual_weight=0, adversarial_weight=1.0,
+                discriminator_weight=1.0, training=False, testing=False, validation=False, model="supervised_model",
+                results_dir="./results", validation_dir="./val_results", checkpoint_dir="./checkpoints/semisupervised_cycleGAN",
+                dataset="voc2012", norm="instance", no_dropout=False, ngf=64, ndf=64, gen_net="deeplab", dis_net="fc_disc")
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    b = main.get_args(["--training", "False", "--dataset", "cityscapes"])   # type=bool quirk: any non-empty string is True
+    assert b.training is True
+    assert main.DEFAULT_CROP == {"voc2012": (320, 320), "acdc": (256, 256), "cityscapes": (512, 1024)}
+
+
+def test_state_dict_keys_are_the_reference_abi():
+    arch = load_sub("arch")
+    cases = [
+        (lambda: arch.define_Gen(3, 21, 64, "deeplab", "instance", False, []), nets.deeplab_spec(3, 21)),
+        (lambda: arch.define_Gen(21, 3, 64, "resnet_9blocks", "instance", True, []), nets.resnet_gen_spec_full(21, 3, 64, 9, "instance", True)),
+        (lambda: arch.define_Gen(3, 21, 64, "resnet_9blocks_softmax", "batch", False, []), nets.resnet_gen_spec_full(3, 21, 64, 9, "batch", False)),
+        (lambda: arch.define_Dis(21, 64, "pixel", 3, "instance", []), nets.pixel_dis_spec(21)),
+        (lambda: arch.define_Dis(3, 64, "n_layers", 3, "instance", []), nets.nlayer_dis_spec(3)),
+        (lambda: arch.define_Dis(3, 64, "n_layers", 3, "batch", []), nets.nlayer_dis_spec(3, norm="batch")),
+    ]
+    for mk, spec in cases:
+        m = quiet(mk)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(spec.keys())
+        for k in sd:
+            assert tuple(sd[k].shape) == tuple(spec[k][0]), k
+        # keyed weights round-trip through load_state_dict(strict=True); conv weights stay channels-last
+        m.load_state_dict({k: torch.zeros(s[0], dtype=torch.int64 if s[1] == "nbt" else torch.float32) for k, s in spec.items()}, strict=True)
+        for p in m.parameters():
+            if p.dim() == 4:
+                assert p.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_deeplab_trainable_set_and_frozen_bn():
+    arch = load_sub("arch")
+    m = quiet(arch.define_Gen, 3, 21, 64, "deeplab", "instance", False, [])
+    train = [k for k, p in m.named_parameters() if p.requires_grad]
+    assert len(train) == 104 + 8          # 104 conv weights + 4 classifier (weight, bias) pairs
+    assert all(".bn" not in k and not k.startswith("bn1") and ".downsample.1" not in k for k in train)
+    arch.set_grad([m], False)
+    assert not any(p.requires_grad for p in m.parameters())
+
+
+def test_out_of_scope_generators_raise():
+    import pytest
+    arch = load_sub("arch")
+    for name in ("unet_128", "enet", "lednet_256"):
+        with pytest.raises(NotImplementedError):
+            arch.define_Gen(3, 3, 64, name, "instance", False, [])
+    with pytest.raises(NotImplementedError):
+        arch.define_Dis(3, 64, "nope", 3, "instance", [])
+
+
+def test_pool_lambda_lr_running_score():
+    u = load_sub("utils")
+    np.random.seed(0)
+    pool = u.Sample_from_Pool(max_elements=3)
+    assert [float(pool([np.float32(i)])[0]) for i in range(12)] == META["pool_trace_seed0_cap3"]
+    lr = u.LambdaLR(400, 0, 100)
+    for e, v in META["lambda_lr"].items():
+        assert abs(lr.step(int(e)) - v) < 1e-15
+    from oracle import weights as W
+    for ds, C in (("voc2012", 21), ("cityscapes", 20), ("acdc", 4)):
+        lt = W.randint(FX.SEED, "g5/lt/" + ds, (2, 16, 16), C).numpy()
+        lp = W.randint(FX.SEED, "g5/lp/" + ds, (2, 16, 16), C).numpy()
+        lp[0] = lt[0]
+        rs = u.runningScore(C, ds)
+        rs.update(lt, lp)
+        sc, _ = rs.get_scores()
+        assert abs(sc["Mean IoU : \t"] - META["miou_" + ds]["miou"]) < 1e-12
+        assert abs(sc["Overall Acc: \t"] - META["miou_" + ds]["acc"]) < 1e-12
+
+
+def test_pool_output_size_rule():
+    F = load_sub("functional")
+    for h, o in META["maxpool_ceil_sizes"].items():
+        assert F.pool_out_size(int(h)) == o
+
+
+def test_synthetic_loader_contract():
+    d = load_sub("data")
+    ld = d.SyntheticLoader(2, 21, 40, 48, 3, seed=1)
+    batches = list(ld)
+    assert len(batches) == 3 == len(ld)
+    img, gt, names = batches[0]
+    assert img.shape == (2, 3, 40, 48) and img.dtype == torch.float32 and float(img.min()) >= -1 and float(img.max()) <= 1
+    assert gt.shape == (2, 1, 40, 48) and gt.dtype == torch.int64 and int(gt.min()) >= 0 and int(gt.max()) < 21
+    assert len(names) == 2
+    again = list(d.SyntheticLoader(2, 21, 40, 48, 3, seed=1))[0]
+    assert torch.equal(again[0], img) and torch.equal(again[1], gt)

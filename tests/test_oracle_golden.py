@@ -1,0 +1,121 @@
+"""oracle/ (the CPU restatement) against the golden vectors taken from the real reference by
+tools/gen_golden.py.  Runs anywhere (no GPU, no /root/reference).  The generator recorded its thread count;
+fp32 comparisons allow for a different count here (thread count moves fp32 sums)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from oracle import fixtures as FX
+from oracle import nets
+from oracle import step as ostep
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+META = json.load(open(os.path.join(GOLD, "meta.json")))
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_micro_semantics():
+    g0 = np.load(os.path.join(GOLD, "g0_micro.npz"))
+    up = TF.interpolate(torch.from_numpy(g0["up_in"]), size=(8, 8), mode="bilinear", align_corners=True)
+    assert rel(up, g0["up_out"]) < 1e-6
+    for h, o in META["maxpool_ceil_sizes"].items():
+        assert TF.max_pool2d(torch.zeros(1, 1, int(h), int(h)), 3, 2, 1, ceil_mode=True).shape[-1] == o
+    assert META["argmax_tie"] == [1, 0]
+    for e, v in META["lambda_lr"].items():
+        assert abs(ostep.lambda_lr(int(e), 400, 0, 100) - v) < 1e-15
+    np.random.seed(0)
+    pool = ostep.Pool(3)
+    assert [float(pool(np.float32(i))) for i in range(12)] == META["pool_trace_seed0_cap3"]
+
+
+def test_running_score_matches_reference():
+    from oracle import weights as W
+    for ds, C in (("voc2012", 21), ("cityscapes", 20), ("acdc", 4)):
+        lt = W.randint(FX.SEED, "g5/lt/" + ds, (2, 16, 16), C).numpy()
+        lp = W.randint(FX.SEED, "g5/lp/" + ds, (2, 16, 16), C).numpy()
+        lp[0] = lt[0]
+        conf = sum(ostep.confusion(a, b, C) for a, b in zip(lt, lp))
+        acc, acc_cls, miou, _ = ostep.running_score(conf, ds)
+        ref = META["miou_" + ds]
+        assert abs(miou - ref["miou"]) < 1e-12 and abs(acc - ref["acc"]) < 1e-12 and abs(acc_cls - ref["acc_cls"]) < 1e-12
+
+
+BLOCKS = [
+    ("conv_norm_relu", "cnr", lambda sd, x: nets.conv_norm_act(sd["0.weight"], sd["0.bias"], x, 1, 1, "instance", "relu")),
+    ("conv_norm_lrelu", "cnl", lambda sd, x: nets.conv_norm_act(sd["0.weight"], sd["0.bias"], x, 2, 1, "instance", "lrelu")),
+    ("dconv_norm_relu", "dcnr", lambda sd, x: nets.conv_norm_act(sd["0.weight"], sd["0.bias"], x, 2, 1, "instance", "relu", transposed=True, out_pad=1)),
+    ("bottleneck", "bneck", lambda sd, x: nets.bottleneck({"b." + k: v for k, v in sd.items()}, "b", x, 1, 2, True)),
+    ("classifier", "cls", lambda sd, x: nets.deeplab_stage({"layer5." + k: v for k, v in sd.items()}, "layer5", x)),
+]
+
+
+@pytest.mark.parametrize("blk", BLOCKS, ids=[b[0] for b in BLOCKS])
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_blocks(blk, dt):
+    g1 = np.load(os.path.join(GOLD, "g1_blocks.npz"))
+    gname, wname, fn = blk
+    dtype = torch.float32 if dt == "f32" else torch.float64
+    sd = FX.block_state(wname, dtype)
+    if wname == "bneck":
+        for k in list(sd):
+            if k.endswith("running_var"):
+                sd[k.replace("running_var", "num_batches_tracked")] = torch.zeros((), dtype=torch.int64)
+    x = FX.block_input(wname, dtype).requires_grad_(True)
+    params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+    y = fn(sd, x)
+    tol = 1e-5 if dt == "f32" else 1e-10
+    assert rel(y, g1["%s/y/%s" % (gname, dt)]) < tol
+    y.backward(FX.block_grad_out(gname, y.shape, dtype))
+    assert rel(x.grad, g1["%s/dx/%s" % (gname, dt)]) < 20 * tol
+    for k, v in sd.items():
+        key = "%s/d_%s/%s" % (gname, k, dt)
+        if key in g1.files and v.grad is not None:
+            assert rel(v.grad, g1[key]) < 20 * tol, k
+
+
+@pytest.mark.parametrize("net", FX.NETS, ids=[n[0] for n in FX.NETS])
+def test_networks_fp64(net):
+    g2 = np.load(os.path.join(GOLD, "g2_nets.npz"))
+    name, kind, args, xshape = net
+    sd = FX.net_weights(name, kind, args, torch.float64)
+    x = FX.net_input(name, xshape, torch.float64).requires_grad_(True)
+    y = FX.oracle_forward(kind, sd, x)
+    assert rel(y, g2[name + "/y/f64"]) < 1e-9
+    (y * FX.net_grad_out(name, y.shape, torch.float64)).sum().backward()
+    assert rel(x.grad, g2[name + "/dx/f64"]) < 1e-8
+
+
+def test_training_steps_s64_fp32():
+    """Three full G+D steps: the restatement reproduced the reference's recorded losses bit-for-bit at the
+    generator's thread count; elsewhere the fp32 summation order may differ (bounded by the fp32-fp64 gap)."""
+    info = META["g3"]["s64"]
+    C, dataset, H, Wd, B, steps = FX.STEP_CONFIGS["s64"]
+    torch.set_num_threads(META["threads"])
+    o = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float32, "s64"), crop=(H, Wd))
+    np.random.seed(0)
+    same_threads = torch.get_num_threads() == META["threads"]
+    for s in range(steps):
+        got = o.step(*FX.step_batch("s64", s, C, H, Wd, B))
+        for k in ostep.LOSS_KEYS:
+            ref, r64 = info["reference_f32"][s][k], info["oracle_f64"][s][k]
+            gap = max(abs(ref - r64) / abs(r64), 1e-6)
+            e = abs(got[k] - ref) / abs(ref)
+            assert e < (1e-6 if same_threads and os.cpu_count() >= META["threads"] else 4 * gap) or e < 4 * gap, (s, k, got[k], ref)
+
+
+def test_supervised_steps_fp64():
+    cfg = META["g4"]["config"]
+    o = ostep.SupervisedOracle(cfg["C"], FX.supervised_state_dict(cfg["C"], torch.float64), crop=(cfg["H"], cfg["H"]))
+    smp = [FX.synth_sample("sup/lab", b, cfg["C"], cfg["H"], cfg["H"], torch.float64) for b in range(cfg["B"])]
+    loss = o.step(torch.stack([a for a, _ in smp]), torch.stack([g for _, g in smp]))
+    assert abs(loss - META["g4"]["oracle_f64"][0]) / loss < 1e-9
+    assert abs(loss - META["g4"]["reference_f32"][0]) / loss < 1e-4   # fp32 reference vs fp64 restatement, first step
