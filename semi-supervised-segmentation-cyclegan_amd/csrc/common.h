@@ -50,6 +50,14 @@ __device__ __forceinline__ int fd_div(int n, const FastDiv& f) {
     return (int)((__umulhi((uint32_t)n, f.mul) + (uint32_t)n) >> f.shift);
 }
 
+// XCD-aware workgroup remap (bijective): the dispatcher places block b on XCD b % 8 (observed, speed only);
+// give every XCD a contiguous chunk of the logical tile space so that neighbouring tiles share its private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // wave64 all-lane sum (double) through ds_bpermute-free shuffles

@@ -18,6 +18,11 @@
 // four consecutive k of row i at k-offset h*4 with one ds_read_b128 and feeds them to four MFMAs:
 // the k -> (instruction, half) assignment is a permutation applied identically to A and B, which
 // a reduction does not care about.
+//
+// Loader: a thread always stages the same PA rows of A / PB rows of B and the same k column, so all
+// row decoding happens once.  FAST path (source channels a multiple of BK, i.e. every >=64-channel
+// layer): a k-tile never straddles a tap, so the gather address of a row changes only at tap
+// boundaries (wave-uniform branch every Cs/BK tiles) and the per-tile loader work is a pointer bump.
 #include "common.h"
 #include "sscg_internal.h"
 
@@ -44,11 +49,12 @@ struct KcParams {
     int tiles_n;
 };
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST>
 __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(!FAST || VEC == 4, "fast path is vectorised");
     // loader geometry
     constexpr int KQ = BK / VEC;          // threads along k
     constexpr int RPP = 256 / KQ;         // rows per pass
@@ -59,91 +65,153 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* As = reinterpret_cast<float*>(smem_raw);                 // [2][BM][LDK]
     float* Bs = As + 2 * BM * LDK;                                  // [2][BN][LDK]
-    int* rowinfo = reinterpret_cast<int*>(Bs + 2 * BN * LDK);       // [BM][4]: pixbase, y0, x0, valid
-    int* tapinfo = rowinfo + BM * 4;                                // [R*S]: (dy << 16) | dx
+    int* tapinfo = reinterpret_cast<int*>(Bs + 2 * BN * LDK);       // [R*S]: (dy << 16) | dx
 
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = tile % p.tiles_n;
     const int tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
-    for (int r = tid; r < BM; r += 256) {
-        int m = m0 + r;
-        int4 info;
-        if (m < p.M) {
-            int img = m / (p.OH * p.OW);
-            int rem = m - img * (p.OH * p.OW);
-            int oy = rem / p.OW;
-            int ox = rem - oy * p.OW;
-            info.x = img * p.SH * p.SW;
-            if (MODE == MODE_FWD) {
-                info.y = oy * p.stride - p.pad;
-                info.z = ox * p.stride - p.pad;
-            } else {
-                info.y = oy + p.pad;
-                info.z = ox + p.pad;
-            }
-            info.w = 1;
-        } else {
-            info.x = 0; info.y = 0; info.z = 0; info.w = 0;
-        }
-        reinterpret_cast<int4*>(rowinfo)[r] = info;
-    }
     for (int t = tid; t < p.R * p.S; t += 256) {
         int ky = t / p.S;
         int kx = t - ky * p.S;
         tapinfo[t] = ((ky * p.dil) << 16) | (kx * p.dil);
     }
-    __syncthreads();
 
     const int kq = tid % KQ;
     const int r0 = tid / KQ;
 
+    // ---- per-thread loader state (decoded once)
+    const float* arow[PA];   // image base of the row's source
+    int ay0[PA], ax0[PA];
+    bool aok[PA];
+#pragma unroll
+    for (int ps = 0; ps < PA; ++ps) {
+        const int m = m0 + r0 + ps * RPP;
+        aok[ps] = m < p.M;
+        const int mm = aok[ps] ? m : 0;
+        const int img = mm / (p.OH * p.OW);
+        const int rem = mm - img * (p.OH * p.OW);
+        const int oy = rem / p.OW;
+        const int ox = rem - oy * p.OW;
+        arow[ps] = p.src + (size_t)img * p.SH * p.SW * p.Cs;
+        if (MODE == MODE_FWD) {
+            ay0[ps] = oy * p.stride - p.pad;
+            ax0[ps] = ox * p.stride - p.pad;
+        } else {
+            ay0[ps] = oy + p.pad;
+            ax0[ps] = ox + p.pad;
+        }
+    }
+    const float* brow[PB];
+    bool bok[PB];
+#pragma unroll
+    for (int ps = 0; ps < PB; ++ps) {
+        const int n = n0 + r0 + ps * RPP;
+        bok[ps] = n < p.Ng;
+        brow[ps] = p.wgt + (size_t)(bok[ps] ? n : 0) * p.Ktot + kq * VEC;
+    }
+    __syncthreads();              // tapinfo visible
+
+    const bool reflect = p.pad_mode == 1;
+
+    // source pixel of row `ps` for tap offsets (tdy, tdx); returns validity
+    auto locate = [&](int ps, int tdy, int tdx, int& pix) -> bool {
+        bool ok = aok[ps];
+        int sy, sx;
+        if (MODE == MODE_FWD) {
+            sy = ay0[ps] + tdy;
+            sx = ax0[ps] + tdx;
+            int ry = sy < 0 ? -sy : sy;
+            int rx = sx < 0 ? -sx : sx;
+            ry = ry >= p.SH ? 2 * (p.SH - 1) - ry : ry;
+            rx = rx >= p.SW ? 2 * (p.SW - 1) - rx : rx;
+            sy = reflect ? ry : sy;
+            sx = reflect ? rx : sx;
+        } else {
+            const int ty = ay0[ps] - tdy;
+            const int tx = ax0[ps] - tdx;
+            if (p.stride == 1) {
+                sy = ty; sx = tx;
+            } else if (p.stride == 2) {
+                sy = ty >> 1; sx = tx >> 1;
+                ok = ok && (((ty | tx) & 1) == 0);
+            } else {
+                sy = ty / p.stride; sx = tx / p.stride;
+                ok = ok && (ty >= 0) && (tx >= 0) && (sy * p.stride == ty) && (sx * p.stride == tx);
+            }
+        }
+        ok = ok && ((unsigned)sy < (unsigned)p.SH) && ((unsigned)sx < (unsigned)p.SW);
+        pix = ok ? sy * p.SW + sx : 0;
+        return ok;
+    };
+
     float ra[PA][VEC];
     float rb[PB][VEC];
+    unsigned okmask = 0;   // validity of the staged loads; applied at LDS-store time so that the loaded registers are
+                           // not touched (=> not waited for) until the MFMAs of the current tile have been issued
 
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + kq * VEC;
-        const bool kvalid = k < p.Ktot;
-        int tap = 0, ci = 0, tdy = 0, tdx = 0;
-        if (kvalid) {
-            tap = k / p.Cs;
-            ci = k - tap * p.Cs;
-            int ti = tapinfo[tap];
-            tdy = ti >> 16;
-            tdx = ti & 0xffff;
-        }
+    // generic-path state: this thread's k column, advanced by BK per tile
+    int lk = kq * VEC;
+    // fast-path state
+    int f_chunk = 0, f_tap = 0, f_k = 0;
+    const int f_nchunk = FAST ? p.Cs / BK : 1;
+    const float* aptr[PA];
+    unsigned f_okbits = 0;
+
+    auto fast_set_tap = [&](int tap) {
+        const int ti = tapinfo[tap];
+        const int tdy = ti >> 16, tdx = ti & 0xffff;
+        f_okbits = 0;
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
-            const int r = r0 + ps * RPP;
-            int4 info = reinterpret_cast<const int4*>(rowinfo)[r];
-            bool ok = kvalid && info.w;
-            int sy, sx;
-            if (MODE == MODE_FWD) {
-                sy = info.y + tdy;
-                sx = info.z + tdx;
-                if (p.pad_mode == 1) {
-                    sy = sy < 0 ? -sy : sy;
-                    sx = sx < 0 ? -sx : sx;
-                    sy = sy >= p.SH ? 2 * (p.SH - 1) - sy : sy;
-                    sx = sx >= p.SW ? 2 * (p.SW - 1) - sx : sx;
-                }
-            } else {
-                int ty = info.y - tdy;
-                int tx = info.z - tdx;
-                if (p.stride == 1) {
-                    sy = ty; sx = tx;
-                } else {
-                    sy = ty / p.stride;
-                    sx = tx / p.stride;
-                    ok = ok && (ty >= 0) && (tx >= 0) && (sy * p.stride == ty) && (sx * p.stride == tx);
-                }
+            int pix;
+            const bool ok = locate(ps, tdy, tdx, pix);
+            f_okbits |= ok ? (1u << ps) : 0u;
+            aptr[ps] = arow[ps] + (size_t)pix * p.Cs + kq * VEC;
+        }
+    };
+    if (FAST) fast_set_tap(0);
+
+    auto load_tile = [&]() {
+        if constexpr (FAST) {
+            if (f_chunk == f_nchunk) {       // wave-uniform: next tap
+                f_chunk = 0;
+                ++f_tap;
+                fast_set_tap(f_tap < p.R * p.S ? f_tap : 0);
             }
-            ok = ok && ((unsigned)sy < (unsigned)p.SH) && ((unsigned)sx < (unsigned)p.SW);
-            if (ok) {
-                const float* g = p.src + ((size_t)(info.x + sy * p.SW + sx) * p.Cs + ci);
+            okmask = f_okbits;
+            const int coff = f_chunk * BK;
+#pragma unroll
+            for (int ps = 0; ps < PA; ++ps) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(aptr[ps] + coff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[ps][e] = v[e];
+            }
+#pragma unroll
+            for (int ps = 0; ps < PB; ++ps) {
+                okmask |= bok[ps] ? (1u << (16 + ps)) : 0u;
+                f32x4 v = *reinterpret_cast<const f32x4*>(brow[ps] + f_k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[ps][e] = v[e];
+            }
+            ++f_chunk;
+            f_k += BK;
+        } else {
+            okmask = 0;
+            const bool kvalid = lk < p.Ktot;
+            const int tap = kvalid ? lk / p.Cs : 0;
+            const int ci = kvalid ? lk - tap * p.Cs : 0;
+            const int ti = tapinfo[tap];
+            const int tdy = ti >> 16, tdx = ti & 0xffff;
+#pragma unroll
+            for (int ps = 0; ps < PA; ++ps) {
+                int pix;
+                const bool ok = locate(ps, tdy, tdx, pix) && kvalid;
+                okmask |= ok ? (1u << ps) : 0u;
+                const float* g = arow[ps] + ((size_t)(ok ? pix : 0) * p.Cs + ci);
                 if constexpr (VEC == 4) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(g);
 #pragma unroll
@@ -151,16 +219,12 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
                 } else {
                     ra[ps][0] = *g;
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) ra[ps][e] = 0.f;
             }
-        }
 #pragma unroll
-        for (int ps = 0; ps < PB; ++ps) {
-            const int n = n0 + r0 + ps * RPP;
-            if (kvalid && n < p.Ng) {
-                const float* g = p.wgt + ((size_t)n * p.Ktot + k);
+            for (int ps = 0; ps < PB; ++ps) {
+                const bool ok = kvalid && bok[ps];
+                okmask |= ok ? (1u << (16 + ps)) : 0u;
+                const float* g = brow[ps] + (ok ? lk - kq * VEC : 0);
                 if constexpr (VEC == 4) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(g);
 #pragma unroll
@@ -168,10 +232,8 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
                 } else {
                     rb[ps][0] = *g;
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) rb[ps][e] = 0.f;
             }
+            lk += BK;
         }
     };
 
@@ -181,25 +243,27 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
             float* d = a + (r0 + ps * RPP) * LDK + kq * VEC;
+            const bool ok = (okmask >> ps) & 1u;
             if constexpr (VEC == 4) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ra[ps][e];
+                for (int e = 0; e < 4; ++e) v[e] = ok ? ra[ps][e] : 0.f;
                 *reinterpret_cast<f32x4*>(d) = v;
             } else {
-                *d = ra[ps][0];
+                *d = ok ? ra[ps][0] : 0.f;
             }
         }
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
             float* d = b + (r0 + ps * RPP) * LDK + kq * VEC;
+            const bool ok = (okmask >> (16 + ps)) & 1u;
             if constexpr (VEC == 4) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rb[ps][e];
+                for (int e = 0; e < 4; ++e) v[e] = ok ? rb[ps][e] : 0.f;
                 *reinterpret_cast<f32x4*>(d) = v;
             } else {
-                *d = rb[ps][0];
+                *d = ok ? rb[ps][0] : 0.f;
             }
         }
     };
@@ -222,29 +286,37 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = (p.Ktot + BK - 1) / BK;
-    load_tile(0);
+    load_tile();
     store_tile(0);
     __syncthreads();
-
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
         const float* a = As + buf * BM * LDK + (row_w + li) * LDK + lh * 4;
         const float* b = Bs + buf * BN * LDK + (col_w + li) * LDK + lh * 4;
+        f32x4 fa[2][TM], fb[2][TN];
+        // fragments of the first k-group are requested right after the barrier ...
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK);
+        // ... and the global loads of tile kt+1 are issued under their latency; they land under the MFMAs
+        if (kt + 1 < nk) load_tile();
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 fa[TM], fb[TN];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + kk * 8);
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + (kk + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + kk * 8);
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + (kk + 1) * 8);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
@@ -267,15 +339,15 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     }
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST>
 int launch_kc(const KcParams& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     KcParams p = p0;
     p.tiles_n = cdiv(p.Ng, BN);
     int tiles_m = cdiv(p.M, BM);
-    size_t smem = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (size_t)BM * 16 + (size_t)p.R * p.S * 4;
-    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC>;
+    size_t smem = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (size_t)p.R * p.S * 4;
+    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -285,28 +357,33 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     return SSCG_OK;
 }
 
-// Tile choice: biggest tile that still gives the chip ~2 workgroups per CU; narrow-N tile for
-// heads with a handful of output channels.
-template <int MODE, int VEC>
+// Tile choice (measured on MI355X, tools/conv_bench.py): 128x128 only when it still yields >= ~2 workgroups
+// per CU; otherwise 64x64, whose finer granularity balances the 256 CUs better on the DeepLab stride-8 maps
+// (8 x 33 x 33 = 8712 rows); a 128x32 tile for heads with a handful of output channels.
+template <int MODE, int VEC, bool FAST>
 int dispatch_kc(const KcParams& p, hipStream_t st, int force_cfg) {
     auto wgs = [&](int bm, int bn) { return (long)cdiv(p.M, bm) * cdiv(p.Ng, bn); };
     int cfg = force_cfg;
     if (cfg < 0) {
         if (p.Ng <= 32) cfg = 4;
-        else if (wgs(128, 128) >= 512) cfg = 0;
-        else if (p.Ng <= 64 && wgs(128, 64) >= 384) cfg = 1;
-        else if (wgs(64, 128) >= 512) cfg = 2;
-        else if (wgs(128, 64) >= 512) cfg = 1;
+        else if (wgs(128, 128) >= 512 && p.Ktot >= 1024) cfg = 0;   // long reductions amortise the big tile's prologue
         else cfg = 3;
     }
     switch (cfg) {
-        case 0: return launch_kc<MODE, 2, 2, 2, 2, VEC>(p, st);
-        case 1: return launch_kc<MODE, 2, 2, 2, 1, VEC>(p, st);
-        case 2: return launch_kc<MODE, 2, 2, 1, 2, VEC>(p, st);
-        case 3: return launch_kc<MODE, 2, 2, 1, 1, VEC>(p, st);
-        case 4: return launch_kc<MODE, 4, 1, 1, 1, VEC>(p, st);
+        case 0: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST>(p, st);
+        case 1: return launch_kc<MODE, 2, 2, 2, 1, VEC, FAST>(p, st);
+        case 2: return launch_kc<MODE, 2, 2, 1, 2, VEC, FAST>(p, st);
+        case 3: return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST>(p, st);
+        case 4: return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST>(p, st);
         default: return SSCG_ERR_BAD_ARG;
     }
+}
+
+template <int MODE>
+int dispatch_mode(const KcParams& p, hipStream_t st, int force_cfg) {
+    if (p.Cs % BK == 0) return dispatch_kc<MODE, 4, true>(p, st, force_cfg);
+    if (p.Cs % 4 == 0) return dispatch_kc<MODE, 4, false>(p, st, force_cfg);
+    return dispatch_kc<MODE, 1, false>(p, st, force_cfg);
 }
 
 }  // namespace
@@ -326,8 +403,10 @@ static int check_desc(const sscg_conv_desc* d) {
     int Q = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
     if (P != d->P || Q != d->Q) return SSCG_ERR_BAD_ARG;
     if (d->pad_mode == 1 && (d->pad >= d->H || d->pad >= d->W)) return SSCG_ERR_BAD_ARG;
-    if ((long)d->N * d->H * d->W * (long)d->C >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
-    if ((long)d->N * d->P * d->Q * (long)d->K >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
+    // per-image extents are indexed with 32-bit arithmetic
+    if ((long)d->H * d->W * (long)d->C >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
+    if ((long)d->P * d->Q * (long)d->K >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
+    if ((long)d->N * d->H * d->W >= (1L << 31) || (long)d->N * d->P * d->Q >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
     return SSCG_OK;
 }
 
@@ -342,9 +421,7 @@ extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const fl
     p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope; p.tiles_n = 0;
-    hipStream_t st = (hipStream_t)stream;
-    if (d->C % 4 == 0) return dispatch_kc<MODE_FWD, 4>(p, st, sscg_force_conv_cfg);
-    return dispatch_kc<MODE_FWD, 1>(p, st, sscg_force_conv_cfg);
+    return dispatch_mode<MODE_FWD>(p, (hipStream_t)stream, sscg_force_conv_cfg);
 }
 
 // Data gradient (and ConvTranspose2d forward): dx[n][iy][ix][c] = sum_{ky,kx,k} dy[n][oy][ox][k] * wt[c][ky][kx][k]
@@ -364,9 +441,7 @@ extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const
     p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = 0; p.act = act; p.slope = slope; p.tiles_n = 0;
-    hipStream_t st = (hipStream_t)stream;
-    if (d->K % 4 == 0) return dispatch_kc<MODE_DGRAD, 4>(p, st, sscg_force_conv_cfg);
-    return dispatch_kc<MODE_DGRAD, 1>(p, st, sscg_force_conv_cfg);
+    return dispatch_mode<MODE_DGRAD>(p, (hipStream_t)stream, sscg_force_conv_cfg);
 }
 
 // [K][RS][C] -> [C][RS][K] (weights are a few MB; one pass per optimiser step per conv that needs dgrad)
