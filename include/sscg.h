@@ -75,6 +75,8 @@ int sscg_colsum(const float* x, float* out, int64_t rows, int cols, float beta, 
 
 /* tuning/test hook: force the forward/dgrad tile configuration (-1 = heuristic) */
 int sscg_debug_set_conv_cfg(int cfg);
+/* tuning hook: wgrad split plan (target workgroup count, minimum k-steps per split for 128x128 tiles) */
+int sscg_debug_set_wgrad_plan(int target_wgs, int min_iters);
 
 /* ------------------------------------------------------------------ normalisation (K3, K4, K7)
  * x is viewed as [G][L][C]: InstanceNorm2d (arch/ops.py:11: affine=False, no running stats) has G = N,

@@ -45,6 +45,7 @@ SIGNATURES = {
     "sscg_colsum_workspace": (_sz, [_i64, _i]),
     "sscg_colsum": (_i, [_p, _p, _i64, _i, _f, _p, _sz, _p]),
     "sscg_debug_set_conv_cfg": (_i, [_i]),
+    "sscg_debug_set_wgrad_plan": (_i, [_i, _i]),
     "sscg_norm_stats_workspace": (_sz, [_i, _i64, _i]),
     "sscg_norm_stats": (_i, [_p, _i, _i64, _i, _f, _p, _p, _p, _p, _f, _p, _sz, _p]),
     "sscg_norm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _f, _p]),

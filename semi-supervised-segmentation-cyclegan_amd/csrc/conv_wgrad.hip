@@ -32,6 +32,8 @@ struct WgParams {
     int npix;                 // N*P*Q
     int chunk;                // pixels per split (multiple of BKP)
     int tiles_n;
+    int tiles;                // tiles_m * tiles_n
+    int splits;
     float beta;               // applied only when splits == 1
     FastDiv div_pq, div_q;
 };
@@ -55,9 +57,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     float* Bs = As + 2 * BKP * LDA;                  // [2][BKP][LDB]
 
     const int tid = threadIdx.x;
-    const int tile_n = blockIdx.x % p.tiles_n;
-    const int tile_m = blockIdx.x / p.tiles_n;
-    const int split = blockIdx.y;
+    // flattened (split, tile) space, XCD-aware: an XCD works on few pixel ranges => dy/x chunks stay in its L2
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / p.tiles;
+    const int tl = lin - split * p.tiles;
+    const int tile_n = tl % p.tiles_n;
+    const int tile_m = tl / p.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int p_begin = split * p.chunk;
@@ -83,57 +88,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
 
     float ra[PA][VA];
     float rb[PB][VB];
+    unsigned okmask = 0;   // applied at LDS-store time: the staged registers stay untouched under the MFMAs
+
+    const float* dyc = p.dy + (a_col_ok ? ma : 0);      // this thread's dy column
+    const float* xc = p.x + cch;                        // this thread's x channel group
+    const bool reflect = p.pad_mode == 1;
 
     auto load_tile = [&](int pt) {
+        okmask = 0;
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
             const int pix = pt + ra0 + ps * RA;
-            if (a_col_ok && pix < p_end) {
-                const float* g = p.dy + ((size_t)pix * p.Kc + ma);
-                if constexpr (VA == 4) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(g);
+            const bool ok = a_col_ok && pix < p_end;
+            okmask |= ok ? (1u << ps) : 0u;
+            const float* g = dyc + (size_t)(ok ? pix : 0) * p.Kc;
+            if constexpr (VA == 4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(g);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ra[ps][e] = v[e];
-                } else {
-                    ra[ps][0] = *g;
-                }
+                for (int e = 0; e < 4; ++e) ra[ps][e] = v[e];
             } else {
-#pragma unroll
-                for (int e = 0; e < VA; ++e) ra[ps][e] = 0.f;
+                ra[ps][0] = *g;
             }
         }
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
             const int pix = pt + rb0 + ps * RB;
             bool ok = b_col_ok && pix < p_end;
-            int img = 0, sy = 0, sx = 0;
-            if (ok) {
-                img = fd_div(pix, p.div_pq);
-                int rem = pix - img * (p.P * p.Q);
-                int oy = fd_div(rem, p.div_q);
-                int ox = rem - oy * p.Q;
-                sy = oy * p.stride + tdy;
-                sx = ox * p.stride + tdx;
-                if (p.pad_mode == 1) {
-                    sy = sy < 0 ? -sy : sy;
-                    sx = sx < 0 ? -sx : sx;
-                    sy = sy >= p.H ? 2 * (p.H - 1) - sy : sy;
-                    sx = sx >= p.W ? 2 * (p.W - 1) - sx : sx;
-                }
-                ok = ((unsigned)sy < (unsigned)p.H) && ((unsigned)sx < (unsigned)p.W);
-            }
-            if (ok) {
-                const float* g = p.x + ((size_t)((img * p.H + sy) * p.W + sx) * p.C + cch);
-                if constexpr (VB == 4) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(g);
+            const int pp = ok ? pix : 0;
+            const int img = fd_div(pp, p.div_pq);
+            const int rem = pp - img * (p.P * p.Q);
+            const int oy = fd_div(rem, p.div_q);
+            const int ox = rem - oy * p.Q;
+            int sy = oy * p.stride + tdy;
+            int sx = ox * p.stride + tdx;
+            int ry = sy < 0 ? -sy : sy;
+            int rx = sx < 0 ? -sx : sx;
+            ry = ry >= p.H ? 2 * (p.H - 1) - ry : ry;
+            rx = rx >= p.W ? 2 * (p.W - 1) - rx : rx;
+            sy = reflect ? ry : sy;
+            sx = reflect ? rx : sx;
+            ok = ok && ((unsigned)sy < (unsigned)p.H) && ((unsigned)sx < (unsigned)p.W);
+            okmask |= ok ? (1u << (16 + ps)) : 0u;
+            const int spix = ok ? (img * p.H + sy) * p.W + sx : 0;
+            const float* g = xc + (size_t)spix * p.C;
+            if constexpr (VB == 4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(g);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rb[ps][e] = v[e];
-                } else {
-                    rb[ps][0] = *g;
-                }
+                for (int e = 0; e < 4; ++e) rb[ps][e] = v[e];
             } else {
-#pragma unroll
-                for (int e = 0; e < VB; ++e) rb[ps][e] = 0.f;
+                rb[ps][0] = *g;
             }
         }
     };
@@ -144,25 +147,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
             float* d = a + (ra0 + ps * RA) * LDA + ca * VA;
+            const bool ok = (okmask >> ps) & 1u;
             if constexpr (VA == 4) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ra[ps][e];
+                for (int e = 0; e < 4; ++e) v[e] = ok ? ra[ps][e] : 0.f;
                 *reinterpret_cast<f32x4*>(d) = v;
             } else {
-                *d = ra[ps][0];
+                *d = ok ? ra[ps][0] : 0.f;
             }
         }
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
             float* d = b + (rb0 + ps * RB) * LDB + cb * VB;
+            const bool ok = (okmask >> (16 + ps)) & 1u;
             if constexpr (VB == 4) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rb[ps][e];
+                for (int e = 0; e < 4; ++e) v[e] = ok ? rb[ps][e] : 0.f;
                 *reinterpret_cast<f32x4*>(d) = v;
             } else {
-                *d = rb[ps][0];
+                *d = ok ? rb[ps][0] : 0.f;
             }
         }
     };
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     }
 
     float* out = p.out + (size_t)split * p.Kc * p.Ng;
-    const bool direct = (gridDim.y == 1);
+    const bool direct = (p.splits == 1);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + col_w + j * 32 + li;
@@ -250,23 +255,35 @@ struct WgPlan {
     int chunk;
 };
 
+int sscg_wgrad_target_wgs = 768;   // tuning hooks (sscg_debug_set_wgrad_plan); defaults from tools/conv_bench.py sweeps
+int sscg_wgrad_min_iters = 12;
+
 WgPlan plan_wgrad(const sscg_conv_desc* d) {
     WgPlan pl;
     const int Kc = d->K;
     const int Ng = d->R * d->S * d->C;
+    const long npix = (long)d->N * d->P * d->Q;
+    const long steps = cdiv(npix, BKP);
+    auto splits_for = [&](int bm, int bn) {
+        long tiles = (long)cdiv(Kc, bm) * cdiv(Ng, bn);
+        long s = cdiv(sscg_wgrad_target_wgs, tiles);
+        if (s < 1) s = 1;
+        long mx = steps / 4 < 1 ? 1 : steps / 4;   // at least 4 k-steps per split
+        if (s > mx) s = mx;
+        if (s > 64) s = 64;
+        return s;
+    };
     if (Kc <= 32) { pl.cfg = 2; pl.bm = 32; pl.bn = 128; }
     else if (Ng <= 32 || d->C < 32) { pl.cfg = 3; pl.bm = 128; pl.bn = 32; }
     else if (Kc <= 64 || Ng <= 64) { pl.cfg = 1; pl.bm = 64; pl.bn = 64; }
-    else { pl.cfg = 0; pl.bm = 128; pl.bn = 128; }
-    const long npix = (long)d->N * d->P * d->Q;
-    const long tiles = (long)cdiv(Kc, pl.bm) * cdiv(Ng, pl.bn);
-    long steps = cdiv(npix, BKP);
-    long want = cdiv(768, tiles);
-    long splits = want < 1 ? 1 : want;
-    // keep at least 4 k-steps per split
-    long max_splits = steps / 4 < 1 ? 1 : steps / 4;
-    if (splits > max_splits) splits = max_splits;
-    if (splits > 64) splits = 64;
+    else {
+        // 128x128 tiles only if every workgroup still gets a long enough pixel range; otherwise 64x64 tiles:
+        // 4x the tiles => 1/4 of the splits => 1/4 of the partial-sum traffic and 4x longer main loops
+        long s0 = splits_for(128, 128);
+        if (steps / s0 >= sscg_wgrad_min_iters) { pl.cfg = 0; pl.bm = 128; pl.bn = 128; }
+        else { pl.cfg = 1; pl.bm = 64; pl.bn = 64; }
+    }
+    long splits = splits_for(pl.bm, pl.bn);
     long steps_per = cdiv(steps, splits);
     pl.chunk = (int)(steps_per * BKP);
     pl.splits = cdiv(npix, pl.chunk);
@@ -279,13 +296,15 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
     constexpr int BN = WN * TN * 32;
     p.tiles_n = cdiv(p.Ng, BN);
     int tiles_m = cdiv(p.Kc, BM);
+    p.tiles = tiles_m * p.tiles_n;
+    p.splits = splits;
     size_t smem = (size_t)(2 * BKP * (BM + 4) + 2 * BKP * (BN + 4)) * sizeof(float);
     auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VA, VB>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, splits), dim3(256), smem, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles * splits), dim3(256), smem, st, p);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -302,6 +321,12 @@ int dispatch_wg(const WgParams& p, const WgPlan& pl, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int sscg_debug_set_wgrad_plan(int target_wgs, int min_iters) {
+    if (target_wgs > 0) sscg_wgrad_target_wgs = target_wgs;
+    if (min_iters > 0) sscg_wgrad_min_iters = min_iters;
+    return SSCG_OK;
+}
 
 extern "C" size_t sscg_conv2d_wgrad_workspace(const sscg_conv_desc* d) {
     if (!d) return 0;
@@ -327,7 +352,7 @@ extern "C" int sscg_conv2d_wgrad(const sscg_conv_desc* d, const float* x, const 
     p.Kc = d->K; p.Ng = d->R * d->S * d->C; p.C = d->C;
     p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.S = d->S;
     p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.pad_mode = d->pad_mode;
-    p.npix = d->N * d->P * d->Q; p.chunk = pl.chunk; p.tiles_n = 0;
+    p.npix = d->N * d->P * d->Q; p.chunk = pl.chunk; p.tiles_n = 0; p.tiles = 0; p.splits = 1;
     p.beta = pl.splits > 1 ? 0.f : beta;
     p.div_pq = make_fastdiv(d->P * d->Q);
     p.div_q = make_fastdiv(d->Q);

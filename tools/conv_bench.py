@@ -59,8 +59,11 @@ def main():
             except Exception as e:
                 line += " | cfg%2d ERR" % cfg
         F.lib.sscg_debug_set_conv_cfg(-1)
-        tw = timeit(lambda: F.conv2d_wgrad(x, gy, w.shape, s, p, d))
-        line += " | wgrad %5.1f TF/s" % (flops / tw / 1e12)
+        for (tw_, mi_) in ((768, 1), (1024, 8), (1536, 8), (1024, 16), (768, 12), (2048, 12)):
+            F.lib.sscg_debug_set_wgrad_plan(tw_, mi_)
+            tw = timeit(lambda: F.conv2d_wgrad(x, gy, w.shape, s, p, d))
+            line += " | wg(%d,%d) %5.1f" % (tw_, mi_, flops / tw / 1e12)
+        F.lib.sscg_debug_set_wgrad_plan(768, 12)
         print(line)
         sys.stdout.flush()
 
