@@ -36,21 +36,63 @@ def _need_hip(t):
 
 
 class _Workspace:
-    """One growable scratch buffer per device (stream-ordered reuse on torch's current stream)."""
+    """One growable scratch buffer per (device, stream): reuse is ordered by the stream it is used on."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 16)
-        b = self.buf.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
-            self.buf[device] = b
+            self.buf[key] = b
         return b
 
 
 _WS = _Workspace()
+
+
+class SideStream:
+    """A second HIP stream per device for work that is independent of the main stream's critical path:
+    weight gradients (needed only by the optimiser step) and the frozen generators' forward (needed only by
+    the discriminator step).  Two kernels in flight let the dispatcher fill the CUs that one launch with an
+    awkward workgroup count (8712-row DeepLab maps: 548 workgroups on 256 CUs) leaves idle."""
+
+    enabled = True
+    _streams = {}
+
+    @classmethod
+    def get(cls, device):
+        s = cls._streams.get(device)
+        if s is None:
+            s = torch.cuda.Stream(device=device)
+            cls._streams[device] = s
+        return s
+
+    @classmethod
+    def join(cls, device=None):
+        """Make the current stream wait for everything queued on the side stream(s)."""
+        for dev, s in cls._streams.items():
+            if device is None or dev == device:
+                torch.cuda.current_stream(dev).wait_stream(s)
+
+
+def run_on_side_stream(device, tensors, fn):
+    """Launch `fn`'s kernels on the side stream after everything queued so far on the current stream.
+    `tensors` are the buffers fn reads: the allocator must not recycle them before the side stream is done."""
+    if not SideStream.enabled:
+        return fn()
+    main = torch.cuda.current_stream(device)
+    side = SideStream.get(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        r = fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    return r
 
 
 def empty_nhwc(n, c, h, w, device, dtype=torch.float32):
@@ -441,19 +483,25 @@ class Conv2dFn(torch.autograd.Function):
             if pad_mode == PAD_REFLECT:
                 raise _lib.SscgError("input gradient through a reflection-padded conv: use ReflectPadFn + pad=0 conv")
             dx = conv2d_dgrad(dy, _cached_wt(ctx.wref), x.shape, w.shape, stride, pad, dil)
-        if ctx.needs_input_grad[1]:
-            acc = _acc_target(ctx.wref)
-            if acc is not None:
-                conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode, out=acc, accumulate=True)
-            else:
-                dw = conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            n, k, p, q = dy.shape
-            acc = _acc_target(ctx.bref)
-            if acc is not None:
-                colsum(n * p * q, k, dy, out=acc, accumulate=True)
-            else:
-                db = colsum(n * p * q, k, dy)
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        wacc = _acc_target(ctx.wref) if want_w else None
+        bacc = _acc_target(ctx.bref) if want_b else None
+        n, k, p, q = dy.shape
+
+        def arena_grads():      # accumulate straight into the optimiser's gradient arena
+            if wacc is not None:
+                conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode, out=wacc, accumulate=True)
+            if bacc is not None:
+                colsum(n * p * q, k, dy, out=bacc, accumulate=True)
+
+        if wacc is not None or bacc is not None:
+            # nothing on the backward critical path reads these: run them beside the data-gradient chain
+            run_on_side_stream(dy.device, (x, dy), arena_grads)
+        if want_w and wacc is None:
+            dw = conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode)
+        if want_b and bacc is None:
+            db = colsum(n * p * q, k, dy)
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -93,6 +93,17 @@ class semisuper_cycleGAN(object):
         self.g_optimizer.zero_grad()
         labels = l_gt.reshape(l_gt.shape[0], l_gt.shape[2], l_gt.shape[3])          # l_gt.squeeze(1)
         onehot_gt = make_one_hot(l_gt, a.dataset, a.gpu_ids)
+
+        # The frozen generators depend only on the input images and feed only the D step: their forward runs
+        # on the side stream, concurrently with the DeepLab forwards/backwards below.
+        def frozen_branch():
+            with torch.no_grad():
+                fake = F.softmax2d(self.old_Gsi(unl_img))                            # :418,421
+                recon = self.old_Gis(fake)                                           # :422
+                if self.as_written:                                                  # :419-420,423: results never used
+                    self.old_Gis(F.softmax2d(self.old_Gsi(l_img)))
+            return recon
+        resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch)
         fake_img = self.interp(self.Gis(onehot_gt))                                  # :385,390
         fake_gt = self.interp(self.Gsi(unl_img))                                     # :386,391
         lab_gt = self.interp(self.Gsi(l_img))                                        # :387,392
@@ -103,11 +114,6 @@ class semisuper_cycleGAN(object):
         with torch.no_grad():
             self.Gis(lab_gt.detach())      # :409 - output unused by the reference, but it advances Gis' BN running stats
         recon_gt = self.interp(self.Gsi(fake_img))                                   # :410,415
-        with torch.no_grad():
-            resnet_fake_gt = F.softmax2d(self.old_Gsi(unl_img))                      # :418,421
-            resnet_recon_img = self.old_Gis(resnet_fake_gt)                          # :422
-            if self.as_written:                                                      # :419-420,423: results never used
-                self.old_Gis(F.softmax2d(self.old_Gsi(l_img)))
         fake_img_dis = self.Di(fake_img)                                             # :431
         resnet_fake_img_dis = self.old_Di(recon_img)                                 # :432
         fake_gt_onehot, _ = F.argmax_onehot(fake_gt.detach())                        # :435-437 (no gradient path)
@@ -122,6 +128,8 @@ class semisuper_cycleGAN(object):
             [lab_loss_CE, lab_loss_MSE, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss],
             [a.lab_CE_weight, a.lab_MSE_weight, a.adversarial_weight, a.adversarial_weight, 1.0, a.lamda_gt])
         gen_loss.backward()                                                          # :472
+        F.SideStream.join(l_img.device)            # side stream: weight gradients + frozen generators are complete
+        resnet_recon_img.record_stream(torch.cuda.current_stream(l_img.device))
         if self.dp is not None:
             self.dp.sync_grads(self.g_optimizer)
         self.g_optimizer.step()                                                      # :474
@@ -149,6 +157,7 @@ class semisuper_cycleGAN(object):
         dis_loss = F.weighted_sum([img_dis_loss, gt_dis_loss, cycle_img_dis_loss],
                                   [a.discriminator_weight, a.discriminator_weight, 1.0])  # :538
         dis_loss.backward()                                                          # :539
+        F.SideStream.join(l_img.device)
         if self.dp is not None:
             self.dp.sync_grads(self.d_optimizer)
         self.d_optimizer.step()                                                      # :542

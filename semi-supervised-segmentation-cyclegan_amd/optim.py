@@ -63,6 +63,7 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         g = self.param_groups[0]
         self._steps += 1
+        F.SideStream.join(self.arena.device)     # weight gradients are accumulated on the side stream
         F.adam_step(self.arena, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                     self._steps, 1.0 / self.world_size)
         F.bump_weight_epoch()
