@@ -103,9 +103,14 @@ def main():
     }
 
     if rank == 0 and not a.no_roofline:
+        # per-kernel timing needs the kernels one at a time: the side stream (concurrent weight gradients /
+        # frozen generators) is switched off for this extra, untimed step only
+        F.SideStream.enabled = False
+        torch.cuda.synchronize()
         with F.ConvProfile() as prof:
             run(a.warmup + a.steps)
         summ = prof.summary()
+        F.SideStream.enabled = True
         kc = {"flops": 0.0, "ms": 0.0, "launches": 0}
         for kind in ("fwd", "dgrad"):
             if kind in summ:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 1
+#define SSCG_ABI_VERSION 2
 
 #define SSCG_ERR_BAD_ARG (-1)
 #define SSCG_ERR_UNSUPPORTED (-2)
@@ -54,13 +54,16 @@ typedef struct sscg_conv_desc {
 
 /* nn.Conv2d forward: arch/ops.py:43,49,68; arch/generators.py:85,90,325,331,336,373,388,415;
  * arch/discriminators.py:45,58,70-75.  y = act(conv(x, w) + bias); bias may be NULL. */
-int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* stream);
+size_t sscg_conv2d_fwd_workspace(const sscg_conv_desc* d);   /* split-K scratch for few-channel heads; may be 0 */
+int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws,
+                    size_t ws_bytes, void* stream);
 
 /* Data gradient of the same conv (autograd of model.py:472,539), and nn.ConvTranspose2d forward
  * (arch/ops.py:55-56): dx = act(dgrad(dy, wt) + bias).  `wt` = weight re-laid as [C][R][S][K]
  * by sscg_weight_krsc_to_crsk.  bias NULL / act NONE for a pure gradient. */
+size_t sscg_conv2d_dgrad_workspace(const sscg_conv_desc* d);
 int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const float* wt, const float* bias, float* dx,
-                      int act, float slope, void* stream);
+                      int act, float slope, void* ws, size_t ws_bytes, void* stream);
 
 /* Weight gradient: dw = beta*dw + wgrad(x, dy); dw is [K][R][S][C]. */
 size_t sscg_conv2d_wgrad_workspace(const sscg_conv_desc* d);

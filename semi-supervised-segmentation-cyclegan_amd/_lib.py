@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsscg.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZEROS, PAD_REFLECT = 0, 1
@@ -37,8 +37,10 @@ _dp = C.POINTER(ConvDesc)
 # name -> (restype, argtypes); must list every symbol of include/sscg.h (tests/test_abi.py checks)
 SIGNATURES = {
     "sscg_abi_version": (_i, []),
-    "sscg_conv2d_fwd": (_i, [_dp, _p, _p, _p, _p, _p]),
-    "sscg_conv2d_dgrad": (_i, [_dp, _p, _p, _p, _p, _i, _f, _p]),
+    "sscg_conv2d_fwd_workspace": (_sz, [_dp]),
+    "sscg_conv2d_fwd": (_i, [_dp, _p, _p, _p, _p, _p, _sz, _p]),
+    "sscg_conv2d_dgrad_workspace": (_sz, [_dp]),
+    "sscg_conv2d_dgrad": (_i, [_dp, _p, _p, _p, _p, _i, _f, _p, _sz, _p]),
     "sscg_conv2d_wgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_wgrad": (_i, [_dp, _p, _p, _p, _f, _p, _sz, _p]),
     "sscg_weight_krsc_to_crsk": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -47,6 +47,10 @@ struct KcParams {
     int act;
     float slope;
     int tiles_n;
+    int tiles;      // tiles_m * tiles_n
+    int splits;     // split-K factor (partials to `part`, reduced by kc_reduce_kernel)
+    int ksplit;     // k-tiles per split
+    float* __restrict__ part;  // [splits][M][Ng] when splits > 1
 };
 
 template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST>
@@ -68,7 +72,9 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     int* tapinfo = reinterpret_cast<int*>(Bs + 2 * BN * LDK);       // [R*S]: (dy << 16) | dx
 
     const int tid = threadIdx.x;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / p.tiles;
+    const int tile = lin - split * p.tiles;
     const int tile_n = tile % p.tiles_n;
     const int tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM;
@@ -153,11 +159,16 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     unsigned okmask = 0;   // validity of the staged loads; applied at LDS-store time so that the loaded registers are
                            // not touched (=> not waited for) until the MFMAs of the current tile have been issued
 
+    const int nk_all = (p.Ktot + BK - 1) / BK;
+    const int kt0 = split * p.ksplit;                       // this workgroup's k-tile range (split-K)
+    const int kt1 = min(nk_all, kt0 + p.ksplit);
     // generic-path state: this thread's k column, advanced by BK per tile
-    int lk = kq * VEC;
+    int lk = kt0 * BK + kq * VEC;
     // fast-path state
-    int f_chunk = 0, f_tap = 0, f_k = 0;
     const int f_nchunk = FAST ? p.Cs / BK : 1;
+    int f_tap = FAST ? kt0 / f_nchunk : 0;
+    int f_chunk = FAST ? kt0 - f_tap * f_nchunk : 0;
+    int f_k = kt0 * BK;
     const float* aptr[PA];
     unsigned f_okbits = 0;
 
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
             aptr[ps] = arow[ps] + (size_t)pix * p.Cs + kq * VEC;
         }
     };
-    if (FAST) fast_set_tap(0);
+    if (FAST) fast_set_tap(f_tap < p.R * p.S ? f_tap : 0);
 
     auto load_tile = [&]() {
         if constexpr (FAST) {
@@ -285,9 +296,11 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (p.Ktot + BK - 1) / BK;
-    load_tile();
-    store_tile(0);
+    const int nk = kt1 - kt0;
+    if (nk > 0) {
+        load_tile();
+        store_tile(0);
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -333,10 +346,42 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < p.M) p.dst[(size_t)m * p.Ng + n] = sscg_act(acc[i][j][e] + bv, p.act, p.slope);
+                if (m < p.M) {
+                    if (p.splits > 1) p.part[((size_t)split * p.M + m) * p.Ng + n] = acc[i][j][e];
+                    else p.dst[(size_t)m * p.Ng + n] = sscg_act(acc[i][j][e] + bv, p.act, p.slope);
+                }
             }
         }
     }
+}
+
+// y[i] = act(sum_s part[s][i] + bias[i % Ng])   (fixed order => deterministic)
+__global__ void kc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y, size_t n,
+                                 int Ng, int splits, int act, float slope) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
+    if (bias) s += bias[i % Ng];
+    y[i] = sscg_act(s, act, slope);
+}
+
+// Split-K plan for heads with a handful of output channels on few rows (DeepLab classifier: 8712 x 21 x 18432):
+// one 128x32 tile column gives only M/128 workgroups, so the reduction is cut into `splits` ranges.
+struct KcSplit { int splits, ksplit; };
+static KcSplit plan_kc_split(int M, int Ng, int Ktot) {
+    KcSplit r = {1, (Ktot + BK - 1) / BK};
+    if (Ng > 32) return r;
+    const int nk = (Ktot + BK - 1) / BK;
+    const int tiles = cdiv(M, 128);
+    if (tiles >= 256 || nk < 32) return r;
+    int s = cdiv(512, tiles);
+    if (s > nk / 8) s = nk / 8;
+    if (s > 32) s = 32;
+    if (s < 2) return r;
+    r.ksplit = cdiv(nk, s);
+    r.splits = cdiv(nk, r.ksplit);
+    return r;
 }
 
 template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST>
@@ -346,14 +391,21 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     KcParams p = p0;
     p.tiles_n = cdiv(p.Ng, BN);
     int tiles_m = cdiv(p.M, BM);
+    p.tiles = tiles_m * p.tiles_n;
     size_t smem = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (size_t)p.R * p.S * 4;
     auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles * p.splits), dim3(256), smem, st, p);
     SSCG_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        size_t n = (size_t)p.M * p.Ng;
+        hipLaunchKernelGGL(kc_reduce_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, p.part, p.bias, p.dst, n, p.Ng, p.splits,
+                           p.act, p.slope);
+        SSCG_LAUNCH_CHECK();
+    }
     return SSCG_OK;
 }
 
@@ -410,8 +462,20 @@ static int check_desc(const sscg_conv_desc* d) {
     return SSCG_OK;
 }
 
+extern "C" size_t sscg_conv2d_fwd_workspace(const sscg_conv_desc* d) {
+    if (!d) return 0;
+    KcSplit sp = plan_kc_split(d->N * d->P * d->Q, d->K, d->R * d->S * d->C);
+    return sp.splits > 1 ? (size_t)sp.splits * d->N * d->P * d->Q * d->K * sizeof(float) : 0;
+}
+
+extern "C" size_t sscg_conv2d_dgrad_workspace(const sscg_conv_desc* d) {
+    if (!d) return 0;
+    KcSplit sp = plan_kc_split(d->N * d->H * d->W, d->C, d->R * d->S * d->K);
+    return sp.splits > 1 ? (size_t)sp.splits * d->N * d->H * d->W * d->C * sizeof(float) : 0;
+}
+
 extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const float* w, const float* bias,
-                               float* y, void* stream) {
+                               float* y, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return SSCG_ERR_BAD_ARG;
@@ -420,7 +484,10 @@ extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const fl
     p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Cs = d->C; p.Ktot = d->R * d->S * d->C;
     p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
-    p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope; p.tiles_n = 0;
+    p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope; p.tiles_n = 0; p.tiles = 0;
+    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot);
+    if (sp.splits > 1 && (!ws || ws_bytes < (size_t)sp.splits * p.M * p.Ng * sizeof(float))) return SSCG_ERR_WORKSPACE;
+    p.splits = sp.splits; p.ksplit = sp.ksplit; p.part = reinterpret_cast<float*>(ws);
     return dispatch_mode<MODE_FWD>(p, (hipStream_t)stream, sscg_force_conv_cfg);
 }
 
@@ -430,7 +497,7 @@ extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const fl
 // generators (arch/generators.py:73,84,89 via model.py:225-228), which never see a backward pass;
 // the Python layer materialises the pad for any other caller.
 extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const float* wt, const float* bias,
-                                 float* dx, int act, float slope, void* stream) {
+                                 float* dx, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dy || !wt || !dx) return SSCG_ERR_BAD_ARG;
@@ -440,7 +507,10 @@ extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const
     p.M = d->N * d->H * d->W; p.Ng = d->C; p.Cs = d->K; p.Ktot = d->R * d->S * d->K;
     p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
-    p.pad_mode = 0; p.act = act; p.slope = slope; p.tiles_n = 0;
+    p.pad_mode = 0; p.act = act; p.slope = slope; p.tiles_n = 0; p.tiles = 0;
+    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot);
+    if (sp.splits > 1 && (!ws || ws_bytes < (size_t)sp.splits * p.M * p.Ng * sizeof(float))) return SSCG_ERR_WORKSPACE;
+    p.splits = sp.splits; p.ksplit = sp.ksplit; p.part = reinterpret_cast<float*>(ws);
     return dispatch_mode<MODE_DGRAD>(p, (hipStream_t)stream, sscg_force_conv_cfg);
 }
 

@@ -167,37 +167,32 @@ int launch_reduce(RedParams p, int G, hipStream_t st) {
     return SSCG_OK;
 }
 
-// Second stage of the column reductions.  A block owns 16 channels; its 256 threads are 16 channels x 16
-// chunk-lanes, each lane strides the chunk axis, lanes are combined through LDS in a fixed order.
+// Second stage of the column reductions.  A block owns 4 channels, one wave each: the 64 lanes stride the chunk
+// axis (<= a handful of dependent loads per lane) and are combined by a fixed-order butterfly (deterministic).
+constexpr int FIN_CH = 4;
 __device__ __forceinline__ void chunk_sum16(const double* __restrict__ part, int g, int chunks, int C, int c, bool cok,
-                                            double* sm, double& s0, double& s1) {
-    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+                                            double* /*sm*/, double& s0, double& s1) {
+    const int lane = threadIdx.x & 63;
     double a = 0.0, b = 0.0;
     if (cok) {
-        for (int k = kl; k < chunks; k += 16) {
+        for (int k = lane; k < chunks; k += 64) {
             size_t o = (((size_t)g * chunks + k) * C + c) * 2;
             a += part[o];
             b += part[o + 1];
         }
     }
-    __syncthreads();  // sm reuse across calls
-    sm[(kl * 16 + cl) * 2] = a;
-    sm[(kl * 16 + cl) * 2 + 1] = b;
-    __syncthreads();
-    s0 = 0.0; s1 = 0.0;
-    if (kl == 0) {
-        for (int r = 0; r < 16; ++r) { s0 += sm[(r * 16 + cl) * 2]; s1 += sm[(r * 16 + cl) * 2 + 1]; }
-    }
+    s0 = wave_sum(a);
+    s1 = wave_sum(b);
 }
 
 __global__ __launch_bounds__(256) void finalize_sum_kernel(const double* __restrict__ part, float* __restrict__ out, int C,
                                                             int chunks, float beta) {
     __shared__ double sm[512];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
     const bool cok = c < C;
     double s, unused;
     chunk_sum16(part, 0, chunks, C, c, cok, sm, s, unused);
-    if ((threadIdx.x >> 4) == 0 && cok) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
+    if ((threadIdx.x & 63) == 0 && cok) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
 }
 
 __global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __restrict__ part, float* __restrict__ mean,
@@ -205,12 +200,12 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __res
                                                               float* __restrict__ rvar, int G, int C, int chunks, long L,
                                                               float eps, float momentum) {
     __shared__ double sm[512];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
     const int g = blockIdx.y;
     const bool cok = c < C;
     double s, ss;
     chunk_sum16(part, g, chunks, C, c, cok, sm, s, ss);
-    if ((threadIdx.x >> 4) == 0 && cok) {
+    if ((threadIdx.x & 63) == 0 && cok) {
         const int i = g * C + c;
         double m = s / (double)L;
         double var = ss / (double)L - m * m;
@@ -230,9 +225,9 @@ __global__ __launch_bounds__(256) void finalize_bwd_kernel(const double* __restr
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C,
                                                             int chunks, long L) {
     __shared__ double sm[512];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
     const bool cok = c < C;
-    const bool lead = (threadIdx.x >> 4) == 0 && cok;
+    const bool lead = (threadIdx.x & 63) == 0 && cok;
     double tg = 0.0, tb = 0.0;
     for (int g = 0; g < G; ++g) {
         double s, sx;
@@ -402,7 +397,7 @@ extern "C" int sscg_colsum(const float* x, float* out, int64_t rows, int cols, f
     int rc = launch_reduce<RM_SUM>(p, 1, st);
     if (rc) return rc;
     RedPlan pl = plan_reduce(1, rows, cols);
-    hipLaunchKernelGGL(finalize_sum_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, st, p.part, out, cols, pl.chunks, beta);
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3(cdiv(cols, FIN_CH)), dim3(256), 0, st, p.part, out, cols, pl.chunks, beta);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -422,7 +417,7 @@ extern "C" int sscg_norm_stats(const float* x, int G, int64_t L, int C, float ep
     int rc = launch_reduce<RM_STATS>(p, G, st);
     if (rc) return rc;
     RedPlan pl = plan_reduce(G, L, C);
-    hipLaunchKernelGGL(finalize_stats_kernel, dim3(cdiv(C, 16), G), dim3(256), 0, st, p.part, mean, rstd,
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3(cdiv(C, FIN_CH), G), dim3(256), 0, st, p.part, mean, rstd,
                        running_mean, running_var, G, C, pl.chunks, (long)L, eps, momentum);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
@@ -478,7 +473,7 @@ extern "C" int sscg_norm_bwd(const float* dy, const float* x, const float* y, co
         if (rc) return rc;
         RedPlan pl = plan_reduce(G, L, C);
         coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + part_bytes(G, L, C));
-        hipLaunchKernelGGL(finalize_bwd_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, p.part, coef, dgamma, dbeta, G, C,
+        hipLaunchKernelGGL(finalize_bwd_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, st, p.part, coef, dgamma, dbeta, G, C,
                            pl.chunks, (long)L);
         SSCG_LAUNCH_CHECK();
     }

@@ -195,8 +195,9 @@ def _timed(kind, d, fn):
 def conv2d_fwd(x, w, bias, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0):
     d = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, act, slope)
     y = empty_nhwc(d.N, d.K, d.P, d.Q, x.device)
-    _timed("fwd", d, lambda: check(lib.sscg_conv2d_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _stream()),
-                                   "sscg_conv2d_fwd"))
+    ws = _WS.get(lib.sscg_conv2d_fwd_workspace(C.byref(d)), x.device)
+    _timed("fwd", d, lambda: check(lib.sscg_conv2d_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(),
+                                                       ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_fwd"))
     return y
 
 
@@ -211,8 +212,9 @@ def weight_transposed(w):
 def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0):
     d = make_desc(xshape, wshape, stride, pad, dil)
     dx = empty_nhwc(d.N, d.C, d.H, d.W, dy.device)
+    ws = _WS.get(lib.sscg_conv2d_dgrad_workspace(C.byref(d)), dy.device)
     _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wt.data_ptr(), _ptr(bias), dx.data_ptr(),
-                                                           act, slope, _stream()), "sscg_conv2d_dgrad"))
+                                                           act, slope, ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_dgrad"))
     return dx
 
 
