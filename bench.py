@@ -54,7 +54,8 @@ def main():
     data = importlib.import_module(PKG + ".data")
     from oracle import fixtures as FX   # only make_args (namespace of CLI defaults) and, below, the CPU baseline
 
-    dp = par.DataParallel() if world > 1 else None
+    # SSCG_FORCE_DP=1 exercises the RCCL code path (init, broadcast, all-reduce) on a single rank
+    dp = par.DataParallel() if (world > 1 or os.environ.get("SSCG_FORCE_DP")) else None
     rank = dp.rank if dp else 0
     local = dp.local_rank if dp else 0
     torch.cuda.set_device(local)
@@ -151,6 +152,10 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
+    if dp:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def cpu_baseline():

@@ -28,7 +28,10 @@
 
 namespace {
 
-constexpr int BK = 32;
+#ifndef SSCG_BK
+#define SSCG_BK 32
+#endif
+constexpr int BK = SSCG_BK;
 constexpr int LDK = BK + 4;
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
@@ -369,10 +372,28 @@ __global__ void kc_reduce_kernel(const float* __restrict__ part, const float* __
 // Split-K plan for heads with a handful of output channels on few rows (DeepLab classifier: 8712 x 21 x 18432):
 // one 128x32 tile column gives only M/128 workgroups, so the reduction is cut into `splits` ranges.
 struct KcSplit { int splits, ksplit; };
+int sscg_force_conv_split = 0;   // tuning hook: bits 8..15 of sscg_debug_set_conv_cfg
 static KcSplit plan_kc_split(int M, int Ng, int Ktot) {
     KcSplit r = {1, (Ktot + BK - 1) / BK};
-    if (Ng > 32) return r;
     const int nk = (Ktot + BK - 1) / BK;
+    if (sscg_force_conv_split > 1) {
+        r.ksplit = cdiv(nk, sscg_force_conv_split);
+        r.splits = cdiv(nk, r.ksplit);
+        return r;
+    }
+    if (Ng > 32) {
+        // 64x64-tile shapes with a long reduction on few rows (DeepLab stride-8 3x3 convs: 8712 rows -> 548 workgroups
+        // = 2.14 per CU): cutting K in three gives 6.4 per CU, i.e. 92 % instead of 71 % load balance
+        // (tools/conv_bench.py: 69 -> 86 TF/s at 256 ch, 96 -> 107 at 512 ch).  1x1 convs (short K) are left alone.
+        const long w128 = (long)cdiv(M, 128) * cdiv(Ng, 128);
+        const bool cfg3 = !(w128 >= 512 && Ktot >= 1024);
+        const long w64 = (long)cdiv(M, 64) * cdiv(Ng, 64);
+        if (cfg3 && nk >= 36 && w64 <= 1200) {
+            r.ksplit = cdiv(nk, 3);
+            r.splits = cdiv(nk, r.ksplit);
+        }
+        return r;
+    }
     const int tiles = cdiv(M, 128);
     if (tiles >= 256 || nk < 32) return r;
     int s = cdiv(512, tiles);
@@ -443,7 +464,9 @@ int dispatch_mode(const KcParams& p, hipStream_t st, int force_cfg) {
 int sscg_force_conv_cfg = -1;  // test/tuning hook (sscg_debug_set_conv_cfg)
 
 extern "C" int sscg_debug_set_conv_cfg(int cfg) {
-    sscg_force_conv_cfg = cfg;
+    if (cfg < 0) { sscg_force_conv_cfg = -1; sscg_force_conv_split = 0; return SSCG_OK; }
+    sscg_force_conv_cfg = (cfg & 0xff) == 0xff ? -1 : (cfg & 0xff);
+    sscg_force_conv_split = (cfg >> 8) & 0xff;
     return SSCG_OK;
 }
 

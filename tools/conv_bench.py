@@ -41,7 +41,7 @@ def timeit(fn, iters=20):
 
 
 def main():
-    cfgs = [int(a) for a in sys.argv[1:]] or [-1, 0, 1, 2, 3, 4]
+    cfgs = [int(a, 0) for a in sys.argv[1:]] or [-1, 0, 1, 2, 3, 4]
     for (N, C, H, W, K, R, s, p, d) in SHAPES:
         x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=CL)
         w = (torch.randn(K, C, R, R, device=dev) * 0.05).contiguous(memory_format=CL)
@@ -55,11 +55,11 @@ def main():
             try:
                 tf = timeit(lambda: F.conv2d_fwd(x, w, None, s, p, d))
                 td = timeit(lambda: F.conv2d_dgrad(gy, wt, x.shape, w.shape, s, p, d))
-                line += " | cfg%2d f %5.1f d %5.1f" % (cfg, flops / tf / 1e12, flops / td / 1e12)
+                line += " | %5s f %5.1f d %5.1f" % (hex(cfg) if cfg > 255 else cfg, flops / tf / 1e12, flops / td / 1e12)
             except Exception as e:
                 line += " | cfg%2d ERR" % cfg
         F.lib.sscg_debug_set_conv_cfg(-1)
-        for (tw_, mi_) in ((768, 1), (1024, 8), (1536, 8), (1024, 16), (768, 12), (2048, 12)):
+        for (tw_, mi_) in ((768, 12),):
             F.lib.sscg_debug_set_wgrad_plan(tw_, mi_)
             tw = timeit(lambda: F.conv2d_wgrad(x, gy, w.shape, s, p, d))
             line += " | wg(%d,%d) %5.1f" % (tw_, mi_, flops / tw / 1e12)
