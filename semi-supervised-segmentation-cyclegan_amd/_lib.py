@@ -100,7 +100,30 @@ def _load():
     v = lib.sscg_abi_version()
     if v != ABI_VERSION:
         raise ImportError("libsscg.so ABI version %d != binding version %d" % (v, ABI_VERSION))
+    if os.environ.get("SSCG_TRACE"):
+        return _Traced(lib)
     return lib
+
+
+class _Traced:
+    """SSCG_TRACE=1: print every entry point before it runs and synchronise after it (fault localisation)."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+
+        def call(*a):
+            import sys
+            import torch
+            sys.stderr.write("[sscg] %s%s\n" % (name, tuple(x if isinstance(x, (int, float)) else "." for x in a)))
+            sys.stderr.flush()
+            r = fn(*a)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            return r
+        return call
 
 
 lib = _load()

@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
             for (int ps = 0; ps < PB; ++ps) {
                 const bool ok = kvalid && bok[ps];
                 okmask |= ok ? (1u << (16 + ps)) : 0u;
-                const float* g = brow[ps] + (ok ? lk - kq * VEC : 0);
+                // masked lanes read the tensor's first element(s): `brow` already carries +kq*VEC, which would run past
+                // the end of a weight that is shorter than one k-tile (e.g. the 128->1 head: Ktot = 1)
+                const float* g = ok ? brow[ps] + (lk - kq * VEC) : p.wgt;
                 if constexpr (VEC == 4) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(g);
 #pragma unroll
