@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-elided", action="store_true")
     ap.add_argument("--batch", type=int, default=B)
     a = ap.parse_args()
 
@@ -103,6 +104,25 @@ def main():
         "step_frac_of_f32_mfma_peak": round(bsz * STEP_TFLOP_PER_PAIR * a.steps / dt / PEAK_F32_MFMA_TFLOPS, 4),
     }
 
+    # secondary figure (BASELINE.md section 2 / SURVEY 8(d)): the same step without the forwards whose outputs the
+    # reference never uses (old_Gsi(l_img) -> old_Gis, model.py:419-420,423) and without old_Di's never-applied wgrad
+    if not a.no_elided:
+        model.as_written = False
+        run(a.warmup + a.steps)
+        if dp:
+            dp.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(a.warmup, a.warmup + a.steps):
+            run(i)
+        torch.cuda.synchronize()
+        if dp:
+            dp.barrier()
+        dte = par.max_over_ranks(time.perf_counter() - t1)
+        model.as_written = True
+        out["elided_dead_work"] = {"value": round(world * bsz * a.steps / dte, 4), "unit": "img/s", "ms_per_step": round(1e3 * dte / a.steps, 3),
+                                   "note": "not the headline: skips 53.25 GMAC/pair of forwards with unused outputs + 1.1 GMAC/pair of unused wgrad"}
+
     if rank == 0 and not a.no_roofline:
         # per-kernel timing needs the kernels one at a time: the side stream (concurrent weight gradients /
         # frozen generators) is switched off for this extra, untimed step only
@@ -127,6 +147,7 @@ def main():
             "conv_ms_per_step": {k: round(v["ms"], 2) for k, v in summ.items()},
             "conv_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in summ.items() if v["ms"] > 0},
         }
+        out["roofline"].update(pmc_traffic())
         # the 3x3 family north_star singles out (3x3 convs only)
         f3 = m3 = 0.0
         for kind, v in summ.items():
@@ -156,6 +177,29 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01c_pmc_per_kernel.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command).  Units and the gfx950
+    correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes: counters are KiB; FETCH_SIZE under-reports wide
+    coalesced reads by 2x.  The live bench cannot collect PMC itself, hence the file."""
+    path = os.path.join(ROOT, "profiles", "r01c_pmc_per_kernel.json")
+    if not os.path.exists(path):
+        return {"traffic": None}
+    d = json.load(open(path))
+    tot_b = tot_n = busy = act = 0.0
+    for name, cs in d.items():
+        if "conv_kc_kernel" in name and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            n = cs["FETCH_SIZE"]["launches"]
+            tot_b += (2.0 * cs["FETCH_SIZE"]["sum"] + cs["WRITE_SIZE"]["sum"]) * 1024.0
+            tot_n += n
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in cs:
+                busy += cs["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"]
+                act += cs["GRBM_GUI_ACTIVE"]["sum"]
+    return {"traffic": round(tot_b / max(tot_n, 1)), "traffic_unit": "HBM bytes per conv_kc launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+            "traffic_source": "profiles/r01c_pmc_per_kernel.json",
+            "mfma_util_pmc": round(busy / max(act / 8.0 * 1024.0, 1.0), 4)}   # GRBM_GUI_ACTIVE is summed over the 8 XCDs, busy cycles over 1024 SIMDs
 
 
 def cpu_baseline():

@@ -56,7 +56,7 @@ struct KcParams {
     float* __restrict__ part;  // [splits][M][Ng] when splits > 1
 };
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2>
 __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* As = reinterpret_cast<float*>(smem_raw);                 // [2][BM][LDK]
-    float* Bs = As + 2 * BM * LDK;                                  // [2][BN][LDK]
-    int* tapinfo = reinterpret_cast<int*>(Bs + 2 * BN * LDK);       // [R*S]: (dy << 16) | dx
+    float* Bs = As + NBUF * BM * LDK;                               // [NBUF][BN][LDK]
+    int* tapinfo = reinterpret_cast<int*>(Bs + NBUF * BN * LDK);       // [R*S]: (dy << 16) | dx
 
     const int tid = threadIdx.x;
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        const int buf = NBUF == 2 ? (kt & 1) : 0;
         const float* a = As + buf * BM * LDK + (row_w + li) * LDK + lh * 4;
         const float* b = Bs + buf * BN * LDK + (col_w + li) * LDK + lh * 4;
         f32x4 fa[2][TM], fb[2][TN];
@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        if (NBUF == 1) __syncthreads();      // single LDS image: every wave is done reading before it is overwritten
+        if (kt + 1 < nk) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -407,7 +408,7 @@ static KcSplit plan_kc_split(int M, int Ng, int Ktot) {
     return r;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2>
 int launch_kc(const KcParams& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -415,8 +416,8 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     p.tiles_n = cdiv(p.Ng, BN);
     int tiles_m = cdiv(p.M, BM);
     p.tiles = tiles_m * p.tiles_n;
-    size_t smem = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (size_t)p.R * p.S * 4;
-    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST>;
+    size_t smem = (size_t)(NBUF * BM * LDK + NBUF * BN * LDK) * sizeof(float) + (size_t)p.R * p.S * 4;
+    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST, NBUF>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -450,6 +451,7 @@ int dispatch_kc(const KcParams& p, hipStream_t st, int force_cfg) {
         case 2: return launch_kc<MODE, 2, 2, 1, 2, VEC, FAST>(p, st);
         case 3: return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST>(p, st);
         case 4: return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST>(p, st);
+        case 5: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 1>(p, st);   // 128x128, single LDS image (36 KB: 4 workgroups/CU)
         default: return SSCG_ERR_BAD_ARG;
     }
 }
