@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsscg.so")
+LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
 ABI_VERSION = 2
 

@@ -56,8 +56,16 @@ struct KcParams {
     float* __restrict__ part;  // [splits][M][Ng] when splits > 1
 };
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2>
+// 256 B of zeros: the source of LDS-DMA lanes that fall into padding / outside the tile
+__device__ float sscg_zero_page[64];
+
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false>
 __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
+    static_assert(!DMA || (FAST && NBUF == 2), "LDS-DMA staging is built on the fast path");
+    // DMA staging: `global_load_lds_dwordx4` writes lane-linear (wave-uniform base + lane*16 B), so the LDS image is
+    // the unpadded [row][32]; bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the
+    // 16-B slot with (row >> 1) & 7, applied to the per-lane SOURCE address and to the read address alike.
+    constexpr int LDR = DMA ? BK : LDK;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -70,9 +78,9 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* As = reinterpret_cast<float*>(smem_raw);                 // [2][BM][LDK]
-    float* Bs = As + NBUF * BM * LDK;                               // [NBUF][BN][LDK]
-    int* tapinfo = reinterpret_cast<int*>(Bs + NBUF * BN * LDK);       // [R*S]: (dy << 16) | dx
+    float* As = reinterpret_cast<float*>(smem_raw);                 // [NBUF][BM][LDR]
+    float* Bs = As + NBUF * BM * LDR;                               // [NBUF][BN][LDR]
+    int* tapinfo = reinterpret_cast<int*>(Bs + NBUF * BN * LDR);       // [R*S]: (dy << 16) | dx
 
     const int tid = threadIdx.x;
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -89,8 +97,10 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
         tapinfo[t] = ((ky * p.dil) << 16) | (kx * p.dil);
     }
 
-    const int kq = tid % KQ;
     const int r0 = tid / KQ;
+    // k slot this thread stages: identity, or (DMA) the slot whose data must land at LDS slot tid%8 of row r0
+    const int kq = DMA ? ((tid % KQ) ^ ((r0 >> 1) & 7)) : (tid % KQ);
+    const int wave_id = tid >> 6;
 
     // ---- per-thread loader state (decoded once)
     const float* arow[PA];   // image base of the row's source
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     int f_k = kt0 * BK;
     const float* aptr[PA];
     unsigned f_okbits = 0;
+    int dma_buf = 0;          // LDS image the next DMA tile lands in
 
     auto fast_set_tap = [&](int tap) {
         const int ti = tapinfo[tap];
@@ -198,18 +209,36 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
             }
             okmask = f_okbits;
             const int coff = f_chunk * BK;
+            if constexpr (DMA) {
+                float* la = As + dma_buf * BM * LDR + wave_id * 256;
+                float* lb = Bs + dma_buf * BN * LDR + wave_id * 256;
 #pragma unroll
-            for (int ps = 0; ps < PA; ++ps) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(aptr[ps] + coff);
+                for (int ps = 0; ps < PA; ++ps) {
+                    const float* g = ((f_okbits >> ps) & 1u) ? aptr[ps] + coff : sscg_zero_page;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(la + ps * 1024), 16, 0, 0);
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ra[ps][e] = v[e];
-            }
+                for (int ps = 0; ps < PB; ++ps) {
+                    const float* g = bok[ps] ? brow[ps] + f_k : sscg_zero_page;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(lb + ps * 1024), 16, 0, 0);
+                }
+                dma_buf ^= 1;
+            } else {
 #pragma unroll
-            for (int ps = 0; ps < PB; ++ps) {
-                okmask |= bok[ps] ? (1u << (16 + ps)) : 0u;
-                f32x4 v = *reinterpret_cast<const f32x4*>(brow[ps] + f_k);
+                for (int ps = 0; ps < PA; ++ps) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(aptr[ps] + coff);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[ps][e] = v[e];
+                    for (int e = 0; e < 4; ++e) ra[ps][e] = v[e];
+                }
+#pragma unroll
+                for (int ps = 0; ps < PB; ++ps) {
+                    okmask |= bok[ps] ? (1u << (16 + ps)) : 0u;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(brow[ps] + f_k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[ps][e] = v[e];
+                }
             }
             ++f_chunk;
             f_k += BK;
@@ -254,6 +283,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     };
 
     auto store_tile = [&](int buf) {
+        if constexpr (DMA) return;   // the DMA already put the tile into LDS
         float* a = As + buf * BM * LDK;
         float* b = Bs + buf * BN * LDK;
 #pragma unroll
@@ -309,14 +339,16 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = NBUF == 2 ? (kt & 1) : 0;
-        const float* a = As + buf * BM * LDK + (row_w + li) * LDK + lh * 4;
-        const float* b = Bs + buf * BN * LDK + (col_w + li) * LDK + lh * 4;
+        const float* a = As + buf * BM * LDR + (row_w + li) * LDR + (DMA ? 0 : lh * 4);
+        const float* b = Bs + buf * BN * LDR + (col_w + li) * LDR + (DMA ? 0 : lh * 4);
+        const int swz = (li >> 1) & 7;    // DMA image: 16-B slot c of a row lives at slot c ^ swz
+        auto koff = [&](int kk) { return DMA ? (((kk * 2 + lh) ^ swz) * 4) : kk * 8; };
         f32x4 fa[2][TM], fb[2][TN];
         // fragments of the first k-group are requested right after the barrier ...
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK);
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDR + koff(0));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK);
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDR + koff(0));
         // ... and the global loads of tile kt+1 are issued under their latency; they land under the MFMAs
         if (kt + 1 < nk) load_tile();
 #pragma unroll
@@ -324,9 +356,9 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
             const int cur = kk & 1, nxt = cur ^ 1;
             if (kk + 1 < BK / 8) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + (kk + 1) * 8);
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDR + koff(kk + 1));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + (kk + 1) * 8);
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDR + koff(kk + 1));
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -408,7 +440,7 @@ static KcSplit plan_kc_split(int M, int Ng, int Ktot) {
     return r;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false>
 int launch_kc(const KcParams& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -416,8 +448,9 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     p.tiles_n = cdiv(p.Ng, BN);
     int tiles_m = cdiv(p.M, BM);
     p.tiles = tiles_m * p.tiles_n;
-    size_t smem = (size_t)(NBUF * BM * LDK + NBUF * BN * LDK) * sizeof(float) + (size_t)p.R * p.S * 4;
-    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST, NBUF>;
+    constexpr int LDR = DMA ? BK : LDK;
+    size_t smem = (size_t)(NBUF * BM * LDR + NBUF * BN * LDR) * sizeof(float) + (size_t)p.R * p.S * 4;
+    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST, NBUF, DMA>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -441,9 +474,10 @@ int dispatch_kc(const KcParams& p, hipStream_t st, int force_cfg) {
     auto wgs = [&](int bm, int bn) { return (long)cdiv(p.M, bm) * cdiv(p.Ng, bn); };
     int cfg = force_cfg;
     if (cfg < 0) {
+        // FAST shapes stage through LDS-DMA (cfg 6/7: +5..8 % over register staging, tools/conv_bench.py)
         if (p.Ng <= 32) cfg = 4;
-        else if (wgs(128, 128) >= 512 && p.Ktot >= 1024) cfg = 0;   // long reductions amortise the big tile's prologue
-        else cfg = 3;
+        else if (wgs(128, 128) >= 512 && p.Ktot >= 1024) cfg = FAST ? 7 : 0;   // long reductions amortise the big tile's prologue
+        else cfg = FAST ? 6 : 3;
     }
     switch (cfg) {
         case 0: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST>(p, st);
@@ -452,6 +486,8 @@ int dispatch_kc(const KcParams& p, hipStream_t st, int force_cfg) {
         case 3: return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST>(p, st);
         case 4: return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST>(p, st);
         case 5: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 1>(p, st);   // 128x128, single LDS image (36 KB: 4 workgroups/CU)
+        case 6: if constexpr (FAST) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
+        case 7: if constexpr (FAST) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
         default: return SSCG_ERR_BAD_ARG;
     }
 }

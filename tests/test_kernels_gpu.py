@@ -85,7 +85,7 @@ def test_conv_fwd_bwd(case, F, dev):
         assert rel_err(xg.grad, xr.grad) < 2e-5
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv_all_tile_configs(cfg, F, dev):
     lib = F.lib
     g = torch.Generator().manual_seed(cfg)
