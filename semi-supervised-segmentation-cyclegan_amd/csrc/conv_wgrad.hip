@@ -38,12 +38,18 @@ struct WgParams {
     FastDiv div_pq, div_q;
 };
 
-template <int WM, int WN, int TM, int TN, int VA, int VB>
+// 256 B of zeros: the source of masked LDS-DMA lanes (device code is not linked across translation units)
+__device__ float sscg_zero_page[64];
+
+template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
+    static_assert(!DMA || (VA == 4 && VB == 4), "LDS-DMA staging needs 16-byte granules");
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int LDA = BM + 4;
-    constexpr int LDB = BN + 4;
+    // register staging pads the rows; LDS-DMA writes lane-linear, i.e. the unpadded [pixel][channel] image, which the
+    // ds_read_b32 fragment reads (lane -> consecutive channel) take without bank conflicts anyway
+    constexpr int LDA = DMA ? BM : BM + 4;
+    constexpr int LDB = DMA ? BN : BN + 4;
     constexpr int CA = BM / VA;          // threads per A row
     constexpr int CB = BN / VB;
     constexpr int RA = 256 / CA;         // rows per pass
@@ -94,8 +100,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     const float* xc = p.x + cch;                        // this thread's x channel group
     const bool reflect = p.pad_mode == 1;
 
+    int dma_buf = 0;
+    const int wave_id = tid >> 6;
     auto load_tile = [&](int pt) {
         okmask = 0;
+        if constexpr (DMA) {
+            float* la = As + dma_buf * BKP * LDA + wave_id * 256;
+            float* lb = Bs + dma_buf * BKP * LDB + wave_id * 256;
+#pragma unroll
+            for (int ps = 0; ps < PA; ++ps) {
+                const int pix = pt + ra0 + ps * RA;
+                const bool ok = a_col_ok && pix < p_end;
+                const float* g = ok ? dyc + (size_t)pix * p.Kc : sscg_zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(la + ps * RA * LDA), 16, 0, 0);
+            }
+#pragma unroll
+            for (int ps = 0; ps < PB; ++ps) {
+                const int pix = pt + rb0 + ps * RB;
+                bool ok = b_col_ok && pix < p_end;
+                const int pp = ok ? pix : 0;
+                const int img = fd_div(pp, p.div_pq);
+                const int rem = pp - img * (p.P * p.Q);
+                const int oy = fd_div(rem, p.div_q);
+                const int ox = rem - oy * p.Q;
+                int sy = oy * p.stride + tdy;
+                int sx = ox * p.stride + tdx;
+                int ry = sy < 0 ? -sy : sy;
+                int rx = sx < 0 ? -sx : sx;
+                ry = ry >= p.H ? 2 * (p.H - 1) - ry : ry;
+                rx = rx >= p.W ? 2 * (p.W - 1) - rx : rx;
+                sy = reflect ? ry : sy;
+                sx = reflect ? rx : sx;
+                ok = ok && ((unsigned)sy < (unsigned)p.H) && ((unsigned)sx < (unsigned)p.W);
+                const float* g = ok ? xc + (size_t)((img * p.H + sy) * p.W + sx) * p.C : sscg_zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(lb + ps * RB * LDB), 16, 0, 0);
+            }
+            dma_buf ^= 1;
+            return;
+        }
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
             const int pix = pt + ra0 + ps * RA;
@@ -142,6 +186,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     };
 
     auto store_tile = [&](int buf) {
+        if constexpr (DMA) return;
         float* a = As + buf * BKP * LDA;
         float* b = Bs + buf * BKP * LDB;
 #pragma unroll
@@ -290,7 +335,7 @@ WgPlan plan_wgrad(const sscg_conv_desc* d) {
     return pl;
 }
 
-template <int WM, int WN, int TM, int TN, int VA, int VB>
+template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false>
 int launch_wg(WgParams p, int splits, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -298,8 +343,8 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
     int tiles_m = cdiv(p.Kc, BM);
     p.tiles = tiles_m * p.tiles_n;
     p.splits = splits;
-    size_t smem = (size_t)(2 * BKP * (BM + 4) + 2 * BKP * (BN + 4)) * sizeof(float);
-    auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VA, VB>;
+    size_t smem = (size_t)(2 * BKP * (DMA ? BM : BM + 4) + 2 * BKP * (DMA ? BN : BN + 4)) * sizeof(float);
+    auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VA, VB, DMA>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -312,8 +357,8 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
 template <int VA, int VB>
 int dispatch_wg(const WgParams& p, const WgPlan& pl, hipStream_t st) {
     switch (pl.cfg) {
-        case 0: return launch_wg<2, 2, 2, 2, VA, VB>(p, pl.splits, st);
-        case 1: return launch_wg<2, 2, 1, 1, VA, VB>(p, pl.splits, st);
+        case 0: return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);   // LDS-DMA staging when vectorisable
+        case 1: return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);
         case 2: return launch_wg<1, 4, 1, 1, VA, VB>(p, pl.splits, st);
         case 3: return launch_wg<4, 1, 1, 1, VA, VB>(p, pl.splits, st);
         default: return SSCG_ERR_BAD_ARG;
