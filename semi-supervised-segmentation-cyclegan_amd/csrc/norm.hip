@@ -283,11 +283,30 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(ApplyParams p) {
             if (p.res) rv[0] = p.res[o];
         }
         float out[VEC];
+        // per-channel parameters as 16-byte loads (the kernel is VMEM-issue bound with one scalar load per parameter)
+        float mu[VEC], rs[VEC], ga[VEC], be[VEC];
+        {
+            const size_t s = (size_t)g * p.C + c;
+            if constexpr (VEC == 4) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(p.mean + s);
+                f32x4 b = *reinterpret_cast<const f32x4*>(p.rstd + s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { mu[e] = a[e]; rs[e] = b[e]; ga[e] = 1.f; be[e] = 0.f; }
+                if (p.gamma) {
+                    f32x4 gg = *reinterpret_cast<const f32x4*>(p.gamma + c);
+                    f32x4 bb = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ga[e] = gg[e]; be[e] = bb[e]; }
+                }
+            } else {
+                mu[0] = p.mean[s]; rs[0] = p.rstd[s];
+                ga[0] = p.gamma ? p.gamma[c] : 1.f; be[0] = p.gamma ? p.beta[c] : 0.f;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const size_t s = (size_t)g * p.C + c + e;
-            float v = (xv[e] - p.mean[s]) * p.rstd[s];
-            if (p.gamma) v = v * p.gamma[c + e] + p.beta[c + e];
+            float v = (xv[e] - mu[e]) * rs[e];
+            if (p.gamma) v = v * ga[e] + be[e];
             if (p.res) v += rv[e];
             out[e] = sscg_act(v, p.act, p.slope);
         }
@@ -343,19 +362,42 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdApplyParams p) {
             if (p.act != SSCG_ACT_NONE) yv[0] = p.y[o];
         }
         float gx[VEC], gr[VEC];
+        float mu[VEC], rsv[VEC], ga[VEC], c1[VEC], c2[VEC];
+        {
+            const size_t s = (size_t)g * p.C + c;
+            if constexpr (VEC == 4) {
+                f32x4 b = *reinterpret_cast<const f32x4*>(p.rstd + s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rsv[e] = b[e]; ga[e] = 1.f; mu[e] = 0.f; c1[e] = 0.f; c2[e] = 0.f; }
+                if (p.gamma) {
+                    f32x4 gg = *reinterpret_cast<const f32x4*>(p.gamma + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ga[e] = gg[e];
+                }
+                if (p.coef) {
+                    f32x4 a = *reinterpret_cast<const f32x4*>(p.mean + s);
+                    f32x4 k0 = *reinterpret_cast<const f32x4*>(p.coef + s * 2);       // (c1,c2) pairs of channels c, c+1
+                    f32x4 k1 = *reinterpret_cast<const f32x4*>(p.coef + s * 2 + 4);   // ... of channels c+2, c+3
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mu[e] = a[e];
+                    c1[0] = k0[0]; c2[0] = k0[1]; c1[1] = k0[2]; c2[1] = k0[3];
+                    c1[2] = k1[0]; c2[2] = k1[1]; c1[3] = k1[2]; c2[3] = k1[3];
+                }
+            } else {
+                rsv[0] = p.rstd[s]; ga[0] = p.gamma ? p.gamma[c] : 1.f;
+                mu[0] = p.coef ? p.mean[s] : 0.f; c1[0] = p.coef ? p.coef[s * 2] : 0.f; c2[0] = p.coef ? p.coef[s * 2 + 1] : 0.f;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const size_t s = (size_t)g * p.C + c + e;
             float gg = p.act != SSCG_ACT_NONE ? act_grad(dv[e], yv[e], p.act, p.slope) : dv[e];
             gr[e] = gg;
-            float rs = p.rstd[s];
-            float gam = p.gamma ? p.gamma[c + e] : 1.f;
             float v = gg;
             if (p.coef) {
-                float xh = (xv[e] - p.mean[s]) * rs;
-                v = gg - p.coef[s * 2] - xh * p.coef[s * 2 + 1];
+                float xh = (xv[e] - mu[e]) * rsv[e];
+                v = gg - c1[e] - xh * c2[e];
             }
-            gx[e] = v * rs * gam;
+            gx[e] = v * rsv[e] * ga[e];
         }
         if constexpr (VEC == 4) {
             f32x4 t = {gx[0], gx[1], gx[2], gx[3]};
