@@ -130,9 +130,11 @@ class semisuper_cycleGAN(object):
         gen_loss.backward()                                                          # :472
         F.SideStream.join(l_img.device)            # side stream: weight gradients + frozen generators are complete
         resnet_recon_img.record_stream(torch.cuda.current_stream(l_img.device))
+        g_works = None
         if self.dp is not None:
-            self.dp.sync_grads(self.g_optimizer)
-        self.g_optimizer.step()                                                      # :474
+            g_works = self.dp.sync_grads_async(self.g_optimizer)     # overlaps the D step; the update is applied below
+        else:
+            self.g_optimizer.step()                                                  # :474
 
         # ---- discriminators (model.py:477-542)
         set_grad([self.Di, self.Ds], True)
@@ -161,6 +163,9 @@ class semisuper_cycleGAN(object):
         if self.dp is not None:
             self.dp.sync_grads(self.d_optimizer)
         self.d_optimizer.step()                                                      # :542
+        if self.dp is not None:
+            self.dp.wait(g_works)
+            self.g_optimizer.step()                                                  # :474 (deferred: no D-step op reads G weights)
         vals = (img_dis_loss, gt_dis_loss, cycle_img_dis_loss, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss,
                 lab_loss_CE, lab_loss_MSE)
         return {k: v.detach() for k, v in zip(LOSS_KEYS, vals)}

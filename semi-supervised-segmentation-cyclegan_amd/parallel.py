@@ -42,18 +42,31 @@ class DataParallel:
     def sync_grads(self, opt):
         allreduce_flat(opt.grad)
 
+    def sync_grads_async(self, opt):
+        """Start the all-reduce of an optimiser's gradient arena and return the work handles: the generator
+        exchange (343 MB) then runs over xGMI while the discriminator step computes (nothing in the D step reads
+        generator weights, so applying the G update after it is the same arithmetic as model.py:474)."""
+        return allreduce_flat(opt.grad, wait=False)
+
+    @staticmethod
+    def wait(works):
+        for w in works or ():
+            w.wait()
+
     def barrier(self):
         dist.barrier()
 
 
-def allreduce_flat(flat, chunk=CHUNK_ELEMS):
-    """In-place sum all-reduce of a 1-D buffer in large chunks (async, then one wait)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return flat
+def allreduce_flat(flat, chunk=CHUNK_ELEMS, wait=True):
+    """In-place sum all-reduce of a 1-D buffer in large chunks (async; `wait=False` returns the work handles)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and dist.get_backend() != "nccl"):
+        return flat if wait else []
     works = []
     n = flat.numel()
     for off in range(0, n, chunk):
         works.append(dist.all_reduce(flat[off:min(n, off + chunk)], op=dist.ReduceOp.SUM, async_op=True))
+    if not wait:
+        return works
     for w in works:
         w.wait()
     return flat
