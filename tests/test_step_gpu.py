@@ -164,3 +164,33 @@ def test_many_steps_stay_finite_and_do_not_fault(dev):
     last = {k: float(v) for k, v in out.items()}
     assert all(np.isfinite(v) for v in last.values())
     assert last["lab_loss_CE"] < first["lab_loss_CE"]          # training on a fixed batch reduces the supervised loss
+
+
+@pytest.mark.parametrize("cfg", [("cityscapes", 20, 64, 128), ("acdc", 4, 64, 64)], ids=["cityscapes_20c_64x128", "acdc_4c_64x64"])
+def test_first_step_other_datasets_vs_live_oracle(cfg, dev):
+    """BASELINE configs 3/5 (Cityscapes, 20 classes, non-square crop) and the ACDC geometry (4 classes): first G+D
+    step against the CPU oracle run live on the same keyed weights/inputs.  Exercises the 20- and 4-channel
+    (vectorised, non-fast-path) conv loaders.  Tolerances: SURVEY App. D (1e-3 direct, 5e-3 chained, first step)."""
+    dataset, C, H, Wd = cfg
+    md = load_sub("model")
+    args = FX.make_args(dataset=dataset, crop_height=H, crop_width=Wd, batch_size=2, gpu_ids=[dev.index or 0],
+                        checkpoint_dir="/tmp/sscg_test_ckpt_ds", as_written=True)
+    m = quiet(md.semisuper_cycleGAN, args)
+    tag = "ds_" + dataset
+    for k, sd in FX.semisup_state_dicts(C, torch.float32, tag).items():
+        getattr(m, k).load_state_dict(sd, strict=True)
+    l_img, l_gt, unl_img = FX.step_batch(tag, 0, C, H, Wd, 2)
+    np.random.seed(0)
+    got = {k: float(v) for k, v in m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev)).items()}
+    np.random.seed(0)
+    o32 = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float32, tag), crop=(H, Wd))
+    ref = o32.step(l_img, l_gt, unl_img)
+    np.random.seed(0)
+    o64 = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float64, tag), crop=(H, Wd))
+    r64 = o64.step(l_img.double(), l_gt, unl_img.double())
+    for k in ostep.LOSS_KEYS:
+        noise = abs(ref[k] - r64[k]) / abs(r64[k])
+        e = abs(got[k] - r64[k]) / abs(r64[k])
+        print("%-20s hip %.6f oracle32 %.6f oracle64 %.6f  e64 %.1e noise %.1e" % (k, got[k], ref[k], r64[k], e, noise))
+        chained = k in ("img_cycle_loss", "gt_cycle_loss", "cycle_img_dis_loss")
+        assert e < (max(4 * noise, 1e-3) if chained else 1e-3), k
