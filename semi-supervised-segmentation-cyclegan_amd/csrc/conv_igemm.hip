@@ -51,9 +51,11 @@ struct KcParams {
     float slope;
     int tiles_n;
     int tiles;      // tiles_m * tiles_n
-    int splits;     // split-K factor (partials to `part`, reduced by kc_reduce_kernel)
+    int splits;     // split-K factor of the tiles >= full_tiles (partials to `part`, reduced by kc_reduce_kernel)
     int ksplit;     // k-tiles per split
-    float* __restrict__ part;  // [splits][M][Ng] when splits > 1
+    int full_tiles; // tiles [0, full_tiles) are computed whole by one workgroup each; the rest ("tail") are split
+    int m_tail0;    // first output row of the tail tiles
+    float* __restrict__ part;  // [splits][M - m_tail0][Ng] when splits > 1
 };
 
 // 256 B of zeros: the source of LDS-DMA lanes that fall into padding / outside the tile
@@ -83,9 +85,19 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     int* tapinfo = reinterpret_cast<int*>(Bs + NBUF * BN * LDR);       // [R*S]: (dy << 16) | dx
 
     const int tid = threadIdx.x;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = lin / p.tiles;
-    const int tile = lin - split * p.tiles;
+    // Whole tiles first (one workgroup each), then the tail tiles cut along K: the tail of a launch that does not
+    // fill a whole number of rounds on the 256 CUs is spread over all of them instead of leaving most CUs idle.
+    int split = 0, tile;
+    bool partial = false;
+    if ((int)blockIdx.x < p.full_tiles) {
+        tile = xcd_remap(blockIdx.x, p.full_tiles);
+    } else {
+        const int ntail = p.tiles - p.full_tiles;
+        const int t = xcd_remap(blockIdx.x - p.full_tiles, gridDim.x - p.full_tiles);
+        split = t / ntail;
+        tile = p.full_tiles + (t - split * ntail);
+        partial = p.splits > 1;
+    }
     const int tile_n = tile % p.tiles_n;
     const int tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM;
@@ -173,8 +185,8 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
                            // not touched (=> not waited for) until the MFMAs of the current tile have been issued
 
     const int nk_all = (p.Ktot + BK - 1) / BK;
-    const int kt0 = split * p.ksplit;                       // this workgroup's k-tile range (split-K)
-    const int kt1 = min(nk_all, kt0 + p.ksplit);
+    const int kt0 = partial ? split * p.ksplit : 0;         // this workgroup's k-tile range (split-K)
+    const int kt1 = partial ? min(nk_all, kt0 + p.ksplit) : nk_all;
     // generic-path state: this thread's k column, advanced by BK per tile
     int lk = kt0 * BK + kq * VEC;
     // fast-path state
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (m < p.M) {
-                    if (p.splits > 1) p.part[((size_t)split * p.M + m) * p.Ng + n] = acc[i][j][e];
+                    if (partial) p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc[i][j][e];
                     else p.dst[(size_t)m * p.Ng + n] = sscg_act(acc[i][j][e] + bv, p.act, p.slope);
                 }
             }
@@ -404,40 +416,73 @@ __global__ void kc_reduce_kernel(const float* __restrict__ part, const float* __
     y[i] = sscg_act(s, act, slope);
 }
 
-// Split-K plan for heads with a handful of output channels on few rows (DeepLab classifier: 8712 x 21 x 18432):
-// one 128x32 tile column gives only M/128 workgroups, so the reduction is cut into `splits` ranges.
-struct KcSplit { int splits, ksplit; };
-int sscg_force_conv_split = 0;   // tuning hook: bits 8..15 of sscg_debug_set_conv_cfg
-static KcSplit plan_kc_split(int M, int Ng, int Ktot) {
-    KcSplit r = {1, (Ktot + BK - 1) / BK};
+// ---- host-side plan: tile configuration + split-K of the tail
+// Tile choice (measured on MI355X, tools/conv_bench.py): 128x128 only when it still yields >= 2 workgroups per CU on a
+// long reduction; otherwise 64x64; a 128x32 tile for heads with a handful of output channels.  Shapes whose source
+// channel count is a multiple of BK stage through LDS-DMA (cfg 6/7).
+static const int KC_BM[8] = {128, 128, 64, 64, 128, 128, 64, 128};
+static const int KC_BN[8] = {128, 64, 128, 64, 32, 128, 64, 128};
+int sscg_force_conv_cfg = -1;    // test/tuning hooks (sscg_debug_set_conv_cfg)
+int sscg_force_conv_split = 0;
+
+static int kc_choose_cfg(int M, int Ng, int Ktot, int Cs) {
+    if (sscg_force_conv_cfg >= 0) return sscg_force_conv_cfg;
+    const bool fast = Cs % BK == 0;
+    if (Ng <= 32) return 4;
+    const long w128 = (long)cdiv(M, 128) * cdiv(Ng, 128);
+    if (w128 >= 512 && Ktot >= 1024) return fast ? 7 : 0;   // long reductions amortise the big tile's prologue
+    return fast ? 6 : 3;
+}
+
+struct KcSplit { int splits, ksplit, full_tiles, m_tail0; };
+
+// Which tiles are cut along K, and how often.
+//  * few-channel heads (Ng <= 32) on few rows: every tile (one 128x32 tile column gives only M/128 workgroups);
+//  * 64x64-tile launches: only the TAIL - the tiles beyond the last whole round of 256 workgroups.  The DeepLab
+//    stride-8 maps give 8712 rows -> 548 tiles: 512 whole tiles (2 per CU) + 36 tail tiles cut in 7, so every CU gets
+//    2 1/7 tiles of work instead of 2 or 3 (71 % balance), and only 6.5 % of the output goes through partial sums.
+static KcSplit plan_kc_split(int M, int Ng, int Ktot, int Cs) {
     const int nk = (Ktot + BK - 1) / BK;
-    if (sscg_force_conv_split > 1) {
+    const int cfg = kc_choose_cfg(M, Ng, Ktot, Cs);
+    const int bm = KC_BM[cfg], bn = KC_BN[cfg];
+    const int tiles_m = cdiv(M, bm), tiles_n = cdiv(Ng, bn);
+    const int tiles = tiles_m * tiles_n;
+    KcSplit r = {1, nk, tiles, M};
+    if (sscg_force_conv_split > 1) {            // tuning hook: split every tile
         r.ksplit = cdiv(nk, sscg_force_conv_split);
         r.splits = cdiv(nk, r.ksplit);
+        r.full_tiles = 0; r.m_tail0 = 0;
         return r;
     }
-    if (Ng > 32) {
-        // 64x64-tile shapes with a long reduction on few rows (DeepLab stride-8 3x3 convs: 8712 rows -> 548 workgroups
-        // = 2.14 per CU): cutting K in three gives 6.4 per CU, i.e. 92 % instead of 71 % load balance
-        // (tools/conv_bench.py: 69 -> 86 TF/s at 256 ch, 96 -> 107 at 512 ch).  1x1 convs (short K) are left alone.
-        const long w128 = (long)cdiv(M, 128) * cdiv(Ng, 128);
-        const bool cfg3 = !(w128 >= 512 && Ktot >= 1024);
-        const long w64 = (long)cdiv(M, 64) * cdiv(Ng, 64);
-        if (cfg3 && nk >= 36 && w64 <= 1200) {
-            r.ksplit = cdiv(nk, 3);
-            r.splits = cdiv(nk, r.ksplit);
-        }
+    if (Ng <= 32) {
+        if (tiles >= 256 || nk < 32) return r;
+        int s = cdiv(512, tiles);
+        if (s > nk / 8) s = nk / 8;
+        if (s > 32) s = 32;
+        if (s < 2) return r;
+        r.ksplit = cdiv(nk, s);
+        r.splits = cdiv(nk, r.ksplit);
+        r.full_tiles = 0; r.m_tail0 = 0;
         return r;
     }
-    const int tiles = cdiv(M, 128);
-    if (tiles >= 256 || nk < 32) return r;
-    int s = cdiv(512, tiles);
-    if (s > nk / 8) s = nk / 8;
-    if (s > 32) s = 32;
+    if (bm != 64 || bn != 64 || nk < 8 || tiles > 2300) return r;
+    const int q = tiles / 256;
+    const int full_m = (q * 256) / tiles_n;          // whole tile rows handled unsplit
+    const int tail = tiles - full_m * tiles_n;
+    if (tail <= 0 || tail > 208) return r;             // an almost complete round is left alone
+    int s = 256 / tail;
+    if (s > 8) s = 8;
+    if (s > nk / 4) s = nk / 4;
     if (s < 2) return r;
     r.ksplit = cdiv(nk, s);
     r.splits = cdiv(nk, r.ksplit);
+    r.full_tiles = full_m * tiles_n;
+    r.m_tail0 = full_m * bm;
     return r;
+}
+
+static size_t kc_split_bytes(const KcSplit& sp, int M, int Ng) {
+    return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
 
 template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false>
@@ -455,37 +500,28 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles * p.splits), dim3(256), smem, st, p);
+    if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
+    const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
     SSCG_LAUNCH_CHECK();
     if (p.splits > 1) {
-        size_t n = (size_t)p.M * p.Ng;
-        hipLaunchKernelGGL(kc_reduce_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, p.part, p.bias, p.dst, n, p.Ng, p.splits,
-                           p.act, p.slope);
+        size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
+        hipLaunchKernelGGL(kc_reduce_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, p.part, p.bias,
+                           p.dst + (size_t)p.m_tail0 * p.Ng, n, p.Ng, p.splits, p.act, p.slope);
         SSCG_LAUNCH_CHECK();
     }
     return SSCG_OK;
 }
 
-// Tile choice (measured on MI355X, tools/conv_bench.py): 128x128 only when it still yields >= ~2 workgroups
-// per CU; otherwise 64x64, whose finer granularity balances the 256 CUs better on the DeepLab stride-8 maps
-// (8 x 33 x 33 = 8712 rows); a 128x32 tile for heads with a handful of output channels.
 template <int MODE, int VEC, bool FAST>
-int dispatch_kc(const KcParams& p, hipStream_t st, int force_cfg) {
-    auto wgs = [&](int bm, int bn) { return (long)cdiv(p.M, bm) * cdiv(p.Ng, bn); };
-    int cfg = force_cfg;
-    if (cfg < 0) {
-        // FAST shapes stage through LDS-DMA (cfg 6/7: +5..8 % over register staging, tools/conv_bench.py)
-        if (p.Ng <= 32) cfg = 4;
-        else if (wgs(128, 128) >= 512 && p.Ktot >= 1024) cfg = FAST ? 7 : 0;   // long reductions amortise the big tile's prologue
-        else cfg = FAST ? 6 : 3;
-    }
-    switch (cfg) {
+int dispatch_kc(const KcParams& p, hipStream_t st) {
+    switch (kc_choose_cfg(p.M, p.Ng, p.Ktot, p.Cs)) {
         case 0: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST>(p, st);
         case 1: return launch_kc<MODE, 2, 2, 2, 1, VEC, FAST>(p, st);
         case 2: return launch_kc<MODE, 2, 2, 1, 2, VEC, FAST>(p, st);
         case 3: return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST>(p, st);
         case 4: return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST>(p, st);
-        case 5: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 1>(p, st);   // 128x128, single LDS image (36 KB: 4 workgroups/CU)
+        case 5: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 1>(p, st);   // 128x128, single LDS image (experimental)
         case 6: if constexpr (FAST) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
         case 7: if constexpr (FAST) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
         default: return SSCG_ERR_BAD_ARG;
@@ -493,15 +529,13 @@ int dispatch_kc(const KcParams& p, hipStream_t st, int force_cfg) {
 }
 
 template <int MODE>
-int dispatch_mode(const KcParams& p, hipStream_t st, int force_cfg) {
-    if (p.Cs % BK == 0) return dispatch_kc<MODE, 4, true>(p, st, force_cfg);
-    if (p.Cs % 4 == 0) return dispatch_kc<MODE, 4, false>(p, st, force_cfg);
-    return dispatch_kc<MODE, 1, false>(p, st, force_cfg);
+int dispatch_mode(const KcParams& p, hipStream_t st) {
+    if (p.Cs % BK == 0) return dispatch_kc<MODE, 4, true>(p, st);
+    if (p.Cs % 4 == 0) return dispatch_kc<MODE, 4, false>(p, st);
+    return dispatch_kc<MODE, 1, false>(p, st);
 }
 
 }  // namespace
-
-int sscg_force_conv_cfg = -1;  // test/tuning hook (sscg_debug_set_conv_cfg)
 
 extern "C" int sscg_debug_set_conv_cfg(int cfg) {
     if (cfg < 0) { sscg_force_conv_cfg = -1; sscg_force_conv_split = 0; return SSCG_OK; }
@@ -527,14 +561,12 @@ static int check_desc(const sscg_conv_desc* d) {
 
 extern "C" size_t sscg_conv2d_fwd_workspace(const sscg_conv_desc* d) {
     if (!d) return 0;
-    KcSplit sp = plan_kc_split(d->N * d->P * d->Q, d->K, d->R * d->S * d->C);
-    return sp.splits > 1 ? (size_t)sp.splits * d->N * d->P * d->Q * d->K * sizeof(float) : 0;
+    return kc_split_bytes(plan_kc_split(d->N * d->P * d->Q, d->K, d->R * d->S * d->C, d->C), d->N * d->P * d->Q, d->K);
 }
 
 extern "C" size_t sscg_conv2d_dgrad_workspace(const sscg_conv_desc* d) {
     if (!d) return 0;
-    KcSplit sp = plan_kc_split(d->N * d->H * d->W, d->C, d->R * d->S * d->K);
-    return sp.splits > 1 ? (size_t)sp.splits * d->N * d->H * d->W * d->C * sizeof(float) : 0;
+    return kc_split_bytes(plan_kc_split(d->N * d->H * d->W, d->C, d->R * d->S * d->K, d->K), d->N * d->H * d->W, d->C);
 }
 
 extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -548,10 +580,11 @@ extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const fl
     p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope; p.tiles_n = 0; p.tiles = 0;
-    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot);
-    if (sp.splits > 1 && (!ws || ws_bytes < (size_t)sp.splits * p.M * p.Ng * sizeof(float))) return SSCG_ERR_WORKSPACE;
-    p.splits = sp.splits; p.ksplit = sp.ksplit; p.part = reinterpret_cast<float*>(ws);
-    return dispatch_mode<MODE_FWD>(p, (hipStream_t)stream, sscg_force_conv_cfg);
+    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs);
+    if (sp.splits > 1 && (!ws || ws_bytes < kc_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
+    p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
+    p.part = reinterpret_cast<float*>(ws);
+    return dispatch_mode<MODE_FWD>(p, (hipStream_t)stream);
 }
 
 // Data gradient (and ConvTranspose2d forward): dx[n][iy][ix][c] = sum_{ky,kx,k} dy[n][oy][ox][k] * wt[c][ky][kx][k]
@@ -571,10 +604,11 @@ extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const
     p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = 0; p.act = act; p.slope = slope; p.tiles_n = 0; p.tiles = 0;
-    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot);
-    if (sp.splits > 1 && (!ws || ws_bytes < (size_t)sp.splits * p.M * p.Ng * sizeof(float))) return SSCG_ERR_WORKSPACE;
-    p.splits = sp.splits; p.ksplit = sp.ksplit; p.part = reinterpret_cast<float*>(ws);
-    return dispatch_mode<MODE_DGRAD>(p, (hipStream_t)stream, sscg_force_conv_cfg);
+    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs);
+    if (sp.splits > 1 && (!ws || ws_bytes < kc_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
+    p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
+    p.part = reinterpret_cast<float*>(ws);
+    return dispatch_mode<MODE_DGRAD>(p, (hipStream_t)stream);
 }
 
 // [K][RS][C] -> [C][RS][K] (weights are a few MB; one pass per optimiser step per conv that needs dgrad)
