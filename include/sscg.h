@@ -78,7 +78,8 @@ int sscg_colsum(const float* x, float* out, int64_t rows, int cols, float beta, 
 
 /* tuning/test hook: force the forward/dgrad tile configuration (-1 = heuristic) */
 int sscg_debug_set_conv_cfg(int cfg);
-/* tuning hook: wgrad split plan (target workgroup count, minimum k-steps per split for 128x128 tiles) */
+/* tuning hook (tools/wgrad_sweep.py): min_iters < 0 forces tile class `target_wgs` (0 = 128x128, 1 = 64x64) with
+ * -min_iters pixel splits; min_iters >= 0 restores the built-in cost model */
 int sscg_debug_set_wgrad_plan(int target_wgs, int min_iters);
 
 /* ------------------------------------------------------------------ normalisation (K3, K4, K7)

@@ -300,8 +300,28 @@ struct WgPlan {
     int chunk;
 };
 
-int sscg_wgrad_target_wgs = 768;   // tuning hooks (sscg_debug_set_wgrad_plan); defaults from tools/conv_bench.py sweeps
-int sscg_wgrad_min_iters = 12;
+int sscg_wgrad_force_cfg = -1, sscg_wgrad_force_splits = 0;   // sweep hook (tools/wgrad_sweep.py)
+
+// Cost model of one (tile class, pixel splits) choice, fitted to tools/wgrad_sweep.py on the MI355X:
+//   workgroups spread over 256 CUs => a CU runs r = ceil(tiles*splits / 256) of them (co-resident or back to back, the
+//   time is the same: they share the CU's matrix cores), each ceil(steps/splits) k-steps plus a prologue/epilogue worth
+//   c0 steps; fewer than 2 (128x128) / 4 (64x64) co-resident workgroups leave load latency exposed (factor f);
+//   the partial tiles cost splits * |dw| bytes written and read again by the reduction.
+struct WgClass { int cfg, bm, bn; float t_step_us, c0; float f[4]; };
+const WgClass WG_CLASSES[] = {
+    {0, 128, 128, 2.13f, 1.5f, {1.25f, 1.f, 1.f, 1.f}},
+    {1, 64, 64, 0.59f, 2.f, {1.5f, 1.17f, 1.08f, 1.f}},
+    {2, 32, 128, 0.70f, 2.f, {1.5f, 1.17f, 1.08f, 1.f}},
+    {3, 128, 32, 0.70f, 2.f, {1.5f, 1.17f, 1.08f, 1.f}},
+};
+
+float wgrad_cost_us(const WgClass& c, long tiles, long steps, long s, double out_bytes) {
+    long r = cdiv(tiles * s, 256);
+    float f = c.f[r > 4 ? 3 : r - 1];
+    float t = (float)r * ((float)cdiv(steps, s) + c.c0) * c.t_step_us * f;
+    if (s > 1) t += (float)(2.0 * s * out_bytes / 4.0e6) + 4.f;
+    return t;
+}
 
 WgPlan plan_wgrad(const sscg_conv_desc* d) {
     WgPlan pl;
@@ -309,26 +329,36 @@ WgPlan plan_wgrad(const sscg_conv_desc* d) {
     const int Ng = d->R * d->S * d->C;
     const long npix = (long)d->N * d->P * d->Q;
     const long steps = cdiv(npix, BKP);
-    auto splits_for = [&](int bm, int bn) {
-        long tiles = (long)cdiv(Kc, bm) * cdiv(Ng, bn);
-        long s = cdiv(sscg_wgrad_target_wgs, tiles);
-        if (s < 1) s = 1;
-        long mx = steps / 4 < 1 ? 1 : steps / 4;   // at least 4 k-steps per split
-        if (s > mx) s = mx;
-        if (s > 64) s = 64;
-        return s;
-    };
-    if (Kc <= 32) { pl.cfg = 2; pl.bm = 32; pl.bn = 128; }
-    else if (Ng <= 32 || d->C < 32) { pl.cfg = 3; pl.bm = 128; pl.bn = 32; }
-    else if (Kc <= 64 || Ng <= 64) { pl.cfg = 1; pl.bm = 64; pl.bn = 64; }
-    else {
-        // 128x128 tiles only if every workgroup still gets a long enough pixel range; otherwise 64x64 tiles:
-        // 4x the tiles => 1/4 of the splits => 1/4 of the partial-sum traffic and 4x longer main loops
-        long s0 = splits_for(128, 128);
-        if (steps / s0 >= sscg_wgrad_min_iters) { pl.cfg = 0; pl.bm = 128; pl.bn = 128; }
-        else { pl.cfg = 1; pl.bm = 64; pl.bn = 64; }
+    const double out_bytes = (double)Kc * Ng * sizeof(float);
+    int first = 0, last = 1;   // candidate classes
+    if (Kc <= 32) first = last = 2;
+    else if (Ng <= 32 || d->C < 32) first = last = 3;
+    else if (Kc <= 64 || Ng <= 64) first = last = 1;
+    float best = 0.f;
+    long best_s = 1;
+    pl.cfg = -1;
+    for (int ci = first; ci <= last; ++ci) {
+        const WgClass& c = WG_CLASSES[ci];
+        const long tiles = (long)cdiv(Kc, c.bm) * cdiv(Ng, c.bn);
+        const long smax = steps / 2 < 1 ? 1 : (steps / 2 > 512 ? 512 : steps / 2);
+        long prev = 0;
+        for (int k = 0; k <= 16; ++k) {       // splits that fill k rounds of 256 workgroups (k = 0: unsplit)
+            long sp = k == 0 ? 1 : (256L * k) / tiles;
+            if (sp < 1) sp = 1;
+            if (sp > smax) sp = smax;
+            if (sp == prev) continue;
+            prev = sp;
+            float t = wgrad_cost_us(c, tiles, steps, sp, out_bytes);
+            if (pl.cfg < 0 || t < best) { best = t; best_s = sp; pl.cfg = c.cfg; pl.bm = c.bm; pl.bn = c.bn; }
+        }
     }
-    long splits = splits_for(pl.bm, pl.bn);
+    long splits = best_s;
+    if (sscg_wgrad_force_cfg >= 0 && pl.cfg <= 1) {
+        pl.cfg = sscg_wgrad_force_cfg;
+        pl.bm = pl.bn = pl.cfg == 0 ? 128 : 64;
+        splits = sscg_wgrad_force_splits;
+        if (splits > steps) splits = steps;
+    }
     long steps_per = cdiv(steps, splits);
     pl.chunk = (int)(steps_per * BKP);
     pl.splits = cdiv(npix, pl.chunk);
@@ -368,8 +398,12 @@ int dispatch_wg(const WgParams& p, const WgPlan& pl, hipStream_t st) {
 }  // namespace
 
 extern "C" int sscg_debug_set_wgrad_plan(int target_wgs, int min_iters) {
-    if (target_wgs > 0) sscg_wgrad_target_wgs = target_wgs;
-    if (min_iters > 0) sscg_wgrad_min_iters = min_iters;
+    if (min_iters < 0) {   // forced (cfg, splits) for the 128x128 / 64x64 classes
+        sscg_wgrad_force_cfg = target_wgs;
+        sscg_wgrad_force_splits = -min_iters;
+        return SSCG_OK;
+    }
+    sscg_wgrad_force_cfg = -1;   // anything else: back to the cost model
     return SSCG_OK;
 }
 
