@@ -76,7 +76,8 @@ int sscg_weight_krsc_to_crsk(const float* w, float* wt, int K, int RS, int C, vo
 size_t sscg_colsum_workspace(int64_t rows, int cols);
 int sscg_colsum(const float* x, float* out, int64_t rows, int cols, float beta, void* ws, size_t ws_bytes, void* stream);
 
-/* tuning/test hook: force the forward/dgrad tile configuration (-1 = heuristic) */
+/* tuning/test hook: bits 0..7 force the forward/dgrad tile configuration (0xff = keep the heuristic), bits 8..15 the
+ * split-K factor (0 = planner, 1 = never split, n > 1 = every tile cut in n); -1 restores the defaults */
 int sscg_debug_set_conv_cfg(int cfg);
 /* tuning hook (tools/wgrad_sweep.py): min_iters < 0 forces tile class `target_wgs` (0 = 128x128, 1 = 64x64) with
  * -min_iters pixel splits; min_iters >= 0 restores the built-in cost model */

@@ -448,6 +448,7 @@ static KcSplit plan_kc_split(int M, int Ng, int Ktot, int Cs) {
     const int tiles_m = cdiv(M, bm), tiles_n = cdiv(Ng, bn);
     const int tiles = tiles_m * tiles_n;
     KcSplit r = {1, nk, tiles, M};
+    if (sscg_force_conv_split == 1) return r;   // tuning hook: never split
     if (sscg_force_conv_split > 1) {            // tuning hook: split every tile
         r.ksplit = cdiv(nk, sscg_force_conv_split);
         r.splits = cdiv(nk, r.ksplit);

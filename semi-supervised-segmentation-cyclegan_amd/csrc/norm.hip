@@ -37,9 +37,13 @@ __device__ __forceinline__ float act_grad(float dy, float y, int act, float slop
     return dy;
 }
 
-// block = 256 threads = RW row-lanes x CW column groups (CW power of two <= 256), VEC channels per group
+// block = 256 threads = RW row-lanes x CW column groups (CW power of two), VEC channels per group; a block owns the
+// channel slab blockIdx.z and the row chunk blockIdx.x of group blockIdx.y.  Rows are taken U at a time so that U
+// (3U for the backward sums) independent 16-byte loads are in flight per thread: these tensors are a few MB, the
+// kernel lives for a handful of memory latencies and nothing else hides them.
 template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
+    constexpr int U = 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* sm = reinterpret_cast<double*>(smem_raw);  // [256][VEC][2]
     const int tid = threadIdx.x;
@@ -65,40 +69,48 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
         const long r_begin = (long)chunk * p.rows_per_chunk;
         const long r_end = min(p.L, r_begin + p.rows_per_chunk);
         const size_t base = (size_t)g * p.L * p.C + c;
-        for (long r = r_begin + rl; r < r_end; r += RW) {
-            const size_t o = base + (size_t)r * p.C;
-            float xv[VEC];
-            if constexpr (VEC == 4) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(p.x + o);
+        const bool has_y = MODE == RM_BWD && p.act != SSCG_ACT_NONE;  // y may be NULL without an activation
+        for (long r0 = r_begin + rl; r0 < r_end; r0 += (long)RW * U) {
+            float xv[U][VEC], dv[U][VEC], yv[U][VEC];
+            bool ok[U];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xv[e] = t[e];
-            } else {
-                xv[0] = p.x[o];
-            }
-            if (MODE == RM_SUM) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) s0[e] += (double)xv[e];
-            } else if (MODE == RM_STATS) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) { double d = (double)xv[e]; s0[e] += d; s1[e] += d * d; }
-            } else {
-                float dv[VEC], yv[VEC];
-                const bool has_y = p.act != SSCG_ACT_NONE;  // y may be NULL without an activation
+            for (int u = 0; u < U; ++u) {
+                const long r = r0 + (long)u * RW;
+                ok[u] = r < r_end;
+                const size_t o = base + (size_t)(ok[u] ? r : r_begin) * p.C;
                 if constexpr (VEC == 4) {
-                    f32x4 t = *reinterpret_cast<const f32x4*>(p.dy + o);
-                    f32x4 u = {0.f, 0.f, 0.f, 0.f};
-                    if (has_y) u = *reinterpret_cast<const f32x4*>(p.y + o);
+                    f32x4 t = *reinterpret_cast<const f32x4*>(p.x + o);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { dv[e] = t[e]; yv[e] = u[e]; }
+                    for (int e = 0; e < 4; ++e) xv[u][e] = t[e];
+                    if (MODE == RM_BWD) {
+                        f32x4 a = *reinterpret_cast<const f32x4*>(p.dy + o);
+                        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                        if (has_y) b = *reinterpret_cast<const f32x4*>(p.y + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { dv[u][e] = a[e]; yv[u][e] = b[e]; }
+                    }
                 } else {
-                    dv[0] = p.dy[o]; yv[0] = has_y ? p.y[o] : 0.f;
+                    xv[u][0] = p.x[o];
+                    if (MODE == RM_BWD) { dv[u][0] = p.dy[o]; yv[u][0] = has_y ? p.y[o] : 0.f; }
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    float gg = act_grad(dv[e], yv[e], p.act, p.slope);
-                    float xh = (xv[e] - mu[e]) * rs[e];
-                    s0[e] += (double)gg;
-                    s1[e] += (double)gg * (double)xh;
+                    if (MODE == RM_SUM) {
+                        s0[e] += (double)xv[u][e];
+                    } else if (MODE == RM_STATS) {
+                        double d = (double)xv[u][e];
+                        s0[e] += d;
+                        s1[e] += d * d;
+                    } else {
+                        float gg = act_grad(dv[u][e], yv[u][e], p.act, p.slope);
+                        float xh = (xv[u][e] - mu[e]) * rs[e];
+                        s0[e] += (double)gg;
+                        s1[e] += (double)gg * (double)xh;
+                    }
                 }
             }
         }
@@ -131,15 +143,18 @@ struct RedPlan {
 RedPlan plan_reduce(int G, long L, int C) {
     RedPlan pl;
     pl.vec = (C % 4 == 0) ? 4 : 1;
-    int groups = C / pl.vec;
+    const int groups = C / pl.vec;
+    // 256-byte row segments per block: narrow slabs => many row lanes => few chunks => a short second stage
+    const int cw_max = pl.vec == 4 ? 16 : 64;
     int cw = 1;
-    while (cw < groups && cw < 256) cw <<= 1;
+    while (cw < groups && cw < cw_max) cw <<= 1;
     pl.CW = cw;
     pl.slabs = cdiv(groups, cw);
-    int rw = 256 / cw;
-    long budget = 2048 / ((long)G * pl.slabs);
+    const int rw = 256 / cw;
+    long budget = 2048 / ((long)G * pl.slabs);   // ~2048 workgroups at most
     if (budget < 1) budget = 1;
-    long by_rows = cdiv(L, (long)rw * 8);  // at least ~8 rows per thread
+    if (budget > 128) budget = 128;
+    long by_rows = cdiv(L, (long)rw * 8);        // at least ~8 rows per thread
     if (by_rows < 1) by_rows = 1;
     long chunks = by_rows < budget ? by_rows : budget;
     pl.rows_per_chunk = cdiv(L, chunks);

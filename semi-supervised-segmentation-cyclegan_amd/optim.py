@@ -30,8 +30,11 @@ class FusedAdam(torch.optim.Optimizer):
         dev = ps[0].device
         if dev.type != "cuda":
             raise F._lib.SscgError("FusedAdam needs parameters on the MI355X (call net.cuda() / pass gpu_ids first)")
-        total = sum(p.numel() for p in ps)
+        # every parameter starts on a 256-byte boundary: the conv loaders and the fused split reductions move 16 bytes
+        # per lane, and a slice at an odd offset would split each of those accesses
+        total = sum(self._padded(p.numel()) for p in ps)
         self.arena = torch.empty(total, dtype=torch.float32, device=dev)
+        F.fill_(self.arena, 0.0)
         self.grad = torch.empty(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.empty(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.empty(total, dtype=torch.float32, device=dev)
@@ -49,7 +52,11 @@ class FusedAdam(torch.optim.Optimizer):
             p._sscg_grad = g
             p._sscg_touched = False
             p.grad = g
-            off += n
+            off += self._padded(n)
+
+    @staticmethod
+    def _padded(n):
+        return (n + 63) // 64 * 64
 
     @staticmethod
     def _view(flat, p, off):

@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Compare every conv call of a network forward/backward with and without split-K (bug-localisation aid)."""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "semi-supervised-segmentation-cyclegan_amd"
+F = importlib.import_module(PKG + ".functional")
+arch = importlib.import_module(PKG + ".arch")
+from oracle import fixtures as FX  # noqa: E402  (debug tool only)
+
+dev = torch.device("cuda:0")
+name, kind, args, xshape = [n for n in FX.NETS if n[0] == (sys.argv[1] if len(sys.argv) > 1 else "resnet9sm_3_21")][0]
+
+log = []
+orig = {k: getattr(F, k) for k in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "norm_bwd", "norm_stats", "norm_apply", "reflect_pad_bwd", "reflect_pad", "add", "act_bwd")}
+
+
+def wrap(k):
+    def f(*a, **kw):
+        out = orig[k](*a, **kw)
+        shapes = [tuple(t.shape) if torch.is_tensor(t) else t for t in a]
+        o = out[0] if isinstance(out, (tuple, list)) else out
+        log.append((k, shapes, o.detach().clone(), [t.detach().clone() if torch.is_tensor(t) else t for t in a] if k == 'norm_bwd' else None))
+        return out
+    return f
+
+
+for k in orig:
+    setattr(F, k, wrap(k))
+
+
+def run(flag):
+    F.lib.sscg_debug_set_conv_cfg(flag)
+    log.clear()
+    torch.manual_seed(0)
+    m = arch.define_Gen(args[0], args[1], 64, kind, norm="instance", use_dropout=False, gpu_ids=[0])
+    m.load_state_dict(FX.net_weights(name, kind, args), strict=True)
+    m.train()
+    x = FX.net_input(name, xshape).to(dev).requires_grad_(True)
+    y = m(x)
+    gy = FX.net_grad_out(name, y.shape).to(dev)
+    y.backward(F.to_nhwc(gy))
+    torch.cuda.synchronize()
+    return list(log), x.grad.clone()
+
+
+a, ga = run(0xff | (1 << 8))     # heuristic tiles, never split
+b, gb = run(-1)
+print("dx diff", ((ga - gb).abs().max() / ga.abs().max()).item())
+done = False
+for (k1, s1, o1, a1), (k2, s2, o2, a2) in zip(a, b):
+    e = ((o1 - o2).abs().max() / o1.abs().max().clamp_min(1e-30)).item()
+    print("%-13s %-70s %.2e %s" % (k1, str(s1)[:70], e, "<<<<" if e > 1e-4 else ""))
+    if e > 1e-4 and k1 == "norm_bwd" and not done:
+        done = True
+        d = (o1 - o2).abs() / o1.abs().max()
+        bad = d > 1e-3
+        print("   elements off by > 1e-3 of max:", int(bad.sum()), "of", d.numel())
+        idx = bad.nonzero()
+        print("   (n, c) of those:", sorted(set((int(i[0]), int(i[1])) for i in idx))[:10])
+        if a1[2] is not None:
+            y1, y2 = a1[2], a2[2]
+            flip = (y1 > 0) != (y2 > 0)
+            print("   relu mask flips between the runs:", int(flip.sum()), "at", flip.nonzero()[:4].tolist(),
+                  " y there:", y1[flip][:4].tolist(), y2[flip][:4].tolist())
+            print("   dy input diff:", ((a1[0] - a2[0]).abs().max() / a1[0].abs().max()).item())
