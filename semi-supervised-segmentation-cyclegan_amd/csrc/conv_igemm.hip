@@ -46,6 +46,10 @@ struct KcParams {
     int OH, OW;   // destination spatial (row decode)
     int R, S;
     int stride, pad, dil;
+    int pad_x;      // horizontal padding (== pad except for the parity classes of a strided data gradient)
+    int wKtot;      // row stride of `wgt` (== Ktot unless the launch walks a sub-lattice of the taps)
+    int wt_ky0, wt_kx0, wt_step, wt_S;   // tap (ty, tx) of this launch = tap (wt_ky0 + ty*wt_step, wt_kx0 + tx*wt_step) of the [R][wt_S] weight
+    int o_step, o_a, o_b, o_W, o_HW;     // output row (img, i, j) -> pixel img*o_HW + (i*o_step + o_a)*o_W + j*o_step + o_b
     int pad_mode;
     int act;
     float slope;
@@ -83,6 +87,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     float* As = reinterpret_cast<float*>(smem_raw);                 // [NBUF][BM][LDR]
     float* Bs = As + NBUF * BM * LDR;                               // [NBUF][BN][LDR]
     int* tapinfo = reinterpret_cast<int*>(Bs + NBUF * BN * LDR);       // [R*S]: (dy << 16) | dx
+    int* wtapinfo = tapinfo + (p.R * p.S > 0 ? p.R * p.S : 1);         // [R*S]: tap index inside the weight row
 
     const int tid = threadIdx.x;
     // Whole tiles first (one workgroup each), then the tail tiles cut along K: the tail of a launch that does not
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
         int ky = t / p.S;
         int kx = t - ky * p.S;
         tapinfo[t] = ((ky * p.dil) << 16) | (kx * p.dil);
+        wtapinfo[t] = (p.wt_ky0 + ky * p.wt_step) * p.wt_S + p.wt_kx0 + kx * p.wt_step;
     }
 
     const int r0 = tid / KQ;
@@ -130,10 +136,10 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
         arow[ps] = p.src + (size_t)img * p.SH * p.SW * p.Cs;
         if (MODE == MODE_FWD) {
             ay0[ps] = oy * p.stride - p.pad;
-            ax0[ps] = ox * p.stride - p.pad;
+            ax0[ps] = ox * p.stride - p.pad_x;
         } else {
             ay0[ps] = oy + p.pad;
-            ax0[ps] = ox + p.pad;
+            ax0[ps] = ox + p.pad_x;
         }
     }
     const float* brow[PB];
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     for (int ps = 0; ps < PB; ++ps) {
         const int n = n0 + r0 + ps * RPP;
         bok[ps] = n < p.Ng;
-        brow[ps] = p.wgt + (size_t)(bok[ps] ? n : 0) * p.Ktot + kq * VEC;
+        brow[ps] = p.wgt + (size_t)(bok[ps] ? n : 0) * p.wKtot + kq * VEC;
     }
     __syncthreads();              // tapinfo visible
 
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     auto fast_set_tap = [&](int tap) {
         const int ti = tapinfo[tap];
         const int tdy = ti >> 16, tdx = ti & 0xffff;
+        f_k = wtapinfo[tap] * p.Cs;          // first channel of this tap inside the weight row
         f_okbits = 0;
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
@@ -210,7 +217,10 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
             aptr[ps] = arow[ps] + (size_t)pix * p.Cs + kq * VEC;
         }
     };
-    if (FAST) fast_set_tap(f_tap < p.R * p.S ? f_tap : 0);
+    if (FAST) {
+        fast_set_tap(f_tap < p.R * p.S ? f_tap : 0);
+        f_k += f_chunk * BK;
+    }
 
     auto load_tile = [&]() {
         if constexpr (FAST) {
@@ -397,23 +407,43 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (m < p.M) {
-                    if (partial) p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc[i][j][e];
-                    else p.dst[(size_t)m * p.Ng + n] = sscg_act(acc[i][j][e] + bv, p.act, p.slope);
+                    if (partial) {
+                        p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc[i][j][e];
+                    } else {
+                        size_t row = (size_t)m;
+                        if (p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
+                            const int img = m / (p.OH * p.OW);
+                            const int rem = m - img * (p.OH * p.OW);
+                            const int oi = rem / p.OW;
+                            const int oj = rem - oi * p.OW;
+                            row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+                        }
+                        p.dst[row * p.Ng + n] = sscg_act(acc[i][j][e] + bv, p.act, p.slope);
+                    }
                 }
             }
         }
     }
 }
 
-// y[i] = act(sum_s part[s][i] + bias[i % Ng])   (fixed order => deterministic)
-__global__ void kc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y, size_t n,
-                                 int Ng, int splits, int act, float slope) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// y[i] = act(sum_s part[s][i] + bias[i % Ng])   (fixed order => deterministic); V floats per thread
+template <int V>
+__global__ __launch_bounds__(256) void kc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                         float* __restrict__ y, size_t n, int Ng, int splits, int act, float slope) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
-    if (bias) s += bias[i % Ng];
-    y[i] = sscg_act(s, act, slope);
+    typedef float vec_t __attribute__((ext_vector_type(V)));
+    vec_t s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < splits; ++k) s += *reinterpret_cast<const vec_t*>(part + (size_t)k * n + i);
+    const int c = (int)(i % Ng);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        float v = s[e];
+        if (bias) v += bias[c + e];     // V == 4 only when Ng % 4 == 0: the V channels are consecutive
+        s[e] = sscg_act(v, act, slope);
+    }
+    *reinterpret_cast<vec_t*>(y + i) = s;
 }
 
 // ---- host-side plan: tile configuration + split-K of the tail
@@ -495,7 +525,7 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     int tiles_m = cdiv(p.M, BM);
     p.tiles = tiles_m * p.tiles_n;
     constexpr int LDR = DMA ? BK : LDK;
-    size_t smem = (size_t)(NBUF * BM * LDR + NBUF * BN * LDR) * sizeof(float) + (size_t)p.R * p.S * 4;
+    size_t smem = (size_t)(NBUF * BM * LDR + NBUF * BN * LDR) * sizeof(float) + (size_t)(p.R * p.S > 0 ? p.R * p.S : 1) * 8;
     auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST, NBUF, DMA>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -507,8 +537,13 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     SSCG_LAUNCH_CHECK();
     if (p.splits > 1) {
         size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
-        hipLaunchKernelGGL(kc_reduce_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, p.part, p.bias,
-                           p.dst + (size_t)p.m_tail0 * p.Ng, n, p.Ng, p.splits, p.act, p.slope);
+        float* yt = p.dst + (size_t)p.m_tail0 * p.Ng;
+        if (p.Ng % 4 == 0 && (((size_t)yt | (size_t)p.part) & 15) == 0)
+            hipLaunchKernelGGL(kc_reduce_kernel<4>, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st, p.part, p.bias, yt, n, p.Ng,
+                               p.splits, p.act, p.slope);
+        else
+            hipLaunchKernelGGL(kc_reduce_kernel<1>, dim3(cdiv((long)n, 256)), dim3(256), 0, st, p.part, p.bias, yt, n, p.Ng,
+                               p.splits, p.act, p.slope);
         SSCG_LAUNCH_CHECK();
     }
     return SSCG_OK;
@@ -545,6 +580,18 @@ extern "C" int sscg_debug_set_conv_cfg(int cfg) {
     return SSCG_OK;
 }
 
+// launch walks every tap of a dense [R][S] weight and writes rows in order
+static void kc_dense_taps(KcParams& p) {
+    p.pad_x = p.pad; p.wKtot = p.Ktot;
+    p.wt_ky0 = 0; p.wt_kx0 = 0; p.wt_step = 1; p.wt_S = p.S;
+    p.o_step = 1; p.o_a = 0; p.o_b = 0; p.o_W = 0; p.o_HW = 0;
+}
+
+// stride-2 data gradients are decomposed into parity classes when the vectorised tap walk applies (K % BK == 0)
+static bool dgrad_by_parity(const sscg_conv_desc* d) {
+    return sscg_force_conv_cfg < 0 && d->stride == 2 && d->dil == 1 && d->pad_mode == 0 && d->K % BK == 0;
+}
+
 static int check_desc(const sscg_conv_desc* d) {
     if (!d) return SSCG_ERR_BAD_ARG;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0) return SSCG_ERR_BAD_ARG;
@@ -567,6 +614,7 @@ extern "C" size_t sscg_conv2d_fwd_workspace(const sscg_conv_desc* d) {
 
 extern "C" size_t sscg_conv2d_dgrad_workspace(const sscg_conv_desc* d) {
     if (!d) return 0;
+    if (dgrad_by_parity(d)) return 0;
     return kc_split_bytes(plan_kc_split(d->N * d->H * d->W, d->C, d->R * d->S * d->K, d->K), d->N * d->H * d->W, d->C);
 }
 
@@ -581,6 +629,7 @@ extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const fl
     p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope; p.tiles_n = 0; p.tiles = 0;
+    kc_dense_taps(p);
     KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs);
     if (sp.splits > 1 && (!ws || ws_bytes < kc_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
@@ -605,6 +654,36 @@ extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const
     p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = 0; p.act = act; p.slope = slope; p.tiles_n = 0; p.tiles = 0;
+    kc_dense_taps(p);
+    if (dgrad_by_parity(d)) {
+        // Stride 2: an output pixel (2i+a, 2j+b) only meets the taps with ky = a+pad, kx = b+pad (mod 2).  Each of the
+        // four parity classes is a stride-1 data gradient over its own sub-lattice of taps, written interleaved into
+        // dx: a quarter of the multiply-adds of walking all R*S taps with three quarters of them masked.
+        p.splits = 1; p.ksplit = 0; p.part = nullptr;
+        p.stride = 1; p.wt_step = 2; p.wt_S = d->S;
+        p.o_step = 2; p.o_W = d->W; p.o_HW = d->H * d->W;
+        for (int a = 0; a < 2; ++a) {
+            for (int b = 0; b < 2; ++b) {
+                const int Ha = (d->H - a + 1) / 2, Wb = (d->W - b + 1) / 2;
+                if (Ha <= 0 || Wb <= 0) continue;
+                const int ky0 = (a + d->pad) & 1, kx0 = (b + d->pad) & 1;
+                KcParams q = p;
+                q.R = ky0 < d->R ? (d->R - ky0 + 1) / 2 : 0;
+                q.S = kx0 < d->S ? (d->S - kx0 + 1) / 2 : 0;
+                if (q.R == 0 || q.S == 0) { q.R = 0; q.S = 0; }     // no tap meets this class: dx = act(bias)
+                q.pad = (a + d->pad - ky0) / 2;
+                q.pad_x = (b + d->pad - kx0) / 2;
+                q.wt_ky0 = ky0; q.wt_kx0 = kx0;
+                q.o_a = a; q.o_b = b;
+                q.OH = Ha; q.OW = Wb;
+                q.M = d->N * Ha * Wb;
+                q.Ktot = q.R * q.S * q.Cs;
+                rc = dispatch_mode<MODE_DGRAD>(q, (hipStream_t)stream);
+                if (rc) return rc;
+            }
+        }
+        return SSCG_OK;
+    }
     KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs);
     if (sp.splits > 1 && (!ws || ws_bytes < kc_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;

@@ -284,13 +284,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     }
 }
 
-// dw[i] = beta * dw[i] + sum_s ws[s][i]  (fixed order)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n, int splits, float beta) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// dw[i] = beta * dw[i] + sum_s ws[s][i]  (fixed order => deterministic).  V floats per thread; the split loop is
+// unrolled so that 8 independent loads are in flight per thread (the kernel is a pure stream of splits * |dw| bytes).
+template <int V>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n, int splits,
+                                                            float beta) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + i];
-    dw[i] = (beta != 0.f) ? beta * dw[i] + s : s;
+    typedef float vec_t __attribute__((ext_vector_type(V)));
+    vec_t s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < splits; ++k) s += *reinterpret_cast<const vec_t*>(ws + (size_t)k * n + i);
+    vec_t* d = reinterpret_cast<vec_t*>(dw + i);
+    *d = (beta != 0.f) ? beta * *d + s : s;
 }
 
 struct WgPlan {
@@ -444,8 +450,12 @@ extern "C" int sscg_conv2d_wgrad(const sscg_conv_desc* d, const float* x, const 
     if (rc) return rc;
     if (pl.splits > 1) {
         size_t n = (size_t)d->K * p.Ng;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st,
-                           reinterpret_cast<const float*>(ws), dw, n, pl.splits, beta);
+        if (n % 4 == 0 && ((size_t)dw & 15) == 0 && ((size_t)ws & 15) == 0)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st,
+                               reinterpret_cast<const float*>(ws), dw, n, pl.splits, beta);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(cdiv((long)n, 256)), dim3(256), 0, st,
+                               reinterpret_cast<const float*>(ws), dw, n, pl.splits, beta);
         SSCG_LAUNCH_CHECK();
     }
     return SSCG_OK;
