@@ -111,8 +111,15 @@ class semisuper_cycleGAN(object):
         lab_gt = F.softmax2d(lab_gt)                                                 # :401
         fake_gt = F.softmax2d(fake_gt)                                               # :402
         recon_img = self.interp(self.Gis(fake_gt))                                   # :408,413
-        with torch.no_grad():
-            self.Gis(lab_gt.detach())      # :409 - output unused by the reference, but it advances Gis' BN running stats
+        # :409 - output unused by the reference, but it advances Gis' BN running stats (after those of the :408 pass
+        # above, which the side stream waits for).  Nothing reads the result: it runs beside the critical path and is
+        # joined before the optimiser touches Gis' weights.
+        lab_det = lab_gt.detach()
+
+        def unused_pass():
+            with torch.no_grad():
+                self.Gis(lab_det)
+        F.run_on_side_stream(l_img.device, (lab_det,), unused_pass)
         recon_gt = self.interp(self.Gsi(fake_img))                                   # :410,415
         fake_img_dis = self.Di(fake_img)                                             # :431
         resnet_fake_img_dis = self.old_Di(recon_img)                                 # :432
