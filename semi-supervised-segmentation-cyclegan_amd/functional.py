@@ -11,6 +11,8 @@ what every kernel assumes.  There is no fallback: a non-HIP tensor raises.
 """
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -77,6 +79,29 @@ class SideStream:
         for dev, s in cls._streams.items():
             if device is None or dev == device:
                 torch.cuda.current_stream(dev).wait_stream(s)
+
+
+class ForkStream:
+    """A third HIP stream: the second lane of the forked generator forwards (model.semisuper_cycleGAN.step).  The
+    step's five trainable DeepLab passes form two independent chains, Gis(onehot) -> Gsi(fake_img) and
+    Gsi(unl) -> Gis(fake_gt), plus Gsi(l_img); autograd replays each op's backward on the stream of its forward, so
+    forking the forward also runs the two backward chains side by side."""
+
+    _streams = {}
+
+    @classmethod
+    def get(cls, device, lane=0):
+        s = cls._streams.get((device, lane))
+        if s is None:
+            s = torch.cuda.Stream(device=device)
+            cls._streams[(device, lane)] = s
+        return s
+
+    @classmethod
+    def join(cls, device):
+        for (dev, _), s in cls._streams.items():
+            if dev == device:
+                torch.cuda.current_stream(device).wait_stream(s)
 
 
 def run_on_side_stream(device, tensors, fn):
@@ -437,9 +462,28 @@ def bump_weight_epoch():
 
 
 
+_WT_USERS = {}      # id -> weakref of the weights whose transposed copy a backward pass has asked for
+
+
+def refresh_transposed_weights(weights=()):
+    """Bring the cached transposed copies of `weights` (and of every weight a backward pass has asked for) up to
+    date on the CURRENT stream.  The step calls this before it forks its forward passes over two streams: their
+    backward passes then only read the cache (a lazily rebuilt copy would be written on one stream and read on
+    the other)."""
+    for w in weights:
+        _cached_wt(w)
+    for r in list(_WT_USERS.values()):
+        w = r()
+        if w is not None:
+            _cached_wt(w)
+
+
 def _cached_wt(w):
     """Transposed copy of a weight, cached ON the tensor object (dies with it; a recycled address can never
     alias).  Valid while neither torch (`_version`) nor our optimiser (`_WEIGHT_EPOCH`) has rewritten it."""
+    if id(w) not in _WT_USERS:
+        key = id(w)
+        _WT_USERS[key] = weakref.ref(w, lambda _r, key=key: _WT_USERS.pop(key, None))
     tag = (w._version, _WEIGHT_EPOCH[0], w.data_ptr())
     ent = getattr(w, "_sscg_wt", None)
     if ent is None or ent[0] != tag:

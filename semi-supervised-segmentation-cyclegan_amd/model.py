@@ -53,6 +53,7 @@ class semisuper_cycleGAN(object):
         self.crop = (args.crop_height, args.crop_width)             # nn.Upsample(..., align_corners=True), model.py:268
         self.running_metrics_val = utils.runningScore(C, args.dataset)
         self.as_written = getattr(args, "as_written", True)         # keep the reference's unused forwards
+        self.fork_forward = getattr(args, "fork_forward", True)     # two stream lanes for the trainable generator passes
         self.dp = data_parallel
 
         self.g_optimizer = FusedAdam(itertools.chain(self.Gis.parameters(), self.Gsi.parameters()), lr=args.lr, betas=(0.5, 0.999))
@@ -104,12 +105,32 @@ class semisuper_cycleGAN(object):
                     self.old_Gis(F.softmax2d(self.old_Gsi(l_img)))
             return recon
         resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch)
-        fake_img = self.interp(self.Gis(onehot_gt))                                  # :385,390
+        dev = l_img.device
+        fork = F.SideStream.enabled and self.fork_forward
+        if fork:
+            # Two lanes: Gis(onehot) -> Gsi(fake_img) on the fork stream, Gsi(unl) -> Gsi(l_img) -> Gis(fake_gt) here.
+            # The reference's order of BN running-stat updates (Gis: :385 before :408; Gsi: :386, :387 before :410) is kept
+            # with two events; autograd runs every backward op on its forward's stream, so the backward chains fork too.
+            F.refresh_transposed_weights(p for net in (self.Gis, self.Gsi) for p in net.parameters() if p.dim() == 4)
+            main, lane = torch.cuda.current_stream(dev), F.ForkStream.get(dev)
+            lane.wait_stream(main)
+            with torch.cuda.stream(lane):
+                fake_img = self.interp(self.Gis(onehot_gt))                          # :385,390
+                gis_first = torch.cuda.Event()
+                gis_first.record(lane)
+            onehot_gt.record_stream(lane)
+        else:
+            fake_img = self.interp(self.Gis(onehot_gt))                              # :385,390
         fake_gt = self.interp(self.Gsi(unl_img))                                     # :386,391
         lab_gt = self.interp(self.Gsi(l_img))                                        # :387,392
+        if fork:
+            gsi_second = torch.cuda.Event()
+            gsi_second.record(main)
         lab_loss_CE = F.cross_entropy(lab_gt, labels)                                # :398
         lab_gt = F.softmax2d(lab_gt)                                                 # :401
         fake_gt = F.softmax2d(fake_gt)                                               # :402
+        if fork:
+            main.wait_event(gis_first)
         recon_img = self.interp(self.Gis(fake_gt))                                   # :408,413
         # :409 - output unused by the reference, but it advances Gis' BN running stats (after those of the :408 pass
         # above, which the side stream waits for).  Nothing reads the result: it runs beside the critical path and is
@@ -120,7 +141,15 @@ class semisuper_cycleGAN(object):
             with torch.no_grad():
                 self.Gis(lab_det)
         F.run_on_side_stream(l_img.device, (lab_det,), unused_pass)
-        recon_gt = self.interp(self.Gsi(fake_img))                                   # :410,415
+        if fork:
+            with torch.cuda.stream(lane):
+                lane.wait_event(gsi_second)
+                recon_gt = self.interp(self.Gsi(fake_img))                           # :410,415
+            main.wait_stream(lane)
+            fake_img.record_stream(main)
+            recon_gt.record_stream(main)
+        else:
+            recon_gt = self.interp(self.Gsi(fake_img))                               # :410,415
         fake_img_dis = self.Di(fake_img)                                             # :431
         resnet_fake_img_dis = self.old_Di(recon_img)                                 # :432
         fake_gt_onehot, _ = F.argmax_onehot(fake_gt.detach())                        # :435-437 (no gradient path)
@@ -135,6 +164,7 @@ class semisuper_cycleGAN(object):
             [lab_loss_CE, lab_loss_MSE, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss],
             [a.lab_CE_weight, a.lab_MSE_weight, a.adversarial_weight, a.adversarial_weight, 1.0, a.lamda_gt])
         gen_loss.backward()                                                          # :472
+        F.ForkStream.join(l_img.device)
         F.SideStream.join(l_img.device)            # side stream: weight gradients + frozen generators are complete
         resnet_recon_img.record_stream(torch.cuda.current_stream(l_img.device))
         g_works = None
