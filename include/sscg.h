@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 2
+#define SSCG_ABI_VERSION 3
 
 #define SSCG_ERR_BAD_ARG (-1)
 #define SSCG_ERR_UNSUPPORTED (-2)
@@ -135,6 +135,10 @@ int sscg_softmax_bwd(const float* dy, const float* y, float* dx, int64_t rows, i
 int sscg_argmax_onehot(const float* x, float* onehot, int64_t* index, int64_t rows, int C, void* stream);
 /* make_one_hot(labels) (utils.py:314-350) */
 int sscg_label_onehot(const int64_t* labels, float* onehot, int64_t rows, int C, void* stream);
+/* runningScore._fast_hist (utils.py:363-369) of the per-epoch evaluation (model.py:555-574):
+ * hist[C*t + p] += 1 for every pixel with 0 <= t < C (others, e.g. the 255 "void" label, are ignored).
+ * `hist` is int64 [C][C] on the device and is accumulated into; C <= 64. */
+int sscg_confusion_hist(const int64_t* label_true, const int64_t* label_pred, int64_t n, int C, int64_t* hist, void* stream);
 
 /* ------------------------------------------------------------------ losses (K10, K11), mean reduction
  * Each forward writes one fp32 scalar to `loss` (device).  Each backward takes the upstream gradient as

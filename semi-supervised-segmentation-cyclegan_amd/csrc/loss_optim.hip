@@ -217,6 +217,36 @@ extern "C" int sscg_label_onehot(const int64_t* labels, float* onehot, int64_t r
     return SSCG_OK;
 }
 
+// Confusion matrix of the evaluation pass: per-block LDS histogram (int32), then integer atomics into the global
+// int64 matrix - integer sums are order independent, so this is bit-exact against np.bincount.
+__global__ __launch_bounds__(256) void confusion_hist_kernel(const int64_t* __restrict__ lt, const int64_t* __restrict__ lp,
+                                                              int64_t n, int C, unsigned long long* __restrict__ hist) {
+    extern __shared__ unsigned int bins[];
+    const int nb = C * C;
+    for (int i = threadIdx.x; i < nb; i += 256) bins[i] = 0u;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = lt[i];
+        const int64_t q = lp[i];
+        if (t >= 0 && t < C && q >= 0 && q < C) atomicAdd(&bins[(int)t * C + (int)q], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += 256)
+        if (bins[i]) atomicAdd(&hist[i], (unsigned long long)bins[i]);
+}
+
+extern "C" int sscg_confusion_hist(const int64_t* label_true, const int64_t* label_pred, int64_t n, int C, int64_t* hist,
+                                   void* stream) {
+    if (!label_true || !label_pred || !hist || n < 0 || C <= 0 || C > 64) return SSCG_ERR_BAD_ARG;
+    if (n == 0) return SSCG_OK;
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);   // ~16 pixels per thread: few global atomics
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(confusion_hist_kernel, dim3((unsigned)blocks), dim3(256), (size_t)C * C * sizeof(unsigned int),
+                       (hipStream_t)stream, label_true, label_pred, n, C, reinterpret_cast<unsigned long long*>(hist));
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
 extern "C" size_t sscg_loss_workspace(int64_t n) {
     (void)n;
     return (size_t)LOSS_BLOCKS * sizeof(double);

@@ -428,6 +428,22 @@ def argmax_index(x):
     return idx
 
 
+def confusion_hist(label_true, label_pred, num_classes, hist=None):
+    """hist[C*t + p] += 1 over the pixels with 0 <= t < C (utils.py:363-369); `hist` int64 [C, C] on the device."""
+    if not (label_true.is_cuda and label_pred.is_cuda):
+        raise _lib.SscgError("sscg kernels run on the MI355X only: got a %s tensor (no CPU fallback)" % label_true.device)
+    lt = label_true.to(torch.int64).contiguous()
+    lp = label_pred.to(torch.int64).contiguous()
+    if lt.numel() != lp.numel():
+        raise _lib.SscgError("confusion_hist: label/prediction sizes differ")
+    if hist is None:
+        hist = torch.empty((num_classes, num_classes), dtype=torch.int64, device=lt.device)
+        check(lib.sscg_fill(hist.data_ptr(), 2 * hist.numel(), 0.0, _stream()), "sscg_fill")   # 2 fp32 zeros per int64 zero
+    check(lib.sscg_confusion_hist(lt.data_ptr(), lp.data_ptr(), lt.numel(), num_classes, hist.data_ptr(), _stream()),
+          "sscg_confusion_hist")
+    return hist
+
+
 def label_onehot(labels, num_classes):
     """utils.make_one_hot (utils.py:314-350): labels int64 [N,1,H,W] -> fp32 one-hot [N,C,H,W] (NHWC memory)."""
     if not labels.is_cuda or labels.dtype != torch.int64:

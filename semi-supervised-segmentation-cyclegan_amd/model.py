@@ -216,8 +216,7 @@ class semisuper_cycleGAN(object):
         for val_img, val_gt, _ in val_loader:
             val_img, val_gt = utils.cuda([val_img, val_gt], self.args.gpu_ids)
             outputs = F.softmax2d(self.interp(self.Gsi(val_img)))
-            pred = F.argmax_index(outputs).cpu().numpy()
-            self.running_metrics_val.update(val_gt.squeeze(1).cpu().numpy(), pred)
+            self.running_metrics_val.update_device(val_gt.squeeze(1), F.argmax_index(outputs))   # :566-569 without the host round trip
         score, class_iou = self.running_metrics_val.get_scores()
         self.Gsi.train()
         self.Gis.train()

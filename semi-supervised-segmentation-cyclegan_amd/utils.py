@@ -68,6 +68,17 @@ class runningScore(object):
     def __init__(self, n_classes, dataset):
         self.n_classes, self.dataset = n_classes, dataset
         self.confusion_matrix = np.zeros((n_classes, n_classes))
+        self._device_hist = None     # int64 [C, C] accumulated by sscg_confusion_hist; folded in by get_scores()
+
+    def update_device(self, label_trues, label_preds):
+        """Same counts as update(), for label / prediction tensors that already live on the MI355X: no
+        device->host copy of the maps per batch (model.py:568-569 moves both to numpy)."""
+        self._device_hist = F.confusion_hist(label_trues, label_preds, self.n_classes, self._device_hist)
+
+    def _fold_device(self):
+        if self._device_hist is not None:
+            self.confusion_matrix += self._device_hist.cpu().numpy().astype(np.float64)
+            self._device_hist = None
 
     def update(self, label_trues, label_preds):
         n = self.n_classes
@@ -77,6 +88,7 @@ class runningScore(object):
             self.confusion_matrix += np.bincount(n * lt[keep].astype(int) + lp[keep], minlength=n * n).reshape(n, n)
 
     def get_scores(self):
+        self._fold_device()
         h, n = self.confusion_matrix, self.n_classes
         with np.errstate(divide="ignore", invalid="ignore"):
             acc = np.diag(h).sum() / h.sum()
@@ -88,6 +100,7 @@ class runningScore(object):
 
     def reset(self):
         self.confusion_matrix = np.zeros((self.n_classes, self.n_classes))
+        self._device_hist = None
 
 
 def save_checkpoint(state, save_path):

@@ -1,8 +1,11 @@
 """Kernel-level parity: every HIP kernel (through the C ABI) against the torch CPU op the reference
 calls at that site, evaluated in fp64.  Tolerances are relative to the largest reference magnitude."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as TF
+
+from conftest import load_sub
 
 pytestmark = pytest.mark.gpu
 
@@ -340,3 +343,33 @@ def test_layout_roundtrip_and_dropout(F, dev):
     assert set(d1.unique().cpu().tolist()) == {0.0, 2.0}
     rp = F.reflect_pad(y, 3)
     assert torch.equal(rp.cpu().contiguous(), TF.pad(x.cpu(), (3, 3, 3, 3), mode="reflect"))
+
+
+@pytest.mark.parametrize("C", [21, 20, 4, 1])
+def test_confusion_hist_bit_exact(C, F, dev):
+    """runningScore._fast_hist (utils.py:363-369): integer counts, void (255) and negative labels ignored."""
+    g = torch.Generator().manual_seed(C)
+    n = 3 * 65 * 67
+    lt = torch.randint(0, C, (n,), generator=g, dtype=torch.int64)
+    lt[torch.rand(n, generator=g) < 0.05] = 255
+    lt[torch.rand(n, generator=g) < 0.01] = -1
+    lp = torch.randint(0, C, (n,), generator=g, dtype=torch.int64)
+    keep = (lt >= 0) & (lt < C)
+    ref = np.bincount((C * lt[keep] + lp[keep]).numpy(), minlength=C * C).reshape(C, C)
+    h = F.confusion_hist(lt.to(dev), lp.to(dev), C)
+    h = F.confusion_hist(lt.to(dev), lp.to(dev), C, h)          # accumulates
+    assert np.array_equal(h.cpu().numpy(), 2 * ref)
+
+
+def test_running_score_device_matches_host(F, dev):
+    utils = load_sub("utils")
+    g = torch.Generator().manual_seed(3)
+    host, devs = utils.runningScore(21, "voc2012"), utils.runningScore(21, "voc2012")
+    for _ in range(3):
+        lt = torch.randint(0, 21, (2, 33, 35), generator=g, dtype=torch.int64)
+        lt[0, :4] = 255
+        lp = torch.randint(0, 21, (2, 33, 35), generator=g, dtype=torch.int64)
+        host.update(lt.numpy(), lp.numpy())
+        devs.update_device(lt.to(dev), lp.to(dev))
+    (s0, c0), (s1, c1) = host.get_scores(), devs.get_scores()
+    assert s0 == s1 and c0 == c1
