@@ -36,6 +36,10 @@ constexpr int LDK = BK + 4;
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
+// XOR swizzle of the 16-byte slot inside a row of the LDS-DMA image: 16 consecutive rows must put one fragment slot into
+// 16 different bank quads (128-byte rows: two rows share the 64 banks; 256-byte rows: one row spans them)
+__device__ __forceinline__ int dma_swizzle(int row) { return BK == 32 ? ((row >> 1) & 7) : (row & (BK / 4 - 1)); }
+
 struct KcParams {
     const float* __restrict__ src;   // A source (input for fwd, dy for dgrad)
     const float* __restrict__ wgt;   // [Ng][Ktot]
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
 
     const int r0 = tid / KQ;
     // k slot this thread stages: identity, or (DMA) the slot whose data must land at LDS slot tid%8 of row r0
-    const int kq = DMA ? ((tid % KQ) ^ ((r0 >> 1) & 7)) : (tid % KQ);
+    const int kq = DMA ? ((tid % KQ) ^ dma_swizzle(r0)) : (tid % KQ);
     const int wave_id = tid >> 6;
 
     // ---- per-thread loader state (decoded once)
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
         const int buf = NBUF == 2 ? (kt & 1) : 0;
         const float* a = As + buf * BM * LDR + (row_w + li) * LDR + (DMA ? 0 : lh * 4);
         const float* b = Bs + buf * BN * LDR + (col_w + li) * LDR + (DMA ? 0 : lh * 4);
-        const int swz = (li >> 1) & 7;    // DMA image: 16-B slot c of a row lives at slot c ^ swz
+        const int swz = dma_swizzle(li);  // DMA image: 16-B slot c of a row lives at slot c ^ swz
         auto koff = [&](int kk) { return DMA ? (((kk * 2 + lh) ^ swz) * 4) : kk * 8; };
         f32x4 fa[2][TM], fb[2][TN];
         // fragments of the first k-group are requested right after the barrier ...
@@ -460,7 +464,7 @@ static int kc_choose_cfg(int M, int Ng, int Ktot, int Cs) {
     const bool fast = Cs % BK == 0;
     if (Ng <= 32) return 4;
     const long w128 = (long)cdiv(M, 128) * cdiv(Ng, 128);
-    if (w128 >= 512 && Ktot >= 1024) return fast ? 7 : 0;   // long reductions amortise the big tile's prologue
+    if (w128 >= 512 && Ktot >= 1024 && Ng > 64) return fast ? 7 : 0;   // long reductions amortise the big tile's prologue (and N fills it)
     return fast ? 6 : 3;
 }
 

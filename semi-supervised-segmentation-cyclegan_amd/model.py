@@ -172,6 +172,8 @@ class semisuper_cycleGAN(object):
             g_works = self.dp.sync_grads_async(self.g_optimizer)     # overlaps the D step; the update is applied below
         else:
             self.g_optimizer.step()                                                  # :474
+            # the transposed weight copies the next step's data gradients read: rebuilt beside the discriminator step
+            F.run_on_side_stream(l_img.device, (), F.refresh_transposed_weights)
 
         # ---- discriminators (model.py:477-542)
         set_grad([self.Di, self.Ds], True)

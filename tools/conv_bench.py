@@ -14,6 +14,10 @@ CL = torch.channels_last
 
 # N, C, H, W, K, R, stride, pad, dil
 SHAPES = [
+    (8, 21, 256, 256, 64, 7, 1, 3, 1),
+    (8, 64, 256, 256, 21, 7, 1, 3, 1),
+    (8, 64, 256, 256, 3, 7, 1, 3, 1),
+    (8, 21, 256, 256, 64, 7, 2, 3, 1),
     (8, 256, 33, 33, 256, 3, 1, 2, 2),
     (8, 512, 33, 33, 512, 3, 1, 4, 4),
     (8, 256, 33, 33, 1024, 1, 1, 0, 1),
