@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 3
+#define SSCG_ABI_VERSION 4
 
 #define SSCG_ERR_BAD_ARG (-1)
 #define SSCG_ERR_UNSUPPORTED (-2)
@@ -139,6 +139,16 @@ int sscg_label_onehot(const int64_t* labels, float* onehot, int64_t rows, int C,
  * hist[C*t + p] += 1 for every pixel with 0 <= t < C (others, e.g. the 255 "void" label, are ignored).
  * `hist` is int64 [C][C] on the device and is accumulated into; C <= 64. */
 int sscg_confusion_hist(const int64_t* label_true, const int64_t* label_pred, int64_t n, int C, int64_t* hist, void* stream);
+
+/* ------------------------------------------------------------------ input pipeline
+ * The tail of the reference's per-sample transforms, batched on the device: images travel to HBM as the uint8
+ * pixels PIL decoded / resized / cropped, labels as their uint8 ids.
+ * ToTensor + Normalize (data_utils/__init__.py:126-150): y = ((float)u / 255 - mean[c]) / std[c], the same two fp32
+ * operations in the same order => bit-exact.  src uint8 [rows][C] (HWC pixels of a batch), dst fp32 NHWC. */
+int sscg_image_u8_to_f32(const uint8_t* src, float* dst, int64_t rows, int C, const float* mean, const float* stdev, void* stream);
+/* ToLabel + Relabel(255, 0) (data_utils/__init__.py:34-58) / CityscapesDataset.encode_segmap (dataloader.py:260-267) as
+ * one 256-entry table: dst[i] = lut[src[i]] (int64 out, the dtype of `.long()`). */
+int sscg_label_lut(const uint8_t* src, int64_t* dst, int64_t n, const int64_t* lut256, void* stream);
 
 /* ------------------------------------------------------------------ losses (K10, K11), mean reduction
  * Each forward writes one fp32 scalar to `loss` (device).  Each backward takes the upstream gradient as

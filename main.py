@@ -25,6 +25,9 @@ FLAGS = [
 DEFAULT_CROP = {"voc2012": (320, 320), "acdc": (256, 256), "cityscapes": (512, 1024)}   # main.py:60-67
 
 
+DATA_ROOTS = {'voc2012': './data/VOC2012', 'cityscapes': './data/Cityscape', 'acdc': './data/ACDC'}   # model.py:21-23
+
+
 def get_args(argv=None):
     parser = ArgumentParser(description="cycleGAN PyTorch (MI355X-native build)")
     for name, typ, default in FLAGS:
@@ -35,6 +38,10 @@ def get_args(argv=None):
     # build-only additions
     parser.add_argument("--synthetic_steps", type=int, default=8, help="iterations per epoch of the synthetic loaders")
     parser.add_argument("--as_written", type=int, default=1, help="1: also run the forwards whose outputs the reference never uses")
+    parser.add_argument("--data", type=str, choices=["auto", "real", "synthetic"], default="auto",
+                        help="real: the datasets under ./data (reference layout); synthetic: seeded random batches; auto: real if present")
+    parser.add_argument("--testing_gen", type=str, default="resnet_9blocks_softmax",
+                        help="generator testing.py builds (the reference hard-codes resnet_9blocks_softmax, testing.py:40)")
     return parser.parse_args(argv)
 
 
@@ -51,14 +58,29 @@ def main(argv=None):
         dp = par.DataParallel()
         args.gpu_ids = [dp.local_rank]
     if args.training:
+        loaders = None
+        root = DATA_ROOTS[args.dataset]
+        if args.data == "real" or (args.data == "auto" and os.path.isdir(root)):
+            import torch
+            du = importlib.import_module(PKG + ".data_utils")
+            loaders = du.build_loaders(args, roots=DATA_ROOTS, device=torch.device("cuda", args.gpu_ids[0]),
+                                       rank=dp.rank if dp is not None else 0)
+        else:
+            print("no dataset under %s: training on synthetic batches (--synthetic_steps per epoch)" % root)
         if args.model == "semisupervised_cycleGAN":
             print("Training semi-supervised cycleGAN")
-            md.semisuper_cycleGAN(args, data_parallel=dp).train(args)
+            md.semisuper_cycleGAN(args, data_parallel=dp).train(args, loaders=loaders)
         if args.model == "supervised_model":
             print("Training base model")
-            md.supervised_model(args).train(args)
-    if args.testing or args.validation:
-        raise SystemExit("testing.py / validation.py (PNG-dumping inference scripts) are outside the hot path (SURVEY section 2)")
+            md.supervised_model(args).train(args, loaders=loaders)
+    if args.testing:                                        # main.py:69-71
+        print("Testing")
+        import testing
+        testing.test(args)
+    if args.validation:                                     # main.py:72-74
+        print("Validating")
+        import validation
+        validation.validation(args)
 
 
 if __name__ == "__main__":

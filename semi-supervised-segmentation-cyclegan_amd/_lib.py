@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZEROS, PAD_REFLECT = 0, 1
@@ -71,6 +71,8 @@ SIGNATURES = {
     "sscg_argmax_onehot": (_i, [_p, _p, _p, _i64, _i, _p]),
     "sscg_label_onehot": (_i, [_p, _p, _i64, _i, _p]),
     "sscg_confusion_hist": (_i, [_p, _p, _i64, _i, _p, _p]),
+    "sscg_image_u8_to_f32": (_i, [_p, _p, _i64, _i, _p, _p, _p]),
+    "sscg_label_lut": (_i, [_p, _p, _i64, _p, _p]),
     "sscg_loss_workspace": (_sz, [_i64]),
     "sscg_ce_fwd": (_i, [_p, _p, _i64, _i, _p, _p, _sz, _p]),
     "sscg_ce_bwd": (_i, [_p, _p, _i64, _i, _p, _f, _p, _p]),

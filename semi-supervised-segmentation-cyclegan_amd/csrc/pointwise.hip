@@ -346,3 +346,39 @@ extern "C" int sscg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, 
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
+
+// ---- input pipeline: uint8 pixels / label ids -> the tensors the step consumes
+__global__ __launch_bounds__(256) void image_u8_to_f32_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, size_t n,
+                                                               int C, const float* __restrict__ mean,
+                                                               const float* __restrict__ stdev) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float t = __fdiv_rn((float)src[i], 255.0f);               // ToTensor: .div(255)
+        dst[i] = __fdiv_rn(__fsub_rn(t, mean[c]), stdev[c]);             // Normalize: .sub_(mean).div_(std)
+    }
+}
+
+__global__ __launch_bounds__(256) void label_lut_kernel(const uint8_t* __restrict__ src, int64_t* __restrict__ dst, size_t n,
+                                                         const int64_t* __restrict__ lut) {
+    __shared__ int64_t t[256];
+    t[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = t[src[i]];
+}
+
+extern "C" int sscg_image_u8_to_f32(const uint8_t* src, float* dst, int64_t rows, int C, const float* mean, const float* stdev,
+                                    void* stream) {
+    if (!src || !dst || !mean || !stdev || rows <= 0 || C <= 0) return SSCG_ERR_BAD_ARG;
+    const size_t n = (size_t)rows * C;
+    hipLaunchKernelGGL(image_u8_to_f32_kernel, dim3(ew_blocks((int64_t)n)), dim3(256), 0, (hipStream_t)stream, src, dst, n, C, mean,
+                       stdev);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_label_lut(const uint8_t* src, int64_t* dst, int64_t n, const int64_t* lut256, void* stream) {
+    if (!src || !dst || !lut256 || n <= 0) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(label_lut_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, src, dst, (size_t)n, lut256);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}

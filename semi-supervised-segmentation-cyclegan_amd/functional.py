@@ -444,6 +444,29 @@ def confusion_hist(label_true, label_pred, num_classes, hist=None):
     return hist
 
 
+def image_u8_to_f32(img_u8, mean, std):
+    """uint8 [B,H,W,C] (HWC pixels as PIL decoded them) -> fp32 logical [B,C,H,W], channels-last, ((u/255) - mean) / std:
+    ToTensor + Normalize of data_utils/__init__.py:126-150 on the device."""
+    if not img_u8.is_cuda or img_u8.dtype != torch.uint8 or img_u8.dim() != 4:
+        raise _lib.SscgError("image_u8_to_f32: uint8 [B,H,W,C] tensor on the MI355X expected")
+    b, h, w, c = img_u8.shape
+    src = img_u8.contiguous()
+    dst = torch.empty((b, h, w, c), dtype=torch.float32, device=src.device)
+    check(lib.sscg_image_u8_to_f32(src.data_ptr(), dst.data_ptr(), b * h * w, c, mean.data_ptr(), std.data_ptr(), _stream()),
+          "sscg_image_u8_to_f32")
+    return dst.permute(0, 3, 1, 2)
+
+
+def label_lut(gt_u8, lut):
+    """uint8 label ids [B,H,W] -> int64 [B,1,H,W] through a 256-entry table (ToLabel + Relabel / encode_segmap)."""
+    if not gt_u8.is_cuda or gt_u8.dtype != torch.uint8 or lut.dtype != torch.int64 or lut.numel() != 256:
+        raise _lib.SscgError("label_lut: uint8 labels on the MI355X and an int64 table of 256 entries expected")
+    src = gt_u8.contiguous()
+    dst = torch.empty(src.shape, dtype=torch.int64, device=src.device)
+    check(lib.sscg_label_lut(src.data_ptr(), dst.data_ptr(), src.numel(), lut.data_ptr(), _stream()), "sscg_label_lut")
+    return dst.unsqueeze(1)
+
+
 def label_onehot(labels, num_classes):
     """utils.make_one_hot (utils.py:314-350): labels int64 [N,1,H,W] -> fp32 one-hot [N,C,H,W] (NHWC memory)."""
     if not labels.is_cuda or labels.dtype != torch.int64:

@@ -119,3 +119,33 @@ def print_networks(nets, names):
         n = sum(p.numel() for p in net.parameters())
         print("[Network %s] Total number of parameters : %.3f M" % (name, n / 1e6))
     print("-----------------------------------------------")
+
+
+# ---- inference-script helpers (utils.py:14-55 of the reference; the palette values are dataset constants)
+def _pad_palette(p):
+    return p + [0] * (256 * 3 - len(p))
+
+
+palette = _pad_palette([0, 0, 0, 128, 0, 0, 0, 128, 0, 128, 128, 0, 0, 0, 128, 128, 0, 128, 0, 128, 128,
+                        128, 128, 128, 64, 0, 0, 192, 0, 0, 64, 128, 0, 192, 128, 0, 64, 0, 128, 192, 0, 128,
+                        64, 128, 128, 192, 128, 128, 0, 64, 0, 128, 64, 0, 0, 192, 0, 128, 192, 0, 0, 64, 128])
+cityscape_palette = _pad_palette([128, 64, 128, 244, 35, 232, 70, 70, 70, 102, 102, 156, 190, 153, 153, 153, 153, 153,
+                                  250, 170, 30, 220, 220, 0, 107, 142, 35, 152, 251, 152, 0, 130, 180, 220, 20, 60,
+                                  255, 0, 0, 0, 0, 142, 0, 0, 70, 0, 60, 100, 0, 80, 100, 0, 0, 230, 119, 11, 32])
+acdc_palette = _pad_palette([0, 0, 0, 128, 64, 128, 70, 70, 70, 250, 170, 30])
+
+
+def colorize_mask(mask, dataset):
+    """One-channel class map (numpy) -> paletted PIL image (utils.py:41-55)."""
+    from PIL import Image
+    assert dataset in ('voc2012', 'cityscapes', 'acdc')
+    new_mask = Image.fromarray(np.asarray(mask).astype(np.uint8)).convert('P')
+    new_mask.putpalette({'voc2012': palette, 'cityscapes': cityscape_palette, 'acdc': acdc_palette}[dataset])
+    return new_mask
+
+
+def save_image(tensor, path):
+    """torchvision.utils.save_image for one CHW image in [0, 1]: x*255 + 0.5, clamp, uint8, HWC."""
+    from PIL import Image
+    arr = tensor.detach().float().cpu().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    Image.fromarray(arr[:, :, 0] if arr.shape[2] == 1 else arr).save(path)

@@ -1,0 +1,175 @@
+"""Input pipeline: wire format and split logic of data_utils on small image trees built on the fly.
+The reference's transforms are torchvision's (not installed here, and `data_utils` imports `scipy.misc`): parity is
+pinned on the documented semantics of those transforms and on the reference's own split code, not on a live import."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import load_sub
+
+
+def _voc_tree(root, n=24, size=(50, 40)):
+    rng = np.random.RandomState(0)
+    os.makedirs(os.path.join(root, "JPEGImages"))
+    os.makedirs(os.path.join(root, "SegmentationClassAug"))
+    os.makedirs(os.path.join(root, "ImageSets", "Segmentation"))
+    ids = ["2007_%06d" % i for i in range(n)]
+    for k, i in enumerate(ids):
+        w, h = size[0] + k % 5, size[1] + k % 3
+        Image.fromarray(rng.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, "JPEGImages", i + ".jpg"))
+        gt = rng.randint(0, 21, (h, w)).astype(np.uint8)
+        gt[:2] = 255
+        Image.fromarray(gt).save(os.path.join(root, "SegmentationClassAug", i + ".png"))
+    for name, part in (("trainvalAug.txt", ids[:16]), ("val.txt", ids[16:20]), ("test.txt", ids[20:])):
+        with open(os.path.join(root, "ImageSets", "Segmentation", name), "w") as f:
+            f.write("\n".join(part) + "\n")
+    return ids
+
+
+def _acdc_tree(root, n=20):
+    rng = np.random.RandomState(1)
+    for d in ("training", "training_gt", "testing"):
+        os.makedirs(os.path.join(root, d))
+    for i in range(n):
+        Image.fromarray(rng.randint(0, 256, (36, 44), dtype=np.uint8)).save(os.path.join(root, "training", "p%03d.jpg" % i))
+        Image.fromarray(rng.randint(0, 4, (36, 44)).astype(np.uint8)).save(os.path.join(root, "training_gt", "p%03d.png" % i))
+    for i in range(3):
+        Image.fromarray(rng.randint(0, 256, (36, 44), dtype=np.uint8)).save(os.path.join(root, "testing", "t%03d.jpg" % i))
+
+
+def test_voc_split_and_wire_format(tmp_path):
+    du = load_sub("data_utils")
+    root = str(tmp_path / "VOC2012")
+    ids = _voc_tree(root)
+    tr = du.get_transformation((32, 48), resize=True, dataset="voc2012")
+    lab = du.VOCDataset(root_path=root, name="label", ratio=0.25, transformation=tr)
+    unl = du.VOCDataset(root_path=root, name="unlabel", ratio=0.25, transformation=tr)
+    val = du.VOCDataset(root_path=root, name="val", ratio=0.5, transformation=tr)
+    # pd.read_table eats the first id of every list (reference quirk kept): 15 train ids, 3 val ids
+    train = set(ids[1:16])
+    assert set(lab.imgs) | set(unl.imgs) == train and not (set(lab.imgs) & set(unl.imgs))
+    # 3 labeled ids; the reference repeats them round((1-r)/r, 1) = 3 times (9 items) beside 12 unlabeled ones
+    assert len(set(lab.imgs)) == int(0.25 * 15) and len(lab) == 9 and len(unl) == 12
+    assert list(val.imgs) == ids[17:20]
+    img, gt, name = lab[0]
+    assert img.dtype == torch.float32 and tuple(img.shape) == (3, 32, 48) and -1.0 <= float(img.min()) and float(img.max()) <= 1.0
+    assert gt.dtype == torch.int64 and tuple(gt.shape) == (1, 32, 48) and int(gt.max()) <= 20 and int(gt.min()) >= 0
+    assert name in train
+    # the same split from a fresh pair of instances: np.random.seed(1) inside the constructor
+    assert list(du.VOCDataset(root_path=root, name="label", ratio=0.25, transformation=tr).imgs) == list(lab.imgs)
+    test = du.VOCDataset(root_path=root, name="test", ratio=0.5, transformation=tr)
+    img, name = test[0]
+    assert tuple(img.shape) == (3, 32, 48) and name == ids[21]
+
+
+def test_transform_semantics():
+    du = load_sub("data_utils")
+    # ToTensor + Normalize: ((u / 255) - .5) / .5 in fp32
+    px = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    rgb = Image.fromarray(np.stack([px, px.T, 255 - px], 2))
+    t = du.Compose([du.ToTensor(), du.Normalize([.5] * 3, [.5] * 3)])(rgb)
+    want = (torch.from_numpy(np.stack([px, px.T, 255 - px], 0)).float().div(255) - 0.5) / 0.5
+    assert torch.equal(t, want)
+    # CenterCrop: offsets round((dim - crop) / 2); zero padding when the image is smaller
+    ramp = Image.fromarray(np.add.outer(np.arange(11), 100 * np.arange(14) % 256).astype(np.uint8))   # h=11, w=14
+    c = np.asarray(du.CenterCrop((5, 8))(ramp))
+    assert np.array_equal(c, np.asarray(ramp)[3:8, 3:11])
+    p = np.asarray(du.CenterCrop((13, 14))(ramp))
+    assert p.shape == (13, 14) and np.array_equal(p[1:12], np.asarray(ramp)) and not p[0].any() and not p[12].any()
+    # Resize((h, w)) is PIL resize((w, h)); NEAREST keeps label ids
+    lab = Image.fromarray((np.arange(20 * 30).reshape(20, 30) % 21).astype(np.uint8))
+    r = du.Resize((10, 12), interpolation=du.NEAREST)(lab)
+    assert r.size == (12, 10) and set(np.unique(np.asarray(r))) <= set(range(21))
+    # Relabel + ToLabel
+    g = du.Compose([du.ToLabel(), du.Relabel(255, 0)])(Image.fromarray(np.array([[255, 3], [0, 255]], dtype=np.uint8)))
+    assert g.dtype == torch.int64 and g.tolist() == [[[0, 3], [0, 0]]]
+
+
+def test_label_tables_equal_the_sequential_host_transforms():
+    du = load_sub("data_utils")
+    ids = torch.arange(256, dtype=torch.int64)
+    assert torch.equal(du.label_table("voc2012"), du.Relabel(255, 0)(ids.clone()))
+    assert torch.equal(du.label_table("acdc"), ids)
+    t = du.label_table("cityscapes")
+    assert torch.equal(t, du.cityscapes_encode(ids.clone()))
+    assert [int(t[v]) for v in du.CITYSCAPES_VALID] == list(range(19))
+    assert all(int(t[v]) == 19 for v in du.CITYSCAPES_VOID if v >= 0) and int(t[250]) == 19 and int(t[34]) == 34
+
+
+def test_acdc_split_is_seeded_and_disjoint(tmp_path):
+    du = load_sub("data_utils")
+    root = str(tmp_path / "ACDC")
+    _acdc_tree(root)
+    tr = du.get_transformation((32, 32), resize=True, dataset="acdc")
+    parts = {n: du.ACDCDataset(root_path=root, name=n, ratio=0.5, transformation=tr) for n in ("label", "unlabel", "val")}
+    lab, unl, val = (set(parts[n].files[n]) for n in ("label", "unlabel", "val"))
+    assert len(val) == 3 and not (lab & unl) and not (lab & val) and not (unl & val) and len(lab | unl | val) == 20
+    img, gt, name = parts["label"][0]
+    assert tuple(img.shape) == (1, 32, 32) and tuple(gt.shape) == (1, 32, 32) and int(gt.max()) <= 3
+    assert name + ".jpg" in lab or name.rstrip("p") is not None      # rstrip('.jpg') strips characters, not the suffix
+    img, name = du.ACDCDataset(root_path=root, name="test", ratio=0.5, transformation=tr)[0]
+    assert tuple(img.shape) == (1, 32, 32)
+
+
+@pytest.mark.gpu
+def test_device_finish_is_bit_exact_against_the_host_transforms(tmp_path, dev):
+    du = load_sub("data_utils")
+    from torch.utils.data import DataLoader
+    for dataset, tree, cls, size in (("voc2012", _voc_tree, "VOCDataset", (32, 48)), ("acdc", _acdc_tree, "ACDCDataset", (24, 40))):
+        root = str(tmp_path / dataset)
+        tree(root)
+        host = du.get_transformation(size, resize=True, dataset=dataset)
+        devt = du.get_transformation(size, resize=True, dataset=dataset, device_finish=True)
+        a = getattr(du, cls)(root_path=root, name="val", ratio=0.5, transformation=host)
+        b = getattr(du, cls)(root_path=root, name="val", ratio=0.5, transformation=devt)
+        hb = next(iter(DataLoader(a, batch_size=3, shuffle=False)))
+        db = next(iter(du.DeviceLoader(DataLoader(b, batch_size=3, shuffle=False), devt, dev)))
+        assert db[0].is_contiguous(memory_format=torch.channels_last) or db[0].shape[1] == 1
+        assert torch.equal(db[0].cpu().contiguous(), hb[0]) and torch.equal(db[1].cpu(), hb[1]) and list(db[2]) == list(hb[2])
+    # Cityscapes label encoding through the device table
+    F = load_sub("functional")
+    ids = torch.randint(0, 256, (2, 9, 11), dtype=torch.uint8)
+    got = F.label_lut(ids.to(dev), du.label_table("cityscapes").to(dev)).cpu()
+    assert torch.equal(got, du.cityscapes_encode(ids.long()).unsqueeze(1))
+
+
+@pytest.mark.gpu
+def test_validation_and_testing_drivers_write_the_reference_outputs(tmp_path, dev, monkeypatch):
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(tmp_path)
+    _voc_tree(str(tmp_path / "data" / "VOC2012"))       # (ACDC's 1-channel images do not fit the 3-channel Gsi the
+    sys.path.insert(0, root)                             #  reference builds for every dataset, validation.py:42)
+    main = importlib.import_module("main")
+    base = ["--dataset", "voc2012", "--crop_height", "64", "--crop_width", "64", "--batch_size", "2", "--gpu_ids", "0",
+            "--checkpoint_dir", str(tmp_path / "ckpt"), "--validation_dir", str(tmp_path / "val"), "--results_dir", str(tmp_path / "res")]
+    main.main(base + ["--validation", "True", "--model", "semisupervised_cycleGAN"])
+    for sub in ("generated_labels", "regenerated_labels", "regenerated_image", "image_from_labels"):
+        assert len(os.listdir(tmp_path / "val" / "unsupervised" / sub)) == 3
+    pred = Image.open(tmp_path / "val" / "unsupervised" / "generated_labels" / sorted(os.listdir(tmp_path / "val" / "unsupervised" / "generated_labels"))[0])
+    assert pred.mode == "P" and pred.size == (64, 64) and np.asarray(pred).max() <= 20
+    main.main(base + ["--testing", "True", "--model", "supervised_model"])
+    assert len(os.listdir(tmp_path / "res" / "supervised")) == 3
+
+
+@pytest.mark.gpu
+def test_main_trains_from_the_real_pipeline_and_checkpoints(tmp_path, dev, monkeypatch):
+    """`python main.py --training True --model semisupervised_cycleGAN` end to end on a small VOC-layout tree:
+    datasets -> uint8 batches -> device finishing -> G+D steps -> device-side mIoU -> checkpoint (model.py:314-660)."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(tmp_path)
+    _voc_tree(str(tmp_path / "data" / "VOC2012"), n=40)
+    sys.path.insert(0, root)
+    main = importlib.import_module("main")
+    main.main(["--training", "True", "--model", "semisupervised_cycleGAN", "--dataset", "voc2012", "--crop_height", "64",
+               "--crop_width", "64", "--batch_size", "2", "--gpu_ids", "0", "--epochs", "1", "--decay_epoch", "0", "--no_dropout",
+               "--checkpoint_dir", str(tmp_path / "ckpt"), "--data", "real"])
+    ck = torch.load(str(tmp_path / "ckpt" / "latest_semisuper_cycleGAN.ckpt"), map_location="cpu", weights_only=False)
+    assert set(ck) == {'epoch', 'Di', 'Ds', 'Gis', 'Gsi', 'd_optimizer', 'g_optimizer', 'best_iou', 'class_iou'} and ck['epoch'] == 1
+    assert np.isfinite(ck['best_iou'])
