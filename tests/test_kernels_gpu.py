@@ -373,3 +373,35 @@ def test_running_score_device_matches_host(F, dev):
         devs.update_device(lt.to(dev), lp.to(dev))
     (s0, c0), (s1, c1) = host.get_scores(), devs.get_scores()
     assert s0 == s1 and c0 == c1
+
+
+def _bench_shapes():
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_conv_shapes.txt")
+    out = []
+    for line in open(path):
+        m = re.match(r"(\d+)x(\d+)x(\d+) c(\d+) k(\d+) r(\d+) s(\d+) p(\d+) d(\d+)", line.strip())
+        if m:
+            out.append(tuple(int(v) for v in m.groups()))
+    return sorted(set(out))
+
+
+@pytest.mark.parametrize("shape", _bench_shapes(), ids=lambda s: "%dx%dx%d_c%d_k%d_r%d_s%d_p%d_d%d" % s)
+def test_conv_adjoint_identities_at_bench_size(shape, F, dev):
+    """Every convolution shape of the BASELINE step (VOC 256x256, batch 8; list recorded by bench.py) at FULL size:
+    <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)>.  Size-independent, ties the three kernels (and their split /
+    parity-class / tile plans at these sizes) to each other; the inner products are taken in fp64."""
+    N, H, W, C, K, R, s, p, d = shape
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    x = torch.randn(N, C, H, W, device=dev, generator=g).contiguous(memory_format=CL)
+    w = (torch.randn(K, C, R, R, device=dev, generator=g) * 0.05).contiguous(memory_format=CL)
+    y = F.conv2d_fwd(x, w, None, s, p, d)
+    dy = torch.randn(y.shape, device=dev, generator=g).contiguous(memory_format=CL)
+    dx = F.conv2d_dgrad(dy, F.weight_transposed(w), x.shape, w.shape, s, p, d)
+    dw = F.conv2d_wgrad(x, dy, w.shape, s, p, d)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    lhs, via_x, via_w = dot(y, dy), dot(x, dx), dot(w, dw)
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(lhs - via_x) <= 5e-8 * scale, (lhs, via_x, scale)      # fp32 noise ~1e-9 * scale; one wrong 64x64 tile ~3e-5 * scale
+    assert abs(lhs - via_w) <= 5e-8 * scale, (lhs, via_w, scale)
