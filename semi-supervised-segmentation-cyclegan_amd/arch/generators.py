@@ -57,10 +57,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        x, shortcut = F.split(x)           # the block input feeds conv1 and the shortcut: their gradients meet in sscg_add
         out = self.bn1(self.conv1(x), ACT_RELU)
         out = self.bn2(self.conv2(out), ACT_RELU)
         out = self.conv3(out)
-        res = x if self.downsample is None else self.downsample(x)
+        res = shortcut if self.downsample is None else self.downsample(shortcut)
         return self.bn3(out, ACT_RELU, 0.0, residual=res)
 
 
@@ -74,7 +75,8 @@ class Classifier_Module(nn.Module):
             [Conv2d(2048, num_classes, 3, 1, p, d, bias=True) for d, p in zip(dilation_series, padding_series)])
 
     def forward(self, x):
-        return F.AddFn.apply(self.conv2d_list[0](x), self.conv2d_list[1](x))
+        a, b = F.split(x)
+        return F.AddFn.apply(self.conv2d_list[0](a), self.conv2d_list[1](b))
 
 
 class ResNet(nn.Module):

@@ -317,6 +317,7 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         mods = list(self.res_block)
+        x, shortcut = F.split(x)
         h = mods[1](x, reflect=1)
         k = 2
         if isinstance(mods[k], Dropout):
@@ -324,7 +325,7 @@ class ResidualBlock(nn.Module):
             k += 1
         conv, norm = mods[k + 1], mods[k + 2]
         h = conv(h, reflect=1)
-        return norm(h, ACT_NONE, 0.0, residual=x)
+        return norm(h, ACT_NONE, 0.0, residual=shortcut)
 
 
 def set_grad(nets, requires_grad=False):

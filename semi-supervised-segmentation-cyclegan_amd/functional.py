@@ -718,6 +718,33 @@ class AddFn(torch.autograd.Function):
         return dy, dy
 
 
+class SplitFn(torch.autograd.Function):
+    """Explicit fan-out of an activation that two (or more) consumers read - a residual block's input, the generated
+    image that feeds a generator, a discriminator and the L1 loss.  Forward returns aliases; backward sums the
+    consumers' gradients with the HIP add kernel in a fixed order, instead of leaving the accumulation to autograd's
+    own (torch) add kernel."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        total = None
+        for g in grads:
+            if g is None:
+                continue
+            total = to_nhwc(g) if total is None else add(total, to_nhwc(g))
+        return total, None
+
+
+def split(x, n=2):
+    """n aliases of x whose gradients are summed by `sscg_add` (no-op outside a gradient-recording forward)."""
+    if n < 2 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return SplitFn.apply(x, n)
+
+
 class DropoutFn(torch.autograd.Function):
     """nn.Dropout(0.5) in training mode.  The keep-mask is a pure function of (seed, element index)."""
 

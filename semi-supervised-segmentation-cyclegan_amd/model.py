@@ -144,13 +144,15 @@ class semisuper_cycleGAN(object):
         if fork:
             with torch.cuda.stream(lane):
                 lane.wait_event(gsi_second)
+                fake_img, fake_img_d, fake_img_l1 = F.split(fake_img, 3)             # consumers: Gsi, Di, L1
                 recon_gt = self.interp(self.Gsi(fake_img))                           # :410,415
             main.wait_stream(lane)
             fake_img.record_stream(main)
             recon_gt.record_stream(main)
         else:
+            fake_img, fake_img_d, fake_img_l1 = F.split(fake_img, 3)                 # consumers: Gsi, Di, L1
             recon_gt = self.interp(self.Gsi(fake_img))                               # :410,415
-        fake_img_dis = self.Di(fake_img)                                             # :431
+        fake_img_dis = self.Di(fake_img_d)                                           # :431
         resnet_fake_img_dis = self.old_Di(recon_img)                                 # :432
         fake_gt_onehot, _ = F.argmax_onehot(fake_gt.detach())                        # :435-437 (no gradient path)
         fake_gt_dis = self.Ds(fake_gt_onehot)                                        # :438
@@ -158,7 +160,7 @@ class semisuper_cycleGAN(object):
         gt_gen_loss = F.mse_const(fake_gt_dis, 1.0)                                  # :446
         img_cycle_loss = F.mse_const(resnet_fake_img_dis, 1.0)                       # :452
         gt_cycle_loss = F.cross_entropy(recon_gt, labels)                            # :455
-        lab_loss_MSE = F.l1_loss(fake_img, l_img)                                    # :461
+        lab_loss_MSE = F.l1_loss(fake_img_l1, l_img)                                 # :461
         # :464-468  gen_loss = CE_w*CE + MSE_w*L1 + adv_w*(img_gen + gt_gen) + img_cycle + lamda_gt*gt_cycle
         gen_loss = F.weighted_sum(
             [lab_loss_CE, lab_loss_MSE, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss],
