@@ -11,6 +11,7 @@ what every kernel assumes.  There is no fallback: a non-HIP tensor raises.
 """
 import ctypes as C
 
+import os
 import weakref
 
 import torch
