@@ -88,8 +88,10 @@ int sscg_debug_set_wgrad_plan(int target_wgs, int min_iters);
  * L = H*W; BatchNorm2d (arch/generators.py:326-337,390,417; arch/ops.py:9) has G = 1, L = N*H*W.
  * eps 1e-5, biased variance for normalisation, unbiased for running_var (torch semantics). */
 size_t sscg_norm_stats_workspace(int G, int64_t L, int C);
-/* mean[G][C], rstd[G][C]; if running_mean != NULL (G must be 1):
- * running = (1-momentum)*running + momentum*batch (running_var from the unbiased batch variance). */
+/* mean[G][C], rstd[G][C]; if running_mean != NULL:
+ * running = (1-momentum)*running + momentum*batch (running_var from the unbiased batch variance), applied once per
+ * group in the order g = 0..G-1.  G > 1 with running statistics is BatchNorm2d over G batches stacked along N in one
+ * launch ("grouped"): bit-identical to G successive forwards of the layer, each on its own batch. */
 int sscg_norm_stats(const float* x, int G, int64_t L, int C, float eps, float* mean, float* rstd,
                     float* running_mean, float* running_var, float momentum, void* ws, size_t ws_bytes, void* stream);
 /* y = act((x-mean)*rstd*gamma + beta + residual); gamma/beta/residual nullable (gamma,beta are [C]). */

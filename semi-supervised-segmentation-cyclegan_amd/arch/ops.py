@@ -92,6 +92,27 @@ class InstanceNorm2d(nn.Module):
         return F.instance_norm_act(x, act, slope, residual, self.eps)
 
 
+_BATCH_GROUPS = [1]
+
+
+class batch_groups:
+    """`with batch_groups(k): net(torch.cat([x1, ..., xk]))` - every BatchNorm2d inside treats the input as k batches
+    stacked along N: per-group batch statistics, running statistics advanced k times in order.  The result is what k
+    separate forwards of the network compute, but every convolution sees k times the rows (the DeepLab maps of one
+    batch of 8 are only 8712 rows, ~2 tiles per CU) and the pass costs one set of launches."""
+
+    def __init__(self, k):
+        self.k = int(k)
+
+    def __enter__(self):
+        self.prev = _BATCH_GROUPS[0]
+        _BATCH_GROUPS[0] = self.k
+
+    def __exit__(self, *exc):
+        _BATCH_GROUPS[0] = self.prev
+        return False
+
+
 class BatchNorm2d(nn.Module):
     """nn.BatchNorm2d twin (affine, running statistics).  `num_batches_tracked` is counted on the host and
     written to its buffer when the state dict is taken, so a forward launches no bookkeeping kernel."""
@@ -123,10 +144,11 @@ class BatchNorm2d(nn.Module):
         return int(self.num_batches_tracked) + self._pending
 
     def forward(self, x, act=ACT_NONE, slope=0.0, residual=None):
+        groups = _BATCH_GROUPS[0]
         if self.training:
-            self._pending += 1
+            self._pending += groups
         return F.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                self.momentum, self.eps, act, slope, residual)
+                                self.momentum, self.eps, act, slope, residual, groups=groups)
 
 
 class _Act(nn.Module):

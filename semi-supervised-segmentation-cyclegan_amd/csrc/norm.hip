@@ -216,21 +216,26 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __res
                                                               float eps, float momentum) {
     __shared__ double sm[512];
     const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
-    const int g = blockIdx.y;
     const bool cok = c < C;
-    double s, ss;
-    chunk_sum16(part, g, chunks, C, c, cok, sm, s, ss);
-    if ((threadIdx.x & 63) == 0 && cok) {
-        const int i = g * C + c;
-        double m = s / (double)L;
-        double var = ss / (double)L - m * m;
-        if (var < 0.0) var = 0.0;
-        mean[i] = (float)m;
-        rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-        if (rmean) {
-            double unb = L > 1 ? var * (double)L / (double)(L - 1) : var;
-            rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
-            rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+    // With running statistics and G > 1 ("grouped" batch norm: G batches normalised separately in one launch) the
+    // groups are walked in order by one wave per channel, so the EMA sees them exactly as G successive forwards would.
+    const int g0 = rmean ? 0 : blockIdx.y;
+    const int g1 = rmean ? G : blockIdx.y + 1;
+    for (int g = g0; g < g1; ++g) {
+        double s, ss;
+        chunk_sum16(part, g, chunks, C, c, cok, sm, s, ss);
+        if ((threadIdx.x & 63) == 0 && cok) {
+            const int i = g * C + c;
+            double m = s / (double)L;
+            double var = ss / (double)L - m * m;
+            if (var < 0.0) var = 0.0;
+            mean[i] = (float)m;
+            rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+            if (rmean) {
+                double unb = L > 1 ? var * (double)L / (double)(L - 1) : var;
+                rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
+                rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+            }
         }
     }
 }
@@ -466,7 +471,6 @@ extern "C" int sscg_norm_stats(const float* x, int G, int64_t L, int C, float ep
                                void* stream) {
     if (!x || !mean || !rstd || G <= 0 || L <= 0 || C <= 0) return SSCG_ERR_BAD_ARG;
     if ((running_mean != nullptr) != (running_var != nullptr)) return SSCG_ERR_BAD_ARG;
-    if (running_mean && G != 1) return SSCG_ERR_BAD_ARG;
     if (!ws || ws_bytes < part_bytes(G, L, C)) return SSCG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     RedParams p = {};
@@ -474,7 +478,7 @@ extern "C" int sscg_norm_stats(const float* x, int G, int64_t L, int C, float ep
     int rc = launch_reduce<RM_STATS>(p, G, st);
     if (rc) return rc;
     RedPlan pl = plan_reduce(G, L, C);
-    hipLaunchKernelGGL(finalize_stats_kernel, dim3(cdiv(C, FIN_CH), G), dim3(256), 0, st, p.part, mean, rstd,
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3(cdiv(C, FIN_CH), running_mean ? 1 : G), dim3(256), 0, st, p.part, mean, rstd,
                        running_mean, running_var, G, C, pl.chunks, (long)L, eps, momentum);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;

@@ -270,8 +270,15 @@ def colsum(x2d_rows, cols, x, out=None, accumulate=False):
 
 
 def _glc(x, per_sample):
+    """[G][L][C] view of an NHWC tensor.  per_sample: True = InstanceNorm (G = N), False = BatchNorm (G = 1), an int
+    k > 1 = BatchNorm over k batches stacked along N (G = k, each group N/k samples)."""
     n, c, h, w = x.shape
-    return (n, h * w, c) if per_sample else (1, n * h * w, c)
+    if per_sample is True:
+        return n, h * w, c
+    k = 1 if per_sample is False else int(per_sample)
+    if k < 1 or n % k:
+        raise _lib.SscgError("batch of %d does not split into %d groups" % (n, k))
+    return k, (n // k) * h * w, c
 
 
 def norm_stats(x, per_sample, eps=1e-5, running_mean=None, running_var=None, momentum=0.1):
@@ -653,9 +660,10 @@ class NormActFn(torch.autograd.Function):
             residual = to_nhwc(residual)
         use_batch_stats = training or running_mean is None
         if use_batch_stats:
-            upd = training and running_mean is not None and not per_sample
+            upd = training and running_mean is not None and per_sample is not True
             mean, rstd = norm_stats(x, per_sample, eps, running_mean if upd else None, running_var if upd else None, momentum)
         else:
+            per_sample = False          # running statistics: one (mean, rstd) row whatever the grouping
             mean = running_mean.view(1, -1)
             rstd = rstd_from_var(running_var, eps).view(1, -1)
         y = norm_apply(x, mean, rstd, gamma, beta, residual, per_sample, act, slope)
@@ -737,6 +745,35 @@ class SplitFn(torch.autograd.Function):
                 continue
             total = to_nhwc(g) if total is None else add(total, to_nhwc(g))
         return total, None
+
+
+class BatchSplitFn(torch.autograd.Function):
+    """k batches stacked along N -> k tensors (views).  Backward stacks the k gradients again (device copies)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = k
+        ctx.shape = x.shape
+        return tuple(t for t in x.chunk(k, 0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = ctx.shape[0] // ctx.k
+        ref = next(g for g in grads if g is not None)
+        out = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device).contiguous(memory_format=CL)
+        for i, g in enumerate(grads):
+            if g is None:
+                fill_(out[i * n:(i + 1) * n], 0.0)
+            else:
+                out[i * n:(i + 1) * n].copy_(g)
+        return out, None
+
+
+def split_batch(x, k):
+    x = to_nhwc(x)
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x.chunk(k, 0)
+    return BatchSplitFn.apply(x, k)
 
 
 def split(x, n=2):
@@ -913,8 +950,11 @@ def instance_norm_act(x, act=ACT_NONE, slope=0.0, residual=None, eps=1e-5):
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
-                   residual=None):
-    return NormActFn.apply(x, gamma, beta, residual, running_mean, running_var, False, training, momentum, eps, act, slope)
+                   residual=None, groups=1):
+    """groups > 1: x holds `groups` batches stacked along N; each is normalised with its own statistics and the running
+    statistics advance once per group, in order - what `groups` successive calls would compute, in one launch."""
+    per = False if groups == 1 else int(groups)
+    return NormActFn.apply(x, gamma, beta, residual, running_mean, running_var, per, training, momentum, eps, act, slope)
 
 
 def upsample_bilinear(x, size):

@@ -19,6 +19,7 @@ import torch
 
 from . import functional as F
 from . import utils
+from . import arch
 from .arch import define_Dis, define_Gen, set_grad
 from .optim import FusedAdam
 from .utils import CLASSES, make_one_hot
@@ -54,6 +55,7 @@ class semisuper_cycleGAN(object):
         self.running_metrics_val = utils.runningScore(C, args.dataset)
         self.as_written = getattr(args, "as_written", True)         # keep the reference's unused forwards
         self.fork_forward = getattr(args, "fork_forward", True)     # two stream lanes for the trainable generator passes
+        self.stack_gsi = getattr(args, "stack_gsi", True)           # the two independent Gsi passes as one grouped-BN pass
         self.dp = data_parallel
 
         self.g_optimizer = FusedAdam(itertools.chain(self.Gis.parameters(), self.Gsi.parameters()), lr=args.lr, betas=(0.5, 0.999))
@@ -121,8 +123,17 @@ class semisuper_cycleGAN(object):
             onehot_gt.record_stream(lane)
         else:
             fake_img = self.interp(self.Gis(onehot_gt))                              # :385,390
-        fake_gt = self.interp(self.Gsi(unl_img))                                     # :386,391
-        lab_gt = self.interp(self.Gsi(l_img))                                        # :387,392
+        if self.stack_gsi:
+            # Gsi(unl_img) and Gsi(l_img) (:386-387) as ONE pass over both batches: every BatchNorm normalises the two
+            # halves separately and advances its running statistics twice, in order (arch.batch_groups) - the same
+            # arithmetic, on convolutions with twice the rows and half the launches.
+            with arch.batch_groups(2):
+                both = self.Gsi(torch.cat([unl_img, l_img], 0))
+            fake_logits, lab_logits = F.split_batch(both, 2)
+            fake_gt, lab_gt = self.interp(fake_logits), self.interp(lab_logits)     # :391-392
+        else:
+            fake_gt = self.interp(self.Gsi(unl_img))                                 # :386,391
+            lab_gt = self.interp(self.Gsi(l_img))                                    # :387,392
         if fork:
             gsi_second = torch.cuda.Event()
             gsi_second.record(main)

@@ -223,3 +223,53 @@ def test_supervised_steps_vs_reference_golden(gold, dev):
 
 def info_nbt(meta, tag, net):
     return meta["g3"]["%s/%s/num_batches_tracked" % (tag, net)]
+
+
+def test_grouped_batchnorm_layer_equals_two_calls(dev):
+    """BatchNorm2d under arch.batch_groups(2) on two stacked batches == two calls of the layer: outputs, input gradients,
+    affine gradients and the twice-advanced running statistics (fp64 statistics: equal to fp32 rounding)."""
+    arch, ops = load_sub("arch"), load_sub("arch.ops")
+    g = torch.Generator().manual_seed(2)
+    mk = lambda: ops.BatchNorm2d(64).to(dev)
+    a, b = mk(), mk()
+    with torch.no_grad():
+        a.weight.copy_(torch.rand(64, generator=g) + 0.5)
+        a.bias.copy_(torch.randn(64, generator=g))
+    b.load_state_dict(a.state_dict())
+    x = (torch.randn(6, 64, 17, 19, generator=g) * 2 + 1).to(dev)
+    gy = torch.randn(6, 64, 17, 19, generator=g).to(dev)
+    xa = x.clone().requires_grad_(True)
+    ya = torch.cat([a(xa[:3], 1), a(xa[3:], 1)], 0)          # act = ReLU
+    ya.backward(gy)
+    xb = x.clone().requires_grad_(True)
+    with arch.batch_groups(2):
+        yb = b(xb, 1)
+    yb.backward(gy)
+    assert rel(yb, ya) < 1e-6 and rel(xb.grad, xa.grad) < 1e-5
+    assert rel(b.weight.grad, a.weight.grad) < 1e-5 and rel(b.bias.grad, a.bias.grad) < 1e-5
+    assert rel(b.running_mean, a.running_mean) < 1e-6 and rel(b.running_var, a.running_var) < 1e-6
+    assert a.batches_tracked() == b.batches_tracked() == 2
+
+
+def test_grouped_batchnorm_pass_equals_two_separate_passes(dev):
+    """arch.batch_groups(2): one DeepLab pass over two stacked batches vs two passes.  Same arithmetic, different fp32
+    summation orders (tile/split plans depend on the row count), amplified by 101 BatchNorm layers: the bound is the
+    reference's own fp32-vs-fp64 distance on this net (3e-4 .. 4e-4 forward)."""
+    arch = load_sub("arch")
+    torch.manual_seed(0)
+    mk = lambda: quiet(arch.define_Gen, 3, 5, 64, "deeplab", norm="instance", use_dropout=False, gpu_ids=[dev.index or 0])
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    g = torch.Generator().manual_seed(1)
+    x1, x2 = (torch.randn(2, 3, 65, 65, generator=g).to(dev) for _ in range(2))
+    with torch.no_grad():
+        y1, y2 = a(x1), a(x2)
+        with arch.batch_groups(2):
+            yb = b(torch.cat([x1, x2], 0))
+    assert rel(yb[:2], y1) < 2e-3 and rel(yb[2:], y2) < 2e-3
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if "running" in k:
+            assert rel(sb[k], sa[k]) < 2e-3, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sa[k]) == int(sb[k]) == 2, k
