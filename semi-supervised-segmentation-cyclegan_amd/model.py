@@ -101,11 +101,14 @@ class semisuper_cycleGAN(object):
         # on the side stream, concurrently with the DeepLab forwards/backwards below.
         def frozen_branch():
             with torch.no_grad():
+                if self.as_written:
+                    # :418-423 runs old_Gsi/old_Gis on unl_img (used) and on l_img (results never used): both batches
+                    # in one pass (per-sample InstanceNorm; batch_groups keeps a BatchNorm variant equivalent too)
+                    with arch.batch_groups(2):
+                        both = self.old_Gis(F.softmax2d(self.old_Gsi(torch.cat([unl_img, l_img], 0))))
+                    return both[:unl_img.shape[0]]
                 fake = F.softmax2d(self.old_Gsi(unl_img))                            # :418,421
-                recon = self.old_Gis(fake)                                           # :422
-                if self.as_written:                                                  # :419-420,423: results never used
-                    self.old_Gis(F.softmax2d(self.old_Gsi(l_img)))
-            return recon
+                return self.old_Gis(fake)                                            # :422
         resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch)
         dev = l_img.device
         fork = F.SideStream.enabled and self.fork_forward
