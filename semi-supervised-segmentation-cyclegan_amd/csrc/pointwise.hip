@@ -32,6 +32,19 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = a[i] + b[i];
 }
 
+// 16 bytes per lane, two independent vectors in flight per thread
+__global__ __launch_bounds__(256) void add4_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ y,
+                                                    size_t n4) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const f32x4 a0 = a[i], b0 = b[i], a1 = a[i + stride], b1 = b[i + stride];
+        y[i] = a0 + b0;
+        y[i + stride] = a1 + b1;
+    }
+    if (i < n4) y[i] = a[i] + b[i];
+}
+
 __global__ void fill_kernel(float* __restrict__ x, size_t n, float v) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = v;
 }
@@ -250,7 +263,13 @@ extern "C" int sscg_act_bwd(const float* dy, const float* y, float* dx, int64_t 
 
 extern "C" int sscg_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
     if (!a || !b || !y || n <= 0) return SSCG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (size_t)n);
+    if (n % 4 == 0 && (((size_t)a | (size_t)b | (size_t)y) & 15) == 0) {
+        const size_t n4 = (size_t)n / 4;
+        hipLaunchKernelGGL(add4_kernel, dim3(ew_blocks((n4 + 1) / 2)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const f32x4*>(a), reinterpret_cast<const f32x4*>(b), reinterpret_cast<f32x4*>(y), n4);
+    } else {
+        hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (size_t)n);
+    }
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

@@ -500,13 +500,14 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
 
 
 # ----------------------------------------------------------------------------- autograd functions
-_WEIGHT_EPOCH = [0]
+_WEIGHT_EPOCH = [0]     # weights owned by no arena optimiser (stock torch optimisers rewrite `_version` instead)
 
 
-def bump_weight_epoch():
-    """Called by the optimiser after it rewrote parameters: invalidates cached transposed weights."""
-    _WEIGHT_EPOCH[0] += 1
-
+def bump_weight_epoch(epoch_cell=None):
+    """Called by the optimiser after it rewrote parameters: invalidates the cached transposed copies of ITS weights
+    (`epoch_cell` is the one-element list its parameters carry as `_sscg_epoch`; the discriminators' update must not
+    make the generators rebuild 450 transposes)."""
+    (epoch_cell if epoch_cell is not None else _WEIGHT_EPOCH)[0] += 1
 
 
 _WT_USERS = {}      # id -> weakref of the weights whose transposed copy a backward pass has asked for
@@ -531,7 +532,7 @@ def _cached_wt(w):
     if id(w) not in _WT_USERS:
         key = id(w)
         _WT_USERS[key] = weakref.ref(w, lambda _r, key=key: _WT_USERS.pop(key, None))
-    tag = (w._version, _WEIGHT_EPOCH[0], w.data_ptr())
+    tag = (w._version, getattr(w, "_sscg_epoch", _WEIGHT_EPOCH)[0], w.data_ptr())
     ent = getattr(w, "_sscg_wt", None)
     if ent is None or ent[0] != tag:
         ent = (tag, weight_transposed(w))

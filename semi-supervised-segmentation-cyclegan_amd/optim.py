@@ -41,6 +41,7 @@ class FusedAdam(torch.optim.Optimizer):
         for t in (self.grad, self.exp_avg, self.exp_avg_sq):
             F.fill_(t, 0.0)
         self.trainable = ps
+        self._epoch = [0]      # bumped by step(): the cached transposed copies of these weights are stale
         self.slices = {}
         off = 0
         for p in ps:
@@ -51,6 +52,7 @@ class FusedAdam(torch.optim.Optimizer):
             g = self._view(self.grad, p, off)
             p._sscg_grad = g
             p._sscg_touched = False
+            p._sscg_epoch = self._epoch
             p.grad = g
             off += self._padded(n)
 
@@ -73,7 +75,7 @@ class FusedAdam(torch.optim.Optimizer):
         F.SideStream.join(self.arena.device)     # weight gradients are accumulated on the side stream
         F.adam_step(self.arena, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                     self._steps, 1.0 / self.world_size)
-        F.bump_weight_epoch()
+        F.bump_weight_epoch(self._epoch)
 
     def mark_touched(self):
         """Parameters whose gradient slice is non-zero have taken part in a backward pass (host check, used lazily by state_dict)."""
