@@ -413,8 +413,144 @@ extern "C" int sscg_debug_set_wgrad_plan(int target_wgs, int min_iters) {
     return SSCG_OK;
 }
 
+// ---- "thin" weight gradients: 1x1 convolutions with a handful of channels on one side (PixelDiscriminator:
+// 3 -> 64, 21 -> 64, 128 -> 1 at 256x256).  dw[k][c] = sum_p dy[p][k] * x[p][c] over 524288 pixels is a pure stream of
+// the wide operand (134 .. 268 MB); on the matrix-core kernel it ran at 0.3 .. 3 TFLOP/s, 6 .. 16x off the HBM roofline.
+// Here a thread owns four wide channels, walks a stripe of pixels with the <= 32 thin values of each pixel broadcast to
+// it, and keeps T x 4 running sums in registers; stripes are combined through LDS, workgroups through the workspace and
+// a fixed-order second stage (deterministic).
+namespace {
+
+constexpr int THIN_MAX = 32;
+constexpr int THIN_BLOCKS = 1024;
+
+struct ThinParams {
+    const float* __restrict__ wide;   // [npix][Wd]
+    const float* __restrict__ thin;   // [npix][T]
+    float* __restrict__ part;         // [blocks][T][Wd]
+    int npix, Wd, T;
+};
+
+template <int T>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(ThinParams p) {
+    constexpr int TB = T < 4 ? T : 4;              // thin channels combined per LDS round (keeps the block at <= 16 KB)
+    extern __shared__ float red[];                 // [lanes][TB][Wd]
+    const int wq = p.Wd / 4;                       // threads across the wide channels
+    const int lanes = 256 / wq;                    // pixel lanes of the block
+    const int q = threadIdx.x % wq;
+    const int pl = threadIdx.x / wq;
+    float acc[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    if (pl < lanes) {
+        const int stride = lanes * gridDim.x;
+        int px = blockIdx.x * lanes + pl;
+        for (; px + stride < p.npix; px += 2 * stride) {       // two pixels in flight per thread
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wide + (size_t)px * p.Wd + q * 4);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(p.wide + (size_t)(px + stride) * p.Wd + q * 4);
+            const float* th0 = p.thin + (size_t)px * T;
+            const float* th1 = p.thin + (size_t)(px + stride) * T;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float v0 = th0[t], v1 = th1[t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(v1, w1[e], fmaf(v0, w0[e], acc[t][e]));
+            }
+        }
+        if (px < p.npix) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wide + (size_t)px * p.Wd + q * 4);
+            const float* th0 = p.thin + (size_t)px * T;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float v0 = th0[t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(v0, w0[e], acc[t][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t0 = 0; t0 < T; t0 += TB) {
+        if (pl < lanes) {
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+                if (t0 + t < T)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) red[((size_t)pl * TB + t) * p.Wd + q * 4 + e] = acc[t0 + t][e];
+        }
+        __syncthreads();
+        const int nt = (T - t0) < TB ? (T - t0) : TB;
+        for (int i = threadIdx.x; i < nt * p.Wd; i += 256) {
+            float s = 0.f;
+            for (int l = 0; l < lanes; ++l) s += red[(size_t)l * TB * p.Wd + i];
+            p.part[(size_t)blockIdx.x * T * p.Wd + (size_t)t0 * p.Wd + i] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// dw[k][c] = beta * dw[k][c] + sum_b part[b][t][w]; one wave per output element, lanes stride the blocks (fixed order)
+__global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int blocks,
+                                                                 int T, int Wd, int K, int C, float beta) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= T * Wd) return;
+    float s = 0.f;
+    for (int b = lane; b < blocks; b += 64) s += part[(size_t)b * T * Wd + o];
+    s = wave_sum(s);
+    if (lane == 0) {
+        const int t = o / Wd, w = o - t * Wd;
+        const int k = (K == T && K <= C) ? t : w;      // which side is the thin one
+        const int c = (K == T && K <= C) ? w : t;
+        float* d = dw + (size_t)k * C + c;
+        *d = beta != 0.f ? beta * *d + s : s;
+    }
+}
+
+bool thin_wgrad_applies(const sscg_conv_desc* d) {
+    if (d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->pad_mode != 0) return false;
+    const int T = d->K < d->C ? d->K : d->C, Wd = d->K < d->C ? d->C : d->K;
+    return T <= THIN_MAX && Wd % 4 == 0 && Wd <= 256 && Wd >= 16 && (long)d->N * d->H * d->W >= 65536;
+}
+
+template <int T>
+void launch_thin(const ThinParams& p, int blocks, size_t smem, hipStream_t st) {
+    hipLaunchKernelGGL(thin_wgrad_kernel<T>, dim3(blocks), dim3(256), smem, st, p);
+}
+
+int thin_wgrad(const sscg_conv_desc* d, const float* x, const float* dy, float* dw, float beta, void* ws, hipStream_t st) {
+    const bool thin_is_k = d->K <= d->C;
+    ThinParams p;
+    p.T = thin_is_k ? d->K : d->C;
+    p.Wd = thin_is_k ? d->C : d->K;
+    p.wide = thin_is_k ? x : dy;
+    p.thin = thin_is_k ? dy : x;
+    p.part = reinterpret_cast<float*>(ws);
+    p.npix = d->N * d->H * d->W;
+    const int lanes = 256 / (p.Wd / 4);
+    const size_t smem = (size_t)lanes * (p.T < 4 ? p.T : 4) * p.Wd * sizeof(float);
+    switch (p.T) {
+#define SSCG_THIN_CASE(n) case n: { if (smem > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(thin_wgrad_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; } launch_thin<n>(p, THIN_BLOCKS, smem, st); break; }
+        SSCG_THIN_CASE(1) SSCG_THIN_CASE(2) SSCG_THIN_CASE(3) SSCG_THIN_CASE(4) SSCG_THIN_CASE(20) SSCG_THIN_CASE(21)
+#undef SSCG_THIN_CASE
+        default: return SSCG_ERR_UNSUPPORTED;
+    }
+    SSCG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3(cdiv(p.T * p.Wd, 4)), dim3(256), 0, st, p.part, dw, THIN_BLOCKS, p.T, p.Wd,
+                       d->K, d->C, beta);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+bool thin_wgrad_supported_T(int T) { return T == 1 || T == 2 || T == 3 || T == 4 || T == 20 || T == 21; }
+
+}  // namespace
+
 extern "C" size_t sscg_conv2d_wgrad_workspace(const sscg_conv_desc* d) {
     if (!d) return 0;
+    if (thin_wgrad_applies(d) && thin_wgrad_supported_T(d->K < d->C ? d->K : d->C))
+        return (size_t)THIN_BLOCKS * d->K * d->C * sizeof(float);
     WgPlan pl = plan_wgrad(d);
     if (pl.splits <= 1) return 0;
     return (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float);
@@ -427,6 +563,10 @@ extern "C" int sscg_conv2d_wgrad(const sscg_conv_desc* d, const float* x, const 
     if (d->N <= 0 || d->C <= 0 || d->K <= 0) return SSCG_ERR_BAD_ARG;
     if ((long)d->N * d->H * d->W * (long)d->C >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
     if ((long)d->N * d->P * d->Q * (long)d->K >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
+    if (thin_wgrad_applies(d) && thin_wgrad_supported_T(d->K < d->C ? d->K : d->C)) {
+        if (!ws || ws_bytes < sscg_conv2d_wgrad_workspace(d)) return SSCG_ERR_WORKSPACE;
+        return thin_wgrad(d, x, dy, dw, beta, ws, (hipStream_t)stream);
+    }
     WgPlan pl = plan_wgrad(d);
     size_t need = pl.splits > 1 ? (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float) : 0;
     if (need > 0 && (!ws || ws_bytes < need)) return SSCG_ERR_WORKSPACE;

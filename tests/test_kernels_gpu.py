@@ -406,3 +406,23 @@ def test_conv_adjoint_identities_at_bench_size(shape, F, dev):
     scale = float(y.double().norm() * dy.double().norm())
     assert abs(lhs - via_x) <= 5e-8 * scale, (lhs, via_x, scale)      # fp32 noise ~1e-9 * scale; one wrong 64x64 tile ~3e-5 * scale
     assert abs(lhs - via_w) <= 5e-8 * scale, (lhs, via_w, scale)
+
+
+@pytest.mark.parametrize("geom", [(4, 128, 1, 128, 128), (4, 3, 64, 128, 128), (2, 21, 64, 192, 176), (4, 20, 64, 128, 128),
+                                  (4, 64, 3, 128, 128), (3, 64, 1, 150, 147)])
+def test_thin_1x1_weight_gradient(geom, F, dev):
+    """The few-channel 1x1 convolutions of the PixelDiscriminator (arch/discriminators.py:70-75) at image resolution take the
+    streaming weight-gradient kernel (>= 65536 pixels, one side <= 32 channels): parity with torch in fp64, and with
+    accumulation into an existing gradient."""
+    N, C, K, H, W = geom
+    g = torch.Generator().manual_seed(N * 1000 + C + K)
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(K, C, 1, 1, generator=g, dtype=torch.float64)
+    dy = torch.randn(N, K, H, W, generator=g, dtype=torch.float64)
+    ref = torch.einsum("nkhw,nchw->kc", dy, x).reshape(K, C, 1, 1)
+    xg, dyg = gpu(x, dev), gpu(dy, dev)
+    dw = F.conv2d_wgrad(xg, dyg, w.shape, 1, 0, 1)
+    assert rel_err(dw, ref) < 2e-5
+    acc = gpu(w, dev).clone()
+    F.conv2d_wgrad(xg, dyg, w.shape, 1, 0, 1, out=acc, accumulate=True)
+    assert rel_err(acc, ref + w) < 2e-5
