@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-elided", action="store_true")
     ap.add_argument("--batch", type=int, default=B)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="arithmetic of the conv contractions; BASELINE config 2 (the bench config) is fp32")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-contraction figure")
     a = ap.parse_args()
 
     import torch
@@ -66,6 +69,7 @@ def main():
     args = FX.make_args(dataset="voc2012", crop_height=H, crop_width=W, batch_size=bsz, gpu_ids=[local], no_dropout=False,
                         checkpoint_dir="/tmp/sscg_bench_ckpt_%d" % rank, as_written=True, epochs=400, decay_epoch=100)
     torch.manual_seed(0)
+    F.set_conv_precision(a.dtype)
     with contextlib.redirect_stdout(io.StringIO()):
         model = md.semisuper_cycleGAN(args, data_parallel=dp)
 
@@ -96,8 +100,9 @@ def main():
     out = {
         "metric": "training images/sec (G+D step) at 256x256", "value": round(value, 4), "unit": "img/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "VOC2012 21-class 256x256 semisupervised_cycleGAN as-written G+D step, batch=%d per GPU, fp32" % bsz,
+        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "VOC2012 21-class 256x256 semisupervised_cycleGAN as-written G+D step, batch=%d per GPU, %s" % (
+                       bsz, "fp32" if a.dtype == "f32" else "bf16 conv contractions (fp32 accumulate, fp32 tensors/norms/Adam)"),
                    "global_batch": world * bsz, "image_unit": "one labeled + one unlabeled 256x256 image", "parallelism": "dp%d" % world,
                    "losses_finite": finite},
         "step_conv_tflops": round(world * bsz * STEP_TFLOP_PER_PAIR * a.steps / dt, 2),
@@ -122,6 +127,26 @@ def main():
         model.as_written = True
         out["elided_dead_work"] = {"value": round(world * bsz * a.steps / dte, 4), "unit": "img/s", "ms_per_step": round(1e3 * dte / a.steps, 3),
                                    "note": "not the headline: skips 53.25 GMAC/pair of forwards with unused outputs + 1.1 GMAC/pair of unused wgrad"}
+
+    # secondary figure: the same as-written step with the heavy convolutions contracting in bf16 (fp32 accumulation,
+    # tensors still fp32 in HBM) - the arithmetic BASELINE configs 3/5 name; never the headline of this fp32 config
+    if a.dtype == "f32" and not a.no_bf16:
+        F.set_conv_precision("bf16")
+        run(a.warmup + a.steps)
+        if dp:
+            dp.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(a.warmup, a.warmup + a.steps):
+            lb = run(i)
+        torch.cuda.synchronize()
+        if dp:
+            dp.barrier()
+        dtb = par.max_over_ranks(time.perf_counter() - t2)
+        F.set_conv_precision("f32")
+        out["bf16_contractions"] = {"value": round(world * bsz * a.steps / dtb, 4), "unit": "img/s", "ms_per_step": round(1e3 * dtb / a.steps, 3),
+                                    "losses_finite": all(bool(torch.isfinite(v)) for v in lb.values()),
+                                    "note": "not the headline (BASELINE config 2 is fp32): conv operands rounded to bf16 in LDS->MFMA, fp32 accumulate"}
 
     if rank == 0 and not a.no_roofline:
         # per-kernel timing needs the kernels one at a time: the side stream (concurrent weight gradients /

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 4
+#define SSCG_ABI_VERSION 5
 
 #define SSCG_ERR_BAD_ARG (-1)
 #define SSCG_ERR_UNSUPPORTED (-2)
@@ -76,6 +76,12 @@ int sscg_weight_krsc_to_crsk(const float* w, float* wt, int K, int RS, int C, vo
 size_t sscg_colsum_workspace(int64_t rows, int cols);
 int sscg_colsum(const float* x, float* out, int64_t rows, int cols, float beta, void* ws, size_t ws_bytes, void* stream);
 
+/* Arithmetic of the convolution contractions on the vectorised LDS-DMA tiles (every heavy conv of the step):
+ * 0 (default) = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products);
+ * 1 = operands rounded to bfloat16 (RNE) on their way out of LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+ * Tensors stay fp32 in HBM either way (BASELINE configs 3/5 name bf16; the headline config is fp32).  Process-wide. */
+int sscg_set_conv_precision(int mode);
+int sscg_get_conv_precision(void);
 /* tuning/test hook: bits 0..7 force the forward/dgrad tile configuration (0xff = keep the heuristic), bits 8..15 the
  * split-K factor (0 = planner, 1 = never split, n > 1 = every tile cut in n); -1 restores the defaults */
 int sscg_debug_set_conv_cfg(int cfg);

@@ -40,6 +40,8 @@ def get_args(argv=None):
     parser.add_argument("--as_written", type=int, default=1, help="1: also run the forwards whose outputs the reference never uses")
     parser.add_argument("--data", type=str, choices=["auto", "real", "synthetic"], default="auto",
                         help="real: the datasets under ./data (reference layout); synthetic: seeded random batches; auto: real if present")
+    parser.add_argument("--dtype", type=str, choices=["f32", "bf16"], default="f32",
+                        help="conv contraction arithmetic: exact fp32 MFMA, or bf16 operands with fp32 accumulation")
     parser.add_argument("--testing_gen", type=str, default="resnet_9blocks_softmax",
                         help="generator testing.py builds (the reference hard-codes resnet_9blocks_softmax, testing.py:40)")
     return parser.parse_args(argv)
@@ -52,6 +54,7 @@ def main(argv=None):
     if args.crop_height is None and args.crop_width is None:
         args.crop_height, args.crop_width = DEFAULT_CROP[args.dataset]
     md = importlib.import_module(PKG + ".model")
+    importlib.import_module(PKG + ".functional").set_conv_precision(args.dtype)
     dp = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         par = importlib.import_module(PKG + ".parallel")

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZEROS, PAD_REFLECT = 0, 1
@@ -46,6 +46,8 @@ SIGNATURES = {
     "sscg_weight_krsc_to_crsk": (_i, [_p, _p, _i, _i, _i, _p]),
     "sscg_colsum_workspace": (_sz, [_i64, _i]),
     "sscg_colsum": (_i, [_p, _p, _i64, _i, _f, _p, _sz, _p]),
+    "sscg_set_conv_precision": (_i, [_i]),
+    "sscg_get_conv_precision": (_i, []),
     "sscg_debug_set_conv_cfg": (_i, [_i]),
     "sscg_debug_set_wgrad_plan": (_i, [_i, _i]),
     "sscg_norm_stats_workspace": (_sz, [_i, _i64, _i]),

@@ -26,6 +26,8 @@
 #include "common.h"
 #include "sscg_internal.h"
 
+int sscg_conv_precision = 0;     // 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulation (sscg_set_conv_precision); read by conv_wgrad.hip
+
 namespace {
 
 #ifndef SSCG_BK
@@ -69,8 +71,12 @@ struct KcParams {
 // 256 B of zeros: the source of LDS-DMA lanes that fall into padding / outside the tile
 __device__ float sscg_zero_page[64];
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false, bool BF16 = false>
 __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
+    // BF16: the operands are rounded to bfloat16 (RNE) when the fragments leave LDS and contracted by
+    // v_mfma_f32_32x32x16_bf16 with fp32 accumulation - tensors in HBM and LDS stay fp32, so loader, swizzle and epilogue are
+    // those of the fp32 kernel.  16x fewer MFMA cycles; the kernel is then bound by LDS reads and the global->LDS copies.
+    static_assert(!BF16 || (DMA && BK == 32), "the bf16 contraction is built on the LDS-DMA path");
     static_assert(!DMA || (FAST && NBUF == 2), "LDS-DMA staging is built on the fast path");
     // DMA staging: `global_load_lds_dwordx4` writes lane-linear (wave-uniform base + lane*16 B), so the LDS image is
     // the unpadded [row][32]; bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the
@@ -369,6 +375,34 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
         const float* b = Bs + buf * BN * LDR + (col_w + li) * LDR + (DMA ? 0 : lh * 4);
         const int swz = dma_swizzle(li);  // DMA image: 16-B slot c of a row lives at slot c ^ swz
         auto koff = [&](int kk) { return DMA ? (((kk * 2 + lh) ^ swz) * 4) : kk * 8; };
+        if constexpr (BF16) {
+            f32x4 ga[4][TM], gb[4][TN];           // the four 8-wide k-groups of this k-tile
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ga[kk][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDR + koff(kk));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) gb[kk][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDR + koff(kk));
+            }
+            if (kt + 1 < nk) load_tile();
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {      // two MFMAs of k = 16: lane half h contributes the k-groups (2*g2, 2*g2+1), slot h
+                bf16x8 pa[TM], pb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pa[i][e] = (__bf16)ga[2 * g2][i][e]; pa[i][4 + e] = (__bf16)ga[2 * g2 + 1][i][e]; }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pb[j][e] = (__bf16)gb[2 * g2][j][e]; pb[j][4 + e] = (__bf16)gb[2 * g2 + 1][j][e]; }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i], pb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
         f32x4 fa[2][TM], fb[2][TN];
         // fragments of the first k-group are requested right after the barrier ...
 #pragma unroll
@@ -393,6 +427,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
+        }
         }
         if (NBUF == 1) __syncthreads();      // single LDS image: every wave is done reading before it is overwritten
         if (kt + 1 < nk) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
@@ -520,7 +555,7 @@ static size_t kc_split_bytes(const KcSplit& sp, int M, int Ng) {
     return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false, bool BF16 = false>
 int launch_kc(const KcParams& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -530,7 +565,7 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     p.tiles = tiles_m * p.tiles_n;
     constexpr int LDR = DMA ? BK : LDK;
     size_t smem = (size_t)(NBUF * BM * LDR + NBUF * BN * LDR) * sizeof(float) + (size_t)(p.R * p.S > 0 ? p.R * p.S : 1) * 8;
-    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST, NBUF, DMA>;
+    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST, NBUF, DMA, BF16>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -562,8 +597,8 @@ int dispatch_kc(const KcParams& p, hipStream_t st) {
         case 3: return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST>(p, st);
         case 4: return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST>(p, st);
         case 5: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 1>(p, st);   // 128x128, single LDS image (experimental)
-        case 6: if constexpr (FAST) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
-        case 7: if constexpr (FAST) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
+        case 6: if constexpr (FAST) { if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
+        case 7: if constexpr (FAST) { if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
         default: return SSCG_ERR_BAD_ARG;
     }
 }
@@ -576,6 +611,14 @@ int dispatch_mode(const KcParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int sscg_set_conv_precision(int mode) {
+    if (mode != 0 && mode != 1) return SSCG_ERR_BAD_ARG;
+    sscg_conv_precision = mode;
+    return SSCG_OK;
+}
+
+extern "C" int sscg_get_conv_precision(void) { return sscg_conv_precision; }
 
 extern "C" int sscg_debug_set_conv_cfg(int cfg) {
     if (cfg < 0) { sscg_force_conv_cfg = -1; sscg_force_conv_split = 0; return SSCG_OK; }

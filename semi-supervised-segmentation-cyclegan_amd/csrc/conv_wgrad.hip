@@ -15,6 +15,8 @@
 #include "common.h"
 #include "sscg_internal.h"
 
+extern int sscg_conv_precision;   // conv_igemm.hip
+
 namespace {
 
 constexpr int BKP = 32;  // pixels per k-step
@@ -41,7 +43,7 @@ struct WgParams {
 // 256 B of zeros: the source of masked LDS-DMA lanes (device code is not linked across translation units)
 __device__ float sscg_zero_page[64];
 
-template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false>
+template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false, bool BF16 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     static_assert(!DMA || (VA == 4 && VB == 4), "LDS-DMA staging needs 16-byte granules");
     constexpr int BM = WM * TM * 32;
@@ -245,6 +247,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
         if (it + 1 < nsteps) load_tile(p_begin + (it + 1) * BKP);
         const float* a = As + buf * BKP * LDA + lh * LDA + row_w + li;
         const float* b = Bs + buf * BKP * LDB + lh * LDB + col_w + li;
+        if constexpr (BF16) {
+            // bf16 contraction (see conv_igemm.hip): eight of this lane's pixel samples -> one operand of a k = 16 MFMA;
+            // the lane half h keeps the pixel parity it has in the fp32 walk, A and B alike
+#pragma unroll
+            for (int g2 = 0; g2 < BKP / 16; ++g2) {
+                bf16x8 pa[TM], pb[TN];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int kp = g2 * 8 + e;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) pa[i][e] = (__bf16)a[kp * 2 * LDA + i * 32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) pb[j][e] = (__bf16)b[kp * 2 * LDB + j * 32];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i], pb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int kp = 0; kp < BKP / 2; ++kp) {
             float fa[TM], fb[TN];
@@ -257,6 +280,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
         }
         if (it + 1 < nsteps) store_tile(buf ^ 1);
         __syncthreads();
@@ -371,7 +395,7 @@ WgPlan plan_wgrad(const sscg_conv_desc* d) {
     return pl;
 }
 
-template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false>
+template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false, bool BF16 = false>
 int launch_wg(WgParams p, int splits, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -380,7 +404,7 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
     p.tiles = tiles_m * p.tiles_n;
     p.splits = splits;
     size_t smem = (size_t)(2 * BKP * (DMA ? BM : BM + 4) + 2 * BKP * (DMA ? BN : BN + 4)) * sizeof(float);
-    auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VA, VB, DMA>;
+    auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VA, VB, DMA, BF16>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -393,8 +417,10 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
 template <int VA, int VB>
 int dispatch_wg(const WgParams& p, const WgPlan& pl, hipStream_t st) {
     switch (pl.cfg) {
-        case 0: return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);   // LDS-DMA staging when vectorisable
-        case 1: return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);
+        case 0: if constexpr (VA == 4 && VB == 4) { if (sscg_conv_precision == 1) return launch_wg<2, 2, 2, 2, VA, VB, true, true>(p, pl.splits, st); }
+                return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);   // LDS-DMA staging when vectorisable
+        case 1: if constexpr (VA == 4 && VB == 4) { if (sscg_conv_precision == 1) return launch_wg<2, 2, 1, 1, VA, VB, true, true>(p, pl.splits, st); }
+                return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);
         case 2: return launch_wg<1, 4, 1, 1, VA, VB>(p, pl.splits, st);
         case 3: return launch_wg<4, 1, 1, 1, VA, VB>(p, pl.splits, st);
         default: return SSCG_ERR_BAD_ARG;

@@ -152,6 +152,24 @@ def to_nchw(x):
     return y
 
 
+def set_conv_precision(mode):
+    """"f32" (default): exact fp32 MFMA contractions.  "bf16": the heavy (vectorised LDS-DMA) convolutions round their
+    operands to bfloat16 and contract on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors stay fp32 in HBM,
+    norms / losses / Adam stay fp32.  Process-wide (sscg_set_conv_precision)."""
+    code = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}.get(str(mode).lower())
+    if code is None:
+        raise _lib.SscgError("conv precision must be 'f32' or 'bf16', got %r" % (mode,))
+    check(lib.sscg_set_conv_precision(code), "sscg_set_conv_precision")
+
+
+def get_conv_precision():
+    return "bf16" if lib.sscg_get_conv_precision() == 1 else "f32"
+
+
+if os.environ.get("SSCG_CONV_PRECISION"):          # tools/ and ad-hoc runs; main.py / bench.py take --dtype
+    set_conv_precision(os.environ["SSCG_CONV_PRECISION"])
+
+
 def conv_out_size(h, k, stride, pad, dil):
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 

@@ -426,3 +426,39 @@ def test_thin_1x1_weight_gradient(geom, F, dev):
     acc = gpu(w, dev).clone()
     F.conv2d_wgrad(xg, dyg, w.shape, 1, 0, 1, out=acc, accumulate=True)
     assert rel_err(acc, ref + w) < 2e-5
+
+
+BF16_CASES = [(2, 256, 33, 33, 256, 3, 1, 2, 2), (2, 256, 17, 19, 1024, 1, 1, 0, 1), (8, 256, 33, 33, 256, 3, 1, 2, 2),
+              (2, 64, 32, 32, 128, 3, 2, 1, 1), (4, 512, 33, 33, 512, 3, 1, 4, 4)]
+
+
+@pytest.mark.parametrize("shape", BF16_CASES)
+def test_conv_bf16_contraction_mode(shape, F, dev):
+    """sscg_set_conv_precision(1): operands rounded to bfloat16 (RNE), exact products, fp32 accumulation.  Against torch fp64
+    convolutions of the bf16-ROUNDED tensors only the accumulation order differs (2e-5); against the unrounded tensors the
+    result must sit at bf16's ~1e-2..1e-3, which shows that the mode is actually engaged."""
+    N, C, H, W, K, R, s, p, d = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) * 0.05
+    xr, wr = x.bfloat16().double(), w.bfloat16().double()
+    xr.requires_grad_(True)
+    wr.requires_grad_(True)
+    yr = TF.conv2d(xr, wr, None, s, p, d)
+    gy = torch.randn(yr.shape, generator=g)
+    gyr = gy.bfloat16().double()
+    yr.backward(gyr)
+    exact = TF.conv2d(x.double(), w.double(), None, s, p, d)
+    try:
+        F.set_conv_precision("bf16")
+        assert F.get_conv_precision() == "bf16"
+        xg, wg, gyg = gpu(x, dev), gpu(w, dev), gpu(gy, dev)
+        y = F.conv2d_fwd(xg, wg, None, s, p, d)
+        dx = F.conv2d_dgrad(gyg, F.weight_transposed(wg), xg.shape, wg.shape, s, p, d)
+        dw = F.conv2d_wgrad(xg, gyg, wg.shape, s, p, d)
+    finally:
+        F.set_conv_precision("f32")
+    assert rel_err(y, yr.detach()) < 2e-5
+    assert 1e-4 < rel_err(y, exact) < 3e-2
+    assert rel_err(dx, xr.grad) < 2e-5
+    assert rel_err(dw, wr.grad) < 5e-5

@@ -273,3 +273,27 @@ def test_grouped_batchnorm_pass_equals_two_separate_passes(dev):
             assert rel(sb[k], sa[k]) < 2e-3, k
         if k.endswith("num_batches_tracked"):
             assert int(sa[k]) == int(sb[k]) == 2, k
+
+
+def test_bf16_contraction_step_stays_within_bf16_noise_of_the_reference(gold, dev):
+    """`--dtype bf16` (sscg_set_conv_precision(1)): the first G+D step of the golden 64x64 configuration.  Kernel-level
+    parity of this mode is exact against bf16-rounded operands (test_kernels_gpu.py); end to end the nine losses must sit
+    within bf16 rounding noise (2^-8 per operand, amplified by DeepLab) of the fp64 reference trajectory."""
+    meta, _, _ = gold
+    F = load_sub("functional")
+    np.random.seed(0)
+    try:
+        F.set_conv_precision("bf16")
+        m, (C, H, Wd, B, steps) = _make_model("s64", dev)
+        l_img, l_gt, unl_img = FX.step_batch("s64", 0, C, H, Wd, B)
+        got = {k: float(v) for k, v in m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev)).items()}
+    finally:
+        F.set_conv_precision("f32")
+    ref64 = meta["g3"]["s64"]["oracle_f64"][0]
+    worst = 0.0
+    for k in ostep.LOSS_KEYS:
+        e = abs(got[k] - ref64[k]) / abs(ref64[k])
+        worst = max(worst, e)
+        print("%-20s bf16 %.6f f64 %.6f  rel %.1e" % (k, got[k], ref64[k], e))
+        assert np.isfinite(got[k]) and e < 0.1, k
+    assert worst > 1e-6          # the mode was engaged: not the fp32 result
