@@ -148,15 +148,17 @@ def main():
                                     "losses_finite": all(bool(torch.isfinite(v)) for v in lb.values()),
                                     "note": "not the headline (BASELINE config 2 is fp32): conv operands rounded to bf16 in LDS->MFMA, fp32 accumulate"}
 
-    if rank == 0 and not a.no_roofline:
+    if not a.no_roofline:
         # per-kernel timing needs the kernels one at a time: the side stream (concurrent weight gradients /
-        # frozen generators) is switched off for this extra, untimed step only
+        # frozen generators) is switched off for this extra, untimed step only.  EVERY rank runs the step (it contains
+        # the gradient all-reduces); rank 0 reports.
         F.SideStream.enabled = False
         torch.cuda.synchronize()
         with F.ConvProfile() as prof:
             run(a.warmup + a.steps)
         summ = prof.summary()
         F.SideStream.enabled = True
+    if rank == 0 and not a.no_roofline:
         kc = {"flops": 0.0, "ms": 0.0, "launches": 0}
         for kind in ("fwd", "dgrad"):
             if kind in summ:

@@ -20,7 +20,10 @@ class DataParallel:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("SSCG_DP_SHARED_GPU"):      # test rig: all ranks on GPU 0 (with SSCG_DP_BACKEND=gloo) - exercises the
+            self.local_rank = 0                       # multi-rank control flow of the step / bench on a 1-GPU box
         if not dist.is_initialized():
+            backend = backend or os.environ.get("SSCG_DP_BACKEND")
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             if backend == "nccl":
