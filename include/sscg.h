@@ -76,7 +76,7 @@ int sscg_weight_krsc_to_crsk(const float* w, float* wt, int K, int RS, int C, vo
 size_t sscg_colsum_workspace(int64_t rows, int cols);
 int sscg_colsum(const float* x, float* out, int64_t rows, int cols, float beta, void* ws, size_t ws_bytes, void* stream);
 
-/* Arithmetic of the convolution contractions on the vectorised LDS-DMA tiles (every heavy conv of the step):
+/* Arithmetic of the convolution contractions on the matrix-core tiles (forward, data gradient, weight gradient):
  * 0 (default) = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products);
  * 1 = operands rounded to bfloat16 (RNE) on their way out of LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation.
  * Tensors stay fp32 in HBM either way (BASELINE configs 3/5 name bf16; the headline config is fp32).  Process-wide. */

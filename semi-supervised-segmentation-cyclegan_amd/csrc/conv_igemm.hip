@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     // BF16: the operands are rounded to bfloat16 (RNE) when the fragments leave LDS and contracted by
     // v_mfma_f32_32x32x16_bf16 with fp32 accumulation - tensors in HBM and LDS stay fp32, so loader, swizzle and epilogue are
     // those of the fp32 kernel.  16x fewer MFMA cycles; the kernel is then bound by LDS reads and the global->LDS copies.
-    static_assert(!BF16 || (DMA && BK == 32), "the bf16 contraction is built on the LDS-DMA path");
+    static_assert(!BF16 || (NBUF == 2 && BK == 32), "the bf16 contraction regroups the four 8-wide k-groups of a 32-wide k-tile");
     static_assert(!DMA || (FAST && NBUF == 2), "LDS-DMA staging is built on the fast path");
     // DMA staging: `global_load_lds_dwordx4` writes lane-linear (wave-uniform base + lane*16 B), so the LDS image is
     // the unpadded [row][32]; bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the
@@ -591,11 +591,16 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
 template <int MODE, int VEC, bool FAST>
 int dispatch_kc(const KcParams& p, hipStream_t st) {
     switch (kc_choose_cfg(p.M, p.Ng, p.Ktot, p.Cs)) {
-        case 0: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST>(p, st);
-        case 1: return launch_kc<MODE, 2, 2, 2, 1, VEC, FAST>(p, st);
-        case 2: return launch_kc<MODE, 2, 2, 1, 2, VEC, FAST>(p, st);
-        case 3: return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST>(p, st);
-        case 4: return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST>(p, st);
+        case 0: if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, false, true>(p, st);
+                return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST>(p, st);
+        case 1: if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 2, 1, VEC, FAST, 2, false, true>(p, st);
+                return launch_kc<MODE, 2, 2, 2, 1, VEC, FAST>(p, st);
+        case 2: if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 1, 2, VEC, FAST, 2, false, true>(p, st);
+                return launch_kc<MODE, 2, 2, 1, 2, VEC, FAST>(p, st);
+        case 3: if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, false, true>(p, st);
+                return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST>(p, st);
+        case 4: if (sscg_conv_precision == 1) return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST, 2, false, true>(p, st);
+                return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST>(p, st);
         case 5: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 1>(p, st);   // 128x128, single LDS image (experimental)
         case 6: if constexpr (FAST) { if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
         case 7: if constexpr (FAST) { if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging

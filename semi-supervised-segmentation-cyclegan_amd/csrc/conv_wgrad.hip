@@ -417,12 +417,14 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
 template <int VA, int VB>
 int dispatch_wg(const WgParams& p, const WgPlan& pl, hipStream_t st) {
     switch (pl.cfg) {
-        case 0: if constexpr (VA == 4 && VB == 4) { if (sscg_conv_precision == 1) return launch_wg<2, 2, 2, 2, VA, VB, true, true>(p, pl.splits, st); }
+        case 0: if (sscg_conv_precision == 1) return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4), true>(p, pl.splits, st);
                 return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);   // LDS-DMA staging when vectorisable
-        case 1: if constexpr (VA == 4 && VB == 4) { if (sscg_conv_precision == 1) return launch_wg<2, 2, 1, 1, VA, VB, true, true>(p, pl.splits, st); }
+        case 1: if (sscg_conv_precision == 1) return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4), true>(p, pl.splits, st);
                 return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);
-        case 2: return launch_wg<1, 4, 1, 1, VA, VB>(p, pl.splits, st);
-        case 3: return launch_wg<4, 1, 1, 1, VA, VB>(p, pl.splits, st);
+        case 2: if (sscg_conv_precision == 1) return launch_wg<1, 4, 1, 1, VA, VB, false, true>(p, pl.splits, st);
+                return launch_wg<1, 4, 1, 1, VA, VB>(p, pl.splits, st);
+        case 3: if (sscg_conv_precision == 1) return launch_wg<4, 1, 1, 1, VA, VB, false, true>(p, pl.splits, st);
+                return launch_wg<4, 1, 1, 1, VA, VB>(p, pl.splits, st);
         default: return SSCG_ERR_BAD_ARG;
     }
 }
