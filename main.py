@@ -42,6 +42,10 @@ def get_args(argv=None):
                         help="real: the datasets under ./data (reference layout); synthetic: seeded random batches; auto: real if present")
     parser.add_argument("--dtype", type=str, choices=["f32", "bf16"], default="f32",
                         help="conv contraction arithmetic: exact fp32 MFMA, or bf16 operands with fp32 accumulation")
+    parser.add_argument("--honour_nets", type=int, default=0,
+                        help="1: build the generators / discriminators --gen_net / --dis_net name (the reference ignores both flags)")
+    parser.add_argument("--variants", type=str, default="",
+                        help="comma list of loss terms the reference has commented out: l1_cycle, lab_gt_dis")
     parser.add_argument("--testing_gen", type=str, default="resnet_9blocks_softmax",
                         help="generator testing.py builds (the reference hard-codes resnet_9blocks_softmax, testing.py:40)")
     return parser.parse_args(argv)

@@ -35,10 +35,21 @@ class semisuper_cycleGAN(object):
         C, ids = self.n_channels, args.gpu_ids
         drop = not args.no_dropout
         # construction order = the reference's (model.py:215-230)
-        self.Gis = define_Gen(input_nc=C, output_nc=3, ngf=args.ngf, netG='deeplab', norm=args.norm, use_dropout=drop, gpu_ids=ids)
-        self.Gsi = define_Gen(input_nc=3, output_nc=C, ngf=args.ngf, netG='deeplab', norm=args.norm, use_dropout=drop, gpu_ids=ids)
-        self.Di = define_Dis(input_nc=3, ndf=args.ndf, netD='pixel', n_layers_D=3, norm=args.norm, gpu_ids=ids)
-        self.Ds = define_Dis(input_nc=C, ndf=args.ndf, netD='pixel', n_layers_D=3, norm=args.norm, gpu_ids=ids)
+        # The reference hard-codes 'deeplab' / 'pixel' and never reads --gen_net / --dis_net (model.py:215-222).  Opt-in
+        # (SURVEY 8(f) N4): --honour_nets 1 builds what the flags name; --variants enables loss terms that are commented
+        # out in the reference (l1_cycle: model.py:453; lab_gt_dis: :439,:447).  Defaults reproduce the reference.
+        honour = bool(getattr(args, "honour_nets", 0))
+        gen = args.gen_net if honour else 'deeplab'
+        dis = args.dis_net if honour else 'pixel'
+        self.variants = set(v for v in str(getattr(args, "variants", "") or "").split(",") if v)
+        unknown = self.variants - {"l1_cycle", "lab_gt_dis"}
+        if unknown:
+            raise ValueError("unknown --variants %s (perceptual loss needs VGG16 weights; the Gaussian-noise branch is dead code, "
+                             "model.py:486-488)" % sorted(unknown))
+        self.Gis = define_Gen(input_nc=C, output_nc=3, ngf=args.ngf, netG=gen, norm=args.norm, use_dropout=drop, gpu_ids=ids)
+        self.Gsi = define_Gen(input_nc=3, output_nc=C, ngf=args.ngf, netG=gen, norm=args.norm, use_dropout=drop, gpu_ids=ids)
+        self.Di = define_Dis(input_nc=3, ndf=args.ndf, netD=dis, n_layers_D=3, norm=args.norm, gpu_ids=ids)
+        self.Ds = define_Dis(input_nc=C, ndf=args.ndf, netD=dis, n_layers_D=3, norm=args.norm, gpu_ids=ids)
         self.old_Gis = define_Gen(input_nc=C, output_nc=3, ngf=args.ngf, netG='resnet_9blocks', norm=args.norm, use_dropout=drop, gpu_ids=ids)
         self.old_Gsi = define_Gen(input_nc=3, output_nc=C, ngf=args.ngf, netG='resnet_9blocks_softmax', norm=args.norm, use_dropout=drop, gpu_ids=ids)
         self.old_Di = define_Dis(input_nc=3, ndf=args.ndf, netD='pixel', n_layers_D=3, norm=args.norm, gpu_ids=ids)
@@ -166,6 +177,16 @@ class semisuper_cycleGAN(object):
         else:
             fake_img, fake_img_d, fake_img_l1 = F.split(fake_img, 3)                 # consumers: Gsi, Di, L1
             recon_gt = self.interp(self.Gsi(fake_img))                               # :410,415
+        extra_terms, extra_weights, extras = [], [], {}
+        if "l1_cycle" in self.variants:                                              # :453 (commented out in the reference)
+            recon_img, recon_img_l1 = F.split(recon_img, 2)
+            extras["img_cycle_l1"] = F.l1_loss(recon_img_l1, unl_img)
+            extra_terms.append(extras["img_cycle_l1"])
+            extra_weights.append(a.lamda_img)
+        if "lab_gt_dis" in self.variants:                                            # :439,:447 (commented out)
+            extras["gt_label_gen_loss"] = F.mse_const(self.Ds(lab_gt), 1.0)
+            extra_terms.append(extras["gt_label_gen_loss"])
+            extra_weights.append(a.adversarial_weight)
         fake_img_dis = self.Di(fake_img_d)                                           # :431
         resnet_fake_img_dis = self.old_Di(recon_img)                                 # :432
         fake_gt_onehot, _ = F.argmax_onehot(fake_gt.detach())                        # :435-437 (no gradient path)
@@ -177,8 +198,8 @@ class semisuper_cycleGAN(object):
         lab_loss_MSE = F.l1_loss(fake_img_l1, l_img)                                 # :461
         # :464-468  gen_loss = CE_w*CE + MSE_w*L1 + adv_w*(img_gen + gt_gen) + img_cycle + lamda_gt*gt_cycle
         gen_loss = F.weighted_sum(
-            [lab_loss_CE, lab_loss_MSE, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss],
-            [a.lab_CE_weight, a.lab_MSE_weight, a.adversarial_weight, a.adversarial_weight, 1.0, a.lamda_gt])
+            [lab_loss_CE, lab_loss_MSE, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss] + extra_terms,
+            [a.lab_CE_weight, a.lab_MSE_weight, a.adversarial_weight, a.adversarial_weight, 1.0, a.lamda_gt] + extra_weights)
         gen_loss.backward()                                                          # :472
         F.ForkStream.join(l_img.device)
         F.SideStream.join(l_img.device)            # side stream: weight gradients + frozen generators are complete
@@ -223,7 +244,9 @@ class semisuper_cycleGAN(object):
             self.g_optimizer.step()                                                  # :474 (deferred: no D-step op reads G weights)
         vals = (img_dis_loss, gt_dis_loss, cycle_img_dis_loss, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss,
                 lab_loss_CE, lab_loss_MSE)
-        return {k: v.detach() for k, v in zip(LOSS_KEYS, vals)}
+        out = {k: v.detach() for k, v in zip(LOSS_KEYS, vals)}
+        out.update({k: v.detach() for k, v in extras.items()})
+        return out
 
     # ------------------------------------------------------------------------------------------ evaluation (model.py:555-574)
     @torch.no_grad()
