@@ -56,7 +56,6 @@ def main():
     F = importlib.import_module(PKG + ".functional")
     par = importlib.import_module(PKG + ".parallel")
     data = importlib.import_module(PKG + ".data")
-    from oracle import fixtures as FX   # only make_args (namespace of CLI defaults) and, below, the CPU baseline
 
     # SSCG_FORCE_DP=1 exercises the RCCL code path (init, broadcast, all-reduce) on a single rank
     dp = par.DataParallel() if (world > 1 or os.environ.get("SSCG_FORCE_DP")) else None
@@ -66,8 +65,11 @@ def main():
     dev = torch.device("cuda", local)
     bsz = a.batch
 
-    args = FX.make_args(dataset="voc2012", crop_height=H, crop_width=W, batch_size=bsz, gpu_ids=[local], no_dropout=False,
-                        checkpoint_dir="/tmp/sscg_bench_ckpt_%d" % rank, as_written=True, epochs=400, decay_epoch=100)
+    import main as cli                   # the product CLI's own defaults (oracle/ is used by the cpu_baseline leg only)
+    args = cli.get_args(["--model", "semisupervised_cycleGAN", "--dataset", "voc2012", "--crop_height", str(H), "--crop_width", str(W),
+                         "--batch_size", str(bsz), "--checkpoint_dir", "/tmp/sscg_bench_ckpt_%d" % rank, "--epochs", "400",
+                         "--decay_epoch", "100", "--dtype", a.dtype])
+    args.gpu_ids, args.as_written = [local], True
     torch.manual_seed(0)
     F.set_conv_precision(a.dtype)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -231,7 +233,7 @@ def pmc_traffic():
 
 def cpu_baseline():
     """oracle/ = CPU restatement of the reference step (validated bit-exact against the reference's losses by
-    tools/gen_golden.py), timed on this box's host cores: one step at the bench geometry with batch 2."""
+    tests/golden/gen_golden.py), timed on this box's host cores: one step at the bench geometry with batch 2."""
     import numpy as np
     import torch
     from oracle import fixtures as FX

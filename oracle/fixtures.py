@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (see oracle/__init__.py) - the shared recipe for golden inputs: which networks, which
-shapes, which keyed streams.  tools/gen_golden.py (build container, with the reference) and tests/ (anywhere)
+shapes, which keyed streams.  tests/golden/gen_golden.py (build container, with the reference) and tests/ (anywhere)
 regenerate identical inputs/weights from here, so fixtures only store outputs."""
 import types
 
@@ -118,7 +118,7 @@ BLOCK_INPUT = {"cls": ("g1/x2048", (2, 2048, 5, 5))}   # every other block uses 
 
 
 def block_state(name, dtype=torch.float32):
-    """Keyed weights of a G1 block - the rule tools/gen_golden.py applies to the reference module's state dict."""
+    """Keyed weights of a G1 block - the rule tests/golden/gen_golden.py applies to the reference module's state dict."""
     sd = {}
     for k, shape in BLOCK_SPECS[name].items():
         key = "g1/%s/%s" % (name, k)

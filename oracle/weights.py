@@ -1,7 +1,7 @@
 """Deterministic, torch-RNG-independent tensor generator keyed by (seed, name).
 
 Weights for the nets are 11-44 M parameters: they are never committed.  Both the reference modules
-(in tools/gen_golden.py) and the build's modules are loaded from this generator, so a golden vector
+(in tests/golden/gen_golden.py) and the build's modules are loaded from this generator, so a golden vector
 only needs (seed, net kind, shapes).  Arithmetic: splitmix64 counter hash -> uniform -> Box-Muller,
 all in numpy uint64/float64 (version independent)."""
 import hashlib

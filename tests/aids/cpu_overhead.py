@@ -1,6 +1,6 @@
 """How long does the host need to *issue* one step (launch-side cost) vs the GPU to execute it?  (tuning aid)"""
 import contextlib, importlib, io, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import fixtures as FX
 md = importlib.import_module("semi-supervised-segmentation-cyclegan_amd.model")

@@ -8,7 +8,7 @@ modules with load_state_dict(strict=True), and
      per block, per network, and for whole training steps of `semisuper_cycleGAN.train`;
   2. writes small fixtures (inputs are regenerated from the keyed generator, so mostly outputs only)
      to tests/golden/*.npz + tests/golden/meta.json.
-No reference source is copied: fixtures are numbers.  Usage: python tools/gen_golden.py
+No reference source is copied: fixtures are numbers.  Usage: python tests/golden/gen_golden.py
 """
 import json
 import os
@@ -19,7 +19,7 @@ import warnings
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 sys.dont_write_bytecode = True
 sys.path.insert(0, ROOT)

@@ -1,4 +1,4 @@
-"""Network- and step-level parity of the HIP path against the golden vectors that tools/gen_golden.py took
+"""Network- and step-level parity of the HIP path against the golden vectors that tests/golden/gen_golden.py took
 from the real reference (tests/golden/), plus the live oracle.  Tolerances follow SURVEY App. D:
 InstanceNorm nets are held to 1e-4 against the fp64 golden; DeepLab-chained quantities are held to
 k x (the reference's own fp32-vs-fp64 distance), never looser than north_star's 1e-3."""

@@ -1,5 +1,5 @@
 """oracle/ (the CPU restatement) against the golden vectors taken from the real reference by
-tools/gen_golden.py.  Runs anywhere (no GPU, no /root/reference).  The generator recorded its thread count;
+tests/golden/gen_golden.py.  Runs anywhere (no GPU, no /root/reference).  The generator recorded its thread count;
 fp32 comparisons allow for a different count here (thread count moves fp32 sums)."""
 import json
 import os
