@@ -52,3 +52,32 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), f
+
+
+def test_argument_errors_are_returned_not_raised():
+    """include/sscg.h: "return value: 0 = ok, <0 = library error (SSCG_ERR_*), >0 = hipError_t.  Never throws/aborts."
+    Argument checks come before any HIP call, so they can be exercised without a GPU."""
+    import ctypes as C
+    L = load_sub("_lib")
+    lib = L.lib
+    BAD_ARG, UNSUPPORTED, WORKSPACE = -1, -2, -3
+    d = L.ConvDesc(N=2, H=16, W=16, C=32, K=32, R=3, S=3, P=16, Q=16, stride=1, pad=1, dil=1, pad_mode=0, act=0, slope=0.0)
+    assert lib.sscg_conv2d_fwd(C.byref(d), None, None, None, None, None, 0, None) == BAD_ARG          # null tensors
+    assert lib.sscg_conv2d_fwd(None, None, None, None, None, None, 0, None) == BAD_ARG                # null descriptor
+    assert lib.sscg_conv2d_wgrad(C.byref(d), None, None, None, 0.0, None, 0, None) == BAD_ARG
+    big = L.ConvDesc(N=64, H=4096, W=4096, C=64, K=64, R=1, S=1, P=4096, Q=4096, stride=1, pad=0, dil=1, pad_mode=0, act=0, slope=0.0)
+    one = C.c_void_p(16)                                                                              # never dereferenced
+    assert lib.sscg_conv2d_wgrad(C.byref(big), one, one, one, 0.0, None, 0, None) == UNSUPPORTED      # >= 2^31 elements
+    # a split plan needs its workspace: the bench-size DeepLab conv without one is refused before any launch
+    dl = L.ConvDesc(N=8, H=33, W=33, C=256, K=256, R=3, S=3, P=33, Q=33, stride=1, pad=2, dil=2, pad_mode=0, act=0, slope=0.0)
+    assert lib.sscg_conv2d_fwd_workspace(C.byref(dl)) > 0 and lib.sscg_conv2d_wgrad_workspace(C.byref(dl)) > 0
+    assert lib.sscg_conv2d_fwd(C.byref(dl), one, one, None, one, None, 0, None) == WORKSPACE
+    assert lib.sscg_conv2d_wgrad(C.byref(dl), one, one, one, 0.0, None, 0, None) == WORKSPACE
+    # normalisation / class ops / optimiser / input pipeline
+    assert lib.sscg_norm_stats(None, 1, 10, 4, 1e-5, None, None, None, None, 0.1, None, 0, None) == BAD_ARG
+    assert lib.sscg_norm_apply(one, one, one, one, None, None, one, 1, 10, 4, 0, 0.0, None) == BAD_ARG  # gamma without beta
+    assert lib.sscg_softmax_fwd(None, None, 10, 4, None) == BAD_ARG
+    assert lib.sscg_confusion_hist(one, one, 10, 65, one, None) == BAD_ARG                            # C > 64
+    assert lib.sscg_label_lut(one, one, 10, None, None) == BAD_ARG
+    assert lib.sscg_set_conv_precision(7) == BAD_ARG and lib.sscg_get_conv_precision() == 0
+    assert lib.sscg_set_conv_precision(1) == 0 and lib.sscg_get_conv_precision() == 1 and lib.sscg_set_conv_precision(0) == 0
