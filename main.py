@@ -55,6 +55,7 @@ def main(argv=None):
     args = get_args(argv)
     args.gpu_ids = [int(s) for s in args.gpu_ids.split(",") if int(s) >= 0]
     args.as_written = bool(args.as_written)
+    args.overlap_d = True                # train() reads the losses after sync_losses()
     if args.crop_height is None and args.crop_width is None:
         args.crop_height, args.crop_width = DEFAULT_CROP[args.dataset]
     md = importlib.import_module(PKG + ".model")

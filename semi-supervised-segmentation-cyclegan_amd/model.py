@@ -67,6 +67,10 @@ class semisuper_cycleGAN(object):
         self.as_written = getattr(args, "as_written", True)         # keep the reference's unused forwards
         self.fork_forward = getattr(args, "fork_forward", True)     # two stream lanes for the trainable generator passes
         self.stack_gsi = getattr(args, "stack_gsi", True)           # the two independent Gsi passes as one grouped-BN pass
+        # D step on its own stream: it then overlaps the NEXT step's generator forwards (which read no discriminator
+        # weight until :431).  Opt-in, because the three discriminator losses a step returns are then produced on that
+        # stream: callers read them after `sync_losses()` (train() and bench.py do).
+        self.overlap_d = bool(getattr(args, "overlap_d", False))
         self.dp = data_parallel
 
         self.g_optimizer = FusedAdam(itertools.chain(self.Gis.parameters(), self.Gsi.parameters()), lr=args.lr, betas=(0.5, 0.999))
@@ -187,6 +191,8 @@ class semisuper_cycleGAN(object):
             extras["gt_label_gen_loss"] = F.mse_const(self.Ds(lab_gt), 1.0)
             extra_terms.append(extras["gt_label_gen_loss"])
             extra_weights.append(a.adversarial_weight)
+        if self.overlap_d:      # the previous step's discriminator update (on the D stream) must have landed
+            torch.cuda.current_stream(dev).wait_stream(F.ForkStream.get(dev, "d"))
         fake_img_dis = self.Di(fake_img_d)                                           # :431
         resnet_fake_img_dis = self.old_Di(recon_img)                                 # :432
         fake_gt_onehot, _ = F.argmax_onehot(fake_gt.detach())                        # :435-437 (no gradient path)
@@ -213,6 +219,34 @@ class semisuper_cycleGAN(object):
             F.run_on_side_stream(l_img.device, (), F.refresh_transposed_weights)
 
         # ---- discriminators (model.py:477-542)
+        if self.overlap_d:
+            main_s, d_s = torch.cuda.current_stream(dev), F.ForkStream.get(dev, "d")
+            d_s.wait_stream(main_s)
+            for t in (recon_img, fake_img, fake_gt, unl_img, onehot_gt, resnet_recon_img):
+                t.record_stream(d_s)
+            with torch.cuda.stream(d_s):
+                d_vals = self._d_step(a, recon_img, fake_img, fake_gt, unl_img, onehot_gt, resnet_recon_img)
+            if self.dp is not None:
+                self.dp.wait(g_works)
+                self.g_optimizer.step()                                              # :474 (deferred past the all-reduce)
+        else:
+            d_vals = self._d_step(a, recon_img, fake_img, fake_gt, unl_img, onehot_gt, resnet_recon_img)
+            if self.dp is not None:
+                self.dp.wait(g_works)
+                self.g_optimizer.step()                                              # :474 (deferred: no D-step op reads G weights)
+        vals = d_vals + (img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss, lab_loss_CE, lab_loss_MSE)
+        out = {k: v.detach() for k, v in zip(LOSS_KEYS, vals)}
+        out.update({k: v.detach() for k, v in extras.items()})
+        return out
+
+    def sync_losses(self):
+        """Make the current stream wait for the discriminator stream (overlap_d): call before reading a step's losses."""
+        if self.overlap_d:
+            dev = torch.device("cuda", self.args.gpu_ids[0])
+            torch.cuda.current_stream(dev).wait_stream(F.ForkStream.get(dev, "d"))
+
+    def _d_step(self, a, recon_img, fake_img, fake_gt, unl_img, onehot_gt, resnet_recon_img):
+        l_img = unl_img
         set_grad([self.Di, self.Ds], True)
         set_grad([self.old_Di], self.as_written)   # old_Di is in no optimiser: its wgrad only exists in the as-written graph
         self.d_optimizer.zero_grad()
@@ -239,14 +273,7 @@ class semisuper_cycleGAN(object):
         if self.dp is not None:
             self.dp.sync_grads(self.d_optimizer)
         self.d_optimizer.step()                                                      # :542
-        if self.dp is not None:
-            self.dp.wait(g_works)
-            self.g_optimizer.step()                                                  # :474 (deferred: no D-step op reads G weights)
-        vals = (img_dis_loss, gt_dis_loss, cycle_img_dis_loss, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss,
-                lab_loss_CE, lab_loss_MSE)
-        out = {k: v.detach() for k, v in zip(LOSS_KEYS, vals)}
-        out.update({k: v.detach() for k, v in extras.items()})
-        return out
+        return (img_dis_loss, gt_dis_loss, cycle_img_dis_loss)
 
     # ------------------------------------------------------------------------------------------ evaluation (model.py:555-574)
     @torch.no_grad()
@@ -286,6 +313,7 @@ class semisuper_cycleGAN(object):
                 losses = self.step(l_img, l_gt, unl_img)
                 done += 1
                 if (i % log_every == 0) and rank0:
+                    self.sync_losses()
                     vals = torch.stack([losses[k] for k in LOSS_KEYS]).cpu().tolist()   # the only host sync of the step
                     rec = dict(zip(LOSS_KEYS, vals))
                     history.append(rec)
@@ -300,6 +328,7 @@ class semisuper_cycleGAN(object):
                         writer.add_scalars('Labelled Loss', {k: rec[k] for k in LOSS_KEYS[7:9]}, it)
                 if max_steps is not None and done >= max_steps:
                     return history
+            self.sync_losses()                       # the last discriminator update is visible to what follows on this stream
             if val_loader is not None:
                 miou, class_iou = self.evaluate(val_loader)
                 if rank0:

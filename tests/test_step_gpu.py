@@ -216,3 +216,31 @@ def test_opt_in_nets_and_loss_variants(dev):
     assert all(bool(torch.isfinite(v)) for v in out.values())
     for k, w0 in before.items():
         assert not torch.equal(next(getattr(m, k).parameters()).detach(), w0), k
+
+
+def test_overlapped_d_step_is_bit_identical_to_the_serial_schedule(dev):
+    """overlap_d: the discriminator step runs on its own stream beside the next step's generator forwards.  Same
+    arithmetic in the same order per tensor => identical losses and weights after three steps."""
+    md = load_sub("model")
+    res = []
+    for overlap in (False, True):
+        args = FX.make_args(dataset="voc2012", crop_height=64, crop_width=64, batch_size=2, gpu_ids=[dev.index or 0],
+                            checkpoint_dir="/tmp/sscg_test_ckpt_ov", as_written=True)
+        args.overlap_d = overlap
+        m = quiet(md.semisuper_cycleGAN, args)
+        for k, sd in FX.semisup_state_dicts(21, torch.float32, "s64").items():
+            getattr(m, k).load_state_dict(sd, strict=True)
+        np.random.seed(0)
+        hist = []
+        for s in range(3):
+            l_img, l_gt, unl_img = FX.step_batch("s64", s, 21, 64, 64, 2)
+            out = m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev))
+            m.sync_losses()
+            hist.append({k: float(v) for k, v in out.items()})
+        torch.cuda.synchronize()
+        res.append((hist, {k: v.detach().clone() for k, v in m.Di.state_dict().items()},
+                    m.Gsi.state_dict()["conv1.weight"].detach().clone()))
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    assert torch.equal(res[0][2], res[1][2])
