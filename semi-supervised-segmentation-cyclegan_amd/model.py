@@ -253,6 +253,9 @@ class semisuper_cycleGAN(object):
         recon_img_p = self.pools[0]([recon_img.detach()])[0]                         # :490
         fake_img_p = self.pools[1]([fake_img.detach()])[0]                           # :491
         fake_gt_p = self.pools[2]([fake_gt.detach()])[0]                             # :493
+        if self.overlap_d:      # a pool may hand back a tensor of an earlier step (allocated on the main stream)
+            for t in (recon_img_p, fake_img_p, fake_gt_p):
+                t.record_stream(torch.cuda.current_stream(t.device))
         unl_img_dis = self.Di(unl_img)                                               # :499
         fake_img_dis = self.Di(fake_img_p)                                           # :500
         resnet_recon_img_dis = self.old_Di(resnet_recon_img)                         # :501
