@@ -154,13 +154,16 @@ def test_many_steps_stay_finite_and_do_not_fault(dev):
     per-step transposed-weight copies happened to land at the end of an allocator segment: 40 steps re-create
     those copies 80 times.  Also checks that the losses stay finite and the discriminator terms move."""
     m, _ = make_model(dev, "many")
+    m.overlap_d = True          # the schedule main.py trains with: D step on its own stream, overlapping the next G forwards
     batch = [t.to(dev) for t in FX.step_batch("many", 0, 21, 64, 64, 2)]
     np.random.seed(0)
     first = last = None
     for it in range(40):
         out = m.step(*batch)
         if it == 0:
+            m.sync_losses()
             first = {k: float(v) for k, v in out.items()}
+    m.sync_losses()
     last = {k: float(v) for k, v in out.items()}
     assert all(np.isfinite(v) for v in last.values())
     assert last["lab_loss_CE"] < first["lab_loss_CE"]          # training on a fixed batch reduces the supervised loss
