@@ -70,7 +70,7 @@ def main():
                          "--batch_size", str(bsz), "--checkpoint_dir", "/tmp/sscg_bench_ckpt_%d" % rank, "--epochs", "400",
                          "--decay_epoch", "100", "--dtype", a.dtype])
     args.gpu_ids, args.as_written = [local], True
-    args.overlap_d = True                # the D step overlaps the next step's generator forwards (what main.py trains with)
+    args.overlap_d = os.environ.get("SSCG_OVERLAP_D", "1") == "1"   # the D step overlaps the next step's generator forwards
     torch.manual_seed(0)
     F.set_conv_precision(a.dtype)
     with contextlib.redirect_stdout(io.StringIO()):

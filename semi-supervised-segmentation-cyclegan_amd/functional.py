@@ -66,18 +66,20 @@ class SideStream:
     enabled = True
     _streams = {}
 
+    lanes = int(os.environ.get("SSCG_SIDE_LANES", "2"))   # measured: 4 streams in flight (main, fork lane, 2 side lanes) is the sweet spot; a 5th costs 20 %
+
     @classmethod
-    def get(cls, device):
-        s = cls._streams.get(device)
+    def get(cls, device, lane=0):
+        s = cls._streams.get((device, lane))
         if s is None:
             s = torch.cuda.Stream(device=device)
-            cls._streams[device] = s
+            cls._streams[(device, lane)] = s
         return s
 
     @classmethod
     def join(cls, device=None):
         """Make the current stream wait for everything queued on the side stream(s)."""
-        for dev, s in cls._streams.items():
+        for (dev, _), s in cls._streams.items():
             if device is None or dev == device:
                 torch.cuda.current_stream(dev).wait_stream(s)
 
@@ -105,13 +107,20 @@ class ForkStream:
                 torch.cuda.current_stream(device).wait_stream(s)
 
 
-def run_on_side_stream(device, tensors, fn):
+def d_stream(device):
+    """Stream of the overlapped discriminator step: the LAST side lane - idle between the end of a backward pass and
+    the next one, which is when the D step runs.  Not a stream of its own: a fifth stream in flight costs ~20 % (the
+    hardware runs four queues side by side; more are time-sliced)."""
+    return SideStream.get(device, SideStream.lanes - 1)
+
+
+def run_on_side_stream(device, tensors, fn, lane=0):
     """Launch `fn`'s kernels on the side stream after everything queued so far on the current stream.
     `tensors` are the buffers fn reads: the allocator must not recycle them before the side stream is done."""
     if not SideStream.enabled:
         return fn()
     main = torch.cuda.current_stream(device)
-    side = SideStream.get(device)
+    side = SideStream.get(device, lane % SideStream.lanes)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         r = fn()
@@ -609,7 +618,7 @@ class Conv2dFn(torch.autograd.Function):
 
         if wacc is not None or bacc is not None:
             # nothing on the backward critical path reads these: run them beside the data-gradient chain
-            run_on_side_stream(dy.device, (x, dy), arena_grads)
+            run_on_side_stream(dy.device, (x, dy), arena_grads, lane=getattr(ctx.wref, "_sscg_lane", 0))
         if want_w and wacc is None:
             dw = conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode)
         if want_b and bacc is None:

@@ -192,7 +192,7 @@ class semisuper_cycleGAN(object):
             extra_terms.append(extras["gt_label_gen_loss"])
             extra_weights.append(a.adversarial_weight)
         if self.overlap_d:      # the previous step's discriminator update (on the D stream) must have landed
-            torch.cuda.current_stream(dev).wait_stream(F.ForkStream.get(dev, "d"))
+            torch.cuda.current_stream(dev).wait_stream(F.d_stream(dev))
         fake_img_dis = self.Di(fake_img_d)                                           # :431
         resnet_fake_img_dis = self.old_Di(recon_img)                                 # :432
         fake_gt_onehot, _ = F.argmax_onehot(fake_gt.detach())                        # :435-437 (no gradient path)
@@ -220,7 +220,7 @@ class semisuper_cycleGAN(object):
 
         # ---- discriminators (model.py:477-542)
         if self.overlap_d:
-            main_s, d_s = torch.cuda.current_stream(dev), F.ForkStream.get(dev, "d")
+            main_s, d_s = torch.cuda.current_stream(dev), F.d_stream(dev)
             d_s.wait_stream(main_s)
             for t in (recon_img, fake_img, fake_gt, unl_img, onehot_gt, resnet_recon_img):
                 t.record_stream(d_s)
@@ -243,7 +243,7 @@ class semisuper_cycleGAN(object):
         """Make the current stream wait for the discriminator stream (overlap_d): call before reading a step's losses."""
         if self.overlap_d:
             dev = torch.device("cuda", self.args.gpu_ids[0])
-            torch.cuda.current_stream(dev).wait_stream(F.ForkStream.get(dev, "d"))
+            torch.cuda.current_stream(dev).wait_stream(F.d_stream(dev))
 
     def _d_step(self, a, recon_img, fake_img, fake_gt, unl_img, onehot_gt, resnet_recon_img):
         l_img = unl_img

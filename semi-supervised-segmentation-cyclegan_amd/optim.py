@@ -53,6 +53,7 @@ class FusedAdam(torch.optim.Optimizer):
             p._sscg_grad = g
             p._sscg_touched = False
             p._sscg_epoch = self._epoch
+            p._sscg_lane = len(self.slices)      # side-stream lane of this parameter's gradient kernels (all of them: they accumulate)
             p.grad = g
             off += self._padded(n)
 
