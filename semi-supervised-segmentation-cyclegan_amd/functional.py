@@ -23,8 +23,12 @@ CL = torch.channels_last
 
 
 # ----------------------------------------------------------------------------- plumbing
+_raw_stream = torch._C._cuda_getCurrentRawStream     # the handle only: torch.cuda.current_stream() builds a Stream object (~6 us)
+_cur_dev = torch.cuda.current_device
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(_cur_dev())
 
 
 def _ptr(t):
@@ -46,7 +50,7 @@ class _Workspace:
 
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 16)
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, _raw_stream(device.index if device.index is not None else _cur_dev()))
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
@@ -183,7 +187,25 @@ def conv_out_size(h, k, stride, pad, dil):
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
+_DESC_CACHE = {}
+
+
 def make_desc(xshape, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0):
+    """ConvDesc of a call, memoised (a step re-issues the same few dozen geometries thousands of times, and the host side
+    of a launch is what bounds the 4-stream schedule)."""
+    key = (tuple(xshape), tuple(wshape), stride, pad, dil, pad_mode, act, slope)
+    d = _DESC_CACHE.get(key)
+    if d is None:
+        d = _DESC_CACHE[key] = _build_desc(xshape, wshape, stride, pad, dil, pad_mode, act, slope)
+    return d
+
+
+def _ws_bytes(d, which):
+    """Workspace size of a conv entry point (asked every time: the split plans also depend on the debug hooks)."""
+    return getattr(lib, "sscg_conv2d_%s_workspace" % which)(C.byref(d))
+
+
+def _build_desc(xshape, wshape, stride, pad, dil, pad_mode, act, slope):
     n, c, h, w = xshape
     k, c2, r, s = wshape
     if c != c2:
@@ -248,7 +270,7 @@ def _timed(kind, d, fn):
 def conv2d_fwd(x, w, bias, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0):
     d = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, act, slope)
     y = empty_nhwc(d.N, d.K, d.P, d.Q, x.device)
-    ws = _WS.get(lib.sscg_conv2d_fwd_workspace(C.byref(d)), x.device)
+    ws = _WS.get(_ws_bytes(d, "fwd"), x.device)
     _timed("fwd", d, lambda: check(lib.sscg_conv2d_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(),
                                                        ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_fwd"))
     return y
@@ -265,7 +287,7 @@ def weight_transposed(w):
 def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0):
     d = make_desc(xshape, wshape, stride, pad, dil)
     dx = empty_nhwc(d.N, d.C, d.H, d.W, dy.device)
-    ws = _WS.get(lib.sscg_conv2d_dgrad_workspace(C.byref(d)), dy.device)
+    ws = _WS.get(_ws_bytes(d, "dgrad"), dy.device)
     _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wt.data_ptr(), _ptr(bias), dx.data_ptr(),
                                                            act, slope, ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_dgrad"))
     return dx
@@ -277,8 +299,7 @@ def conv2d_wgrad(x, dy, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, out=None, 
         k, c, r, s = wshape
         out = torch.empty((k, c, r, s), dtype=x.dtype, device=x.device, memory_format=CL)
         accumulate = False
-    nb = lib.sscg_conv2d_wgrad_workspace(C.byref(d))
-    ws = _WS.get(nb, x.device)
+    ws = _WS.get(_ws_bytes(d, "wgrad"), x.device)
     _timed("wgrad", d, lambda: check(lib.sscg_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), out.data_ptr(),
                                                            1.0 if accumulate else 0.0, ws.data_ptr(), ws.numel(), _stream()),
                                      "sscg_conv2d_wgrad"))
@@ -289,11 +310,23 @@ def colsum(x2d_rows, cols, x, out=None, accumulate=False):
     if out is None:
         out = torch.empty(cols, dtype=torch.float32, device=x.device)
         accumulate = False
-    nb = lib.sscg_colsum_workspace(x2d_rows, cols)
+    nb = _cached_size(lib.sscg_colsum_workspace, x2d_rows, cols)
     ws = _WS.get(nb, x.device)
     check(lib.sscg_colsum(x.data_ptr(), out.data_ptr(), x2d_rows, cols, 1.0 if accumulate else 0.0, ws.data_ptr(),
                           ws.numel(), _stream()), "sscg_colsum")
     return out
+
+
+_SIZE_CACHE = {}
+
+
+def _cached_size(fn, *args):
+    """Workspace size queries that depend on the geometry alone (no tuning hook changes them)."""
+    key = (id(fn),) + args
+    v = _SIZE_CACHE.get(key)
+    if v is None:
+        v = _SIZE_CACHE[key] = fn(*args)
+    return v
 
 
 def _glc(x, per_sample):
@@ -312,7 +345,7 @@ def norm_stats(x, per_sample, eps=1e-5, running_mean=None, running_var=None, mom
     g, l, c = _glc(x, per_sample)
     mean = torch.empty((g, c), dtype=torch.float32, device=x.device)
     rstd = torch.empty((g, c), dtype=torch.float32, device=x.device)
-    nb = lib.sscg_norm_stats_workspace(g, l, c)
+    nb = _cached_size(lib.sscg_norm_stats_workspace, g, l, c)
     ws = _WS.get(nb, x.device)
     check(lib.sscg_norm_stats(x.data_ptr(), g, l, c, eps, mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean),
                               _ptr(running_var), momentum, ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_stats")
@@ -332,7 +365,7 @@ def norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad=Tru
     g, l, c = _glc(x, per_sample)
     dx = torch.empty_like(x, memory_format=CL)
     dres = torch.empty_like(x, memory_format=CL) if want_dres else None
-    nb = lib.sscg_norm_bwd_workspace(g, l, c)
+    nb = _cached_size(lib.sscg_norm_bwd_workspace, g, l, c)
     ws = _WS.get(nb, x.device)
     check(lib.sscg_norm_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
                             dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), g, l, c, act, slope,
