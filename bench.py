@@ -36,7 +36,7 @@ C, H, W, B = 21, 256, 256, 8
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -210,11 +210,11 @@ def main():
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01n_pmc_per_kernel.json:
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01q_pmc_per_kernel.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command).  Units and the gfx950
     correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes: counters are KiB; FETCH_SIZE under-reports wide
     coalesced reads by 2x.  The live bench cannot collect PMC itself, hence the file."""
-    path = os.path.join(ROOT, "profiles", "r01n_pmc_per_kernel.json")
+    path = os.path.join(ROOT, "profiles", "r01q_pmc_per_kernel.json")
     if not os.path.exists(path):
         return {"traffic": None}
     d = json.load(open(path))
@@ -228,7 +228,7 @@ def pmc_traffic():
                 busy += cs["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"]
                 act += cs["GRBM_GUI_ACTIVE"]["sum"]
     return {"traffic": round(tot_b / max(tot_n, 1)), "traffic_unit": "HBM bytes per conv_kc launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
-            "traffic_source": "profiles/r01n_pmc_per_kernel.json",
+            "traffic_source": "profiles/r01q_pmc_per_kernel.json",
             "mfma_util_pmc": round(busy / max(act / 8.0 * 1024.0, 1.0), 4)}   # GRBM_GUI_ACTIVE is summed over the 8 XCDs, busy cycles over 1024 SIMDs
 
 
