@@ -173,3 +173,43 @@ def test_main_trains_from_the_real_pipeline_and_checkpoints(tmp_path, dev, monke
     ck = torch.load(str(tmp_path / "ckpt" / "latest_semisuper_cycleGAN.ckpt"), map_location="cpu", weights_only=False)
     assert set(ck) == {'epoch', 'Di', 'Ds', 'Gis', 'Gsi', 'd_optimizer', 'g_optimizer', 'best_iou', 'class_iou'} and ck['epoch'] == 1
     assert np.isfinite(ck['best_iou'])
+
+
+def _cityscapes_tree(root, n_train=8, n_val=3):
+    rng = np.random.RandomState(2)
+    for split, n in (("train", n_train), ("val", n_val)):
+        for i in range(n):
+            city = "aachen" if i % 2 else "bochum"
+            os.makedirs(os.path.join(root, "leftImg8bit", split, city), exist_ok=True)
+            os.makedirs(os.path.join(root, "gtFine", "trainval", city), exist_ok=True)
+            stem = "%s_%06d_000019" % (city, i + (100 if split == "val" else 0))
+            Image.fromarray(rng.randint(0, 256, (40, 80, 3), dtype=np.uint8)).save(
+                os.path.join(root, "leftImg8bit", split, city, stem + "_leftImg8bit.png"))
+            Image.fromarray(rng.randint(0, 34, (40, 80)).astype(np.uint8)).save(
+                os.path.join(root, "gtFine", "trainval", city, stem + "_gtFine_labelIds.png"))
+
+
+def test_cityscapes_layout_label_encoding_and_split(tmp_path, monkeypatch):
+    """CityscapesDataset: file layout (leftImg8bit/<split>/<city>, gtFine/trainval/<city>), the 34 -> 19 + unlabelled
+    encoding (dataloader.py:260-267) on the host path, names, and the seeded disjoint split."""
+    du = load_sub("data_utils")
+    monkeypatch.chdir(tmp_path)
+    root = "./data/Cityscape"                    # the reference's root string: sample names are cut at fixed offsets of it
+    _cityscapes_tree(root)
+    tr = du.get_transformation((32, 64), resize=True, dataset="cityscapes")
+    lab = du.CityscapesDataset(root_path=root, name="label", ratio=0.5, transformation=tr)
+    unl = du.CityscapesDataset(root_path=root, name="unlabel", ratio=0.5, transformation=tr)
+    val = du.CityscapesDataset(root_path=root, name="val", ratio=0.5, transformation=tr)
+    assert len(lab) == len(unl) == 4 and len(val) == 3 and not (set(lab.files["label"]) & set(unl.files["unlabel"]))
+    img, gt, name = lab[0]
+    assert tuple(img.shape) == (3, 32, 64) and tuple(gt.shape) == (1, 32, 64) and gt.dtype == torch.int64
+    assert int(gt.min()) >= 0 and int(gt.max()) <= 19
+    assert "/" not in name and "_000019_leftImg8bit" in name
+    # the label file of a sample is found through the city directory and the 15-character '_leftImg8bit.png' suffix
+    raw = np.asarray(Image.open(lab._paths(lab.items[0])[1]).resize((64, 32), 0))
+    assert torch.equal(gt[0], du.cityscapes_encode(torch.from_numpy(raw.copy()).long()))
+    # device_finish mode hands out the raw ids: the table of DeviceLoader does the encoding
+    trd = du.get_transformation((32, 64), resize=True, dataset="cityscapes", device_finish=True)
+    rawds = du.CityscapesDataset(root_path=root, name="label", ratio=0.5, transformation=trd)
+    _, gt_u8, _ = rawds[0]
+    assert gt_u8.dtype == torch.uint8 and torch.equal(trd["lut"][gt_u8.long()], gt[0])
