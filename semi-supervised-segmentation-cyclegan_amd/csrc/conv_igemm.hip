@@ -71,8 +71,13 @@ struct KcParams {
 // 256 B of zeros: the source of LDS-DMA lanes that fall into padding / outside the tile
 __device__ float sscg_zero_page[64];
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false, bool BF16 = false>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false, bool BF16 = false, bool N4 = false>
 __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
+    // N4: at most four output columns (the 3-channel heads).  The 256 x 32 tile is staged exactly like any other, but the
+    // contraction runs on v_mfma_f32_4x4x1_f32 - 16 independent 4x4 outer products per instruction = 64 rows x 4 columns x
+    // 1 k: lane l feeds row l of the wave's 64 (a 16-byte fragment = 4 k = 4 instructions) and column l % 4 of the filter
+    // tile.  1/8 of the matrix-core time of the 32-wide tile, which spends 29 of its 32 columns on padding.
+    static_assert(!N4 || (WM == 4 && WN == 1 && TM == 2 && TN == 1 && !BF16 && NBUF == 2), "N4 tile = 4 waves x 64 rows, one column quad");
     // BF16: the operands are rounded to bfloat16 (RNE) when the fragments leave LDS and contracted by
     // v_mfma_f32_32x32x16_bf16 with fp32 accumulation - tensors in HBM and LDS stay fp32, so loader, swizzle and epilogue are
     // those of the fp32 kernel.  16x fewer MFMA cycles; the kernel is then bound by LDS reads and the global->LDS copies.
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};    // N4: rows 4 * (lane / 4) + r of the wave's 64, column lane % 4
     const int nk = kt1 - kt0;
     if (nk > 0) {
         load_tile();
@@ -375,7 +381,23 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
         const float* b = Bs + buf * BN * LDR + (col_w + li) * LDR + (DMA ? 0 : lh * 4);
         const int swz = dma_swizzle(li);  // DMA image: 16-B slot c of a row lives at slot c ^ swz
         auto koff = [&](int kk) { return DMA ? (((kk * 2 + lh) ^ swz) * 4) : kk * 8; };
-        if constexpr (BF16) {
+        if constexpr (N4) {
+            const int arow_l = row_w + lane;                          // this lane's row of the A image
+            const float* a4p = As + buf * BM * LDR + arow_l * LDR;
+            const float* b4p = Bs + buf * BN * LDR + (lane & 3) * LDR;
+            const int sa = DMA ? dma_swizzle(arow_l) : 0, sb = DMA ? dma_swizzle(lane & 3) : 0;
+            f32x4 qa[BK / 4], qb[BK / 4];
+#pragma unroll
+            for (int c = 0; c < BK / 4; ++c) {
+                qa[c] = *reinterpret_cast<const f32x4*>(a4p + ((c ^ sa) * 4));
+                qb[c] = *reinterpret_cast<const f32x4*>(b4p + ((c ^ sb) * 4));
+            }
+            if (kt + 1 < nk) load_tile();
+#pragma unroll
+            for (int c = 0; c < BK / 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[c][e], qb[c][e], acc4, 0, 0, 0);
+        } else if constexpr (BF16) {
             f32x4 ga[4][TM], gb[4][TN];           // the four 8-wide k-groups of this k-tile
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -434,6 +456,32 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
         __syncthreads();
     }
 
+    if constexpr (N4) {
+        // D layout of v_mfma_f32_4x4x1: lane = 4 * block + column, register = row of the block
+        const int n = n0 + (lane & 3);
+        if (n < p.Ng) {
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + row_w + (lane & ~3) + r;
+                if (m >= p.M) continue;
+                if (partial) {
+                    p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc4[r];
+                } else {
+                    size_t row = (size_t)m;
+                    if (p.o_step != 1) {
+                        const int img = m / (p.OH * p.OW);
+                        const int rem = m - img * (p.OH * p.OW);
+                        const int oi = rem / p.OW;
+                        const int oj = rem - oi * p.OW;
+                        row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+                    }
+                    p.dst[row * p.Ng + n] = sscg_act(acc4[r] + bv, p.act, p.slope);
+                }
+            }
+        }
+        return;
+    }
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -489,14 +537,15 @@ __global__ __launch_bounds__(256) void kc_reduce_kernel(const float* __restrict_
 // Tile choice (measured on MI355X, tools/conv_bench.py): 128x128 only when it still yields >= 2 workgroups per CU on a
 // long reduction; otherwise 64x64; a 128x32 tile for heads with a handful of output channels.  Shapes whose source
 // channel count is a multiple of BK stage through LDS-DMA (cfg 6/7).
-static const int KC_BM[8] = {128, 128, 64, 64, 128, 128, 64, 128};
-static const int KC_BN[8] = {128, 64, 128, 64, 32, 128, 64, 128};
+static const int KC_BM[9] = {128, 128, 64, 64, 128, 128, 64, 128, 256};
+static const int KC_BN[9] = {128, 64, 128, 64, 32, 128, 64, 128, 32};
 int sscg_force_conv_cfg = -1;    // test/tuning hooks (sscg_debug_set_conv_cfg)
 int sscg_force_conv_split = 0;
 
 static int kc_choose_cfg(int M, int Ng, int Ktot, int Cs) {
     if (sscg_force_conv_cfg >= 0) return sscg_force_conv_cfg;
     const bool fast = Cs % BK == 0;
+    if (Ng <= 4 && fast) return 8;
     if (Ng <= 32) return 4;
     const long w128 = (long)cdiv(M, 128) * cdiv(Ng, 128);
     if (w128 >= 512 && Ktot >= 1024 && Ng > 64) return fast ? 7 : 0;   // long reductions amortise the big tile's prologue (and N fills it)
@@ -555,7 +604,7 @@ static size_t kc_split_bytes(const KcSplit& sp, int M, int Ng) {
     return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false, bool BF16 = false>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false, bool BF16 = false, bool N4 = false>
 int launch_kc(const KcParams& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -565,7 +614,7 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     p.tiles = tiles_m * p.tiles_n;
     constexpr int LDR = DMA ? BK : LDK;
     size_t smem = (size_t)(NBUF * BM * LDR + NBUF * BN * LDR) * sizeof(float) + (size_t)(p.R * p.S > 0 ? p.R * p.S : 1) * 8;
-    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST, NBUF, DMA, BF16>;
+    auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST, NBUF, DMA, BF16, N4>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -604,6 +653,7 @@ int dispatch_kc(const KcParams& p, hipStream_t st) {
         case 5: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 1>(p, st);   // 128x128, single LDS image (experimental)
         case 6: if constexpr (FAST) { if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
         case 7: if constexpr (FAST) { if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
+        case 8: if constexpr (FAST) return launch_kc<MODE, 4, 1, 2, 1, VEC, FAST, 2, true, false, true>(p, st); else return SSCG_ERR_UNSUPPORTED;   // 256 x (<= 4): 4x4x1 MFMA
         default: return SSCG_ERR_BAD_ARG;
     }
 }

@@ -430,7 +430,8 @@ def test_thin_1x1_weight_gradient(geom, F, dev):
 
 BF16_CASES = [(2, 256, 33, 33, 256, 3, 1, 2, 2), (2, 256, 17, 19, 1024, 1, 1, 0, 1), (8, 256, 33, 33, 256, 3, 1, 2, 2),
               (2, 64, 32, 32, 128, 3, 2, 1, 1), (4, 512, 33, 33, 512, 3, 1, 4, 4),
-              (2, 21, 40, 40, 64, 7, 1, 3, 1), (2, 64, 40, 40, 3, 7, 1, 3, 1), (2, 20, 17, 19, 36, 3, 1, 1, 1)]   # generic / narrow tiles
+              (2, 21, 40, 40, 64, 7, 1, 3, 1), (2, 64, 40, 40, 21, 7, 1, 3, 1), (2, 20, 17, 19, 36, 3, 1, 1, 1)]   # generic / narrow tiles
+# (heads with <= 4 output channels run on the 4x4x1 fp32 MFMA tile in either mode: they are staging-bound, not MFMA-bound)
 
 
 @pytest.mark.parametrize("shape", BF16_CASES)

@@ -14,6 +14,8 @@ CL = torch.channels_last
 
 # N, C, H, W, K, R, stride, pad, dil
 SHAPES = [
+    (16, 64, 256, 256, 3, 7, 1, 3, 1),
+    (8, 2048, 33, 33, 3, 3, 1, 6, 6),
     (8, 21, 256, 256, 64, 7, 1, 3, 1),
     (8, 64, 256, 256, 21, 7, 1, 3, 1),
     (8, 64, 256, 256, 3, 7, 1, 3, 1),
