@@ -7,7 +7,7 @@ and `resnet_{6,9}blocks[_softmax]` (the classic CycleGAN generator - the frozen 
 from torch import nn
 
 from .. import functional as F
-from .._lib import ACT_NONE, ACT_RELU, ACT_TANH
+from .._lib import ACT_RELU
 from .ops import (BatchNorm2d, Conv2d, FusedSequential, ReflectionPad2d, ResidualBlock, Tanh, as_norm_layer,
                   conv_norm_relu, dconv_norm_relu, get_norm_layer, init_network)
 

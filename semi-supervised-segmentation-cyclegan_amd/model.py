@@ -14,7 +14,6 @@ that are deliberate and MI355X-first:
 import itertools
 import os
 
-import numpy as np
 import torch
 
 from . import functional as F

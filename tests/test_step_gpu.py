@@ -2,7 +2,6 @@
 flat-arena optimiser, reflection-pad adjoint, determinism of the two-stream schedule."""
 import contextlib
 import io
-import os
 
 import numpy as np
 import pytest
