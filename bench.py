@@ -47,11 +47,12 @@ def main():
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-contraction figure")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a.gpus))          # `python bench.py --gpus N` launches its own N ranks
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        if a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+        raise SystemExit("bench.py --gpus %d inside a %d-rank job" % (a.gpus, world))
     md = importlib.import_module(PKG + ".model")
     F = importlib.import_module(PKG + ".functional")
     par = importlib.import_module(PKG + ".parallel")
@@ -104,6 +105,7 @@ def main():
         "metric": "training images/sec (G+D step) at 256x256", "value": round(value, 4), "unit": "img/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        **({"shared_gpu": True} if os.environ.get("SSCG_DP_SHARED_GPU") else {}),
         "config": {"workload": "VOC2012 21-class 256x256 semisupervised_cycleGAN as-written G+D step, batch=%d per GPU, %s" % (
                        bsz, "fp32" if a.dtype == "f32" else "bf16 conv contractions (fp32 accumulate, fp32 tensors/norms/Adam)"),
                    "global_batch": world * bsz, "image_unit": "one labeled + one unlabeled 256x256 image", "parallelism": "dp%d" % world,
@@ -207,6 +209,30 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """Re-execute this command line under torch.distributed.run with one rank per GPU (what the driver's own launcher
+    does).  A box with fewer than n GPUs (the 1-GPU test box) runs the ranks on GPU 0 over gloo - the same control flow,
+    not a scaling figure; the JSON line then says "shared_gpu": true."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        import torch
+        have = torch.cuda.device_count()
+    except Exception:
+        have = 0
+    if have < n:
+        env.update(SSCG_DP_SHARED_GPU="1", SSCG_DP_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def pmc_traffic():

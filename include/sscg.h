@@ -122,6 +122,9 @@ int sscg_add(const float* a, const float* b, float* y, int64_t n, void* stream);
 /* nn.Dropout(0.5) in training mode (arch/ops.py:66): y = x * keep / (1-p); keep is derived from a
  * counter-based hash of (seed, element index), so backward can regenerate it. */
 int sscg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* utils.GaussianNoise (utils.py:116-140; call site model.py:486-488): y = x + sigma * x * n, n ~ N(0, 1) drawn from a
+ * counter-based hash of (seed, element index) through Box-Muller. */
+int sscg_gauss_noise(const float* x, float* y, int64_t n, float sigma, uint64_t seed, void* stream);
 /* nn.MaxPool2d(3, 2, 1, ceil_mode=True) (arch/generators.py:394); idx = window position 0..8 of the first max */
 int sscg_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, int P, int Q, void* stream);
 int sscg_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, int P, int Q, void* stream);
@@ -162,9 +165,14 @@ int sscg_label_lut(const uint8_t* src, int64_t* dst, int64_t n, const int64_t* l
  * Each forward writes one fp32 scalar to `loss` (device).  Each backward takes the upstream gradient as
  * a device scalar `gscale` (NULL = 1) times the host factor `w`. */
 size_t sscg_loss_workspace(int64_t n);
-/* nn.CrossEntropyLoss (model.py:272; calls :398,:455): logits [rows][C], labels [rows] */
-int sscg_ce_fwd(const float* logits, const int64_t* labels, int64_t rows, int C, float* loss, void* ws, size_t ws_bytes, void* stream);
-int sscg_ce_bwd(const float* logits, const int64_t* labels, int64_t rows, int C, const float* gscale, float w, float* dx, void* stream);
+/* nn.CrossEntropyLoss (model.py:272; calls :398,:455): logits [rows][C], labels [rows].  Pixels whose label is outside
+ * [0, C) are ignored (no read past the row, excluded from the mean, zero gradient) - torch's ignore_index behaviour for
+ * every out-of-range id.  `valid` (nullable) receives the number of counted pixels; the backward divides by it
+ * (NULL = rows). */
+int sscg_ce_fwd(const float* logits, const int64_t* labels, int64_t rows, int C, float* loss, float* valid, void* ws,
+                size_t ws_bytes, void* stream);
+int sscg_ce_bwd(const float* logits, const int64_t* labels, int64_t rows, int C, const float* gscale, float w,
+                const float* valid, float* dx, void* stream);
 /* nn.MSELoss against a constant target map of ones/zeros (LSGAN; model.py:445-446,452,521-528) */
 int sscg_mse_const_fwd(const float* x, int64_t n, float target, float* loss, void* ws, size_t ws_bytes, void* stream);
 int sscg_mse_const_bwd(const float* x, int64_t n, float target, const float* gscale, float w, float* dx, void* stream);

@@ -58,6 +58,9 @@ def main(argv=None):
     args.overlap_d = True                # train() reads the losses after sync_losses()
     if args.crop_height is None and args.crop_width is None:
         args.crop_height, args.crop_width = DEFAULT_CROP[args.dataset]
+    if args.gpu_ids:
+        import torch
+        torch.cuda.set_device(args.gpu_ids[0])          # arch/ops.py:31-34: everything lives on gpu_ids[0]
     md = importlib.import_module(PKG + ".model")
     importlib.import_module(PKG + ".functional").set_conv_precision(args.dtype)
     dp = None
@@ -80,7 +83,7 @@ def main(argv=None):
             md.semisuper_cycleGAN(args, data_parallel=dp).train(args, loaders=loaders)
         if args.model == "supervised_model":
             print("Training base model")
-            md.supervised_model(args).train(args, loaders=loaders)
+            md.supervised_model(args, data_parallel=dp).train(args, loaders=loaders)
     if args.testing:                                        # main.py:69-71
         print("Testing")
         import testing

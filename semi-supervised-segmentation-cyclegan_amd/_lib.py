@@ -60,6 +60,7 @@ SIGNATURES = {
     "sscg_act_bwd": (_i, [_p, _p, _p, _i64, _i, _f, _p]),
     "sscg_add": (_i, [_p, _p, _p, _i64, _p]),
     "sscg_dropout": (_i, [_p, _p, _i64, _f, C.c_uint64, _p]),
+    "sscg_gauss_noise": (_i, [_p, _p, _i64, _f, C.c_uint64, _p]),
     "sscg_maxpool3x3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sscg_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sscg_upsample_bilinear_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -76,8 +77,8 @@ SIGNATURES = {
     "sscg_image_u8_to_f32": (_i, [_p, _p, _i64, _i, _p, _p, _p]),
     "sscg_label_lut": (_i, [_p, _p, _i64, _p, _p]),
     "sscg_loss_workspace": (_sz, [_i64]),
-    "sscg_ce_fwd": (_i, [_p, _p, _i64, _i, _p, _p, _sz, _p]),
-    "sscg_ce_bwd": (_i, [_p, _p, _i64, _i, _p, _f, _p, _p]),
+    "sscg_ce_fwd": (_i, [_p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
+    "sscg_ce_bwd": (_i, [_p, _p, _i64, _i, _p, _f, _p, _p, _p]),
     "sscg_mse_const_fwd": (_i, [_p, _i64, _f, _p, _p, _sz, _p]),
     "sscg_mse_const_bwd": (_i, [_p, _i64, _f, _p, _f, _p, _p]),
     "sscg_l1_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),

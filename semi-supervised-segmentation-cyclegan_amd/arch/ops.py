@@ -177,15 +177,21 @@ class Tanh(_Act):
     code = ACT_TANH
 
 
+_DROPOUT_INSTANCES = [0]
+
+
 class Dropout(nn.Module):
     """nn.Dropout: counter-hash mask (seed advances per call; torch's Philox stream cannot be matched, so
-    parity runs use --no_dropout, SURVEY section 7 'hard parts')."""
+    parity runs use --no_dropout, SURVEY section 7 'hard parts').  Every instance draws from its own stream: the seed
+    mixes the run seed (torch.initial_seed(), i.e. torch.manual_seed) with the instance's construction index, so the
+    nine residual blocks of a generator - and the two frozen generators - see independent masks, as nn.Dropout's do."""
 
     def __init__(self, p=0.5):
         super().__init__()
         self.p = p
         self._calls = 0
-        self.seed = 0x5eed
+        _DROPOUT_INSTANCES[0] += 1
+        self.seed = ((torch.initial_seed() * 0x9E3779B1 + _DROPOUT_INSTANCES[0] * 0x85EBCA6B) & 0x7FFFFFFFFFF) | 1
 
     def forward(self, x):
         if not self.training or self.p == 0.0:

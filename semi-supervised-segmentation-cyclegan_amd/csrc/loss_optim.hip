@@ -84,40 +84,72 @@ __global__ void argmax_onehot_kernel(const float* __restrict__ x, float* __restr
 
 __global__ void label_onehot_kernel(const int64_t* __restrict__ lab, float* __restrict__ oh, size_t rows, int C) {
     for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256) {
-        int l = (int)lab[r];
+        const int64_t l64 = lab[r];
+        const int l = (l64 < 0 || l64 >= C) ? -1 : (int)l64;     // out-of-range id: an all-zero row, as scatter_ would refuse it
         float* o = oh + r * C;
         for (int c = 0; c < C; ++c) o[c] = (c == l) ? 1.f : 0.f;
     }
 }
 
 // ---------------------------------------------------------------- cross entropy
+// Pixels whose label lies outside [0, C) take no part in the loss (nn.CrossEntropyLoss's ignore_index semantics,
+// extended to every out-of-range id: the 255 "void" of an un-relabelled VOC map, a raw Cityscapes id, -100): they add
+// nothing to the sum, are not counted in the mean and get a zero gradient - never an out-of-bounds read.
 __global__ void ce_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ lab, size_t rows, int C,
-                              double* __restrict__ part) {
-    double acc = 0.0;
+                              double* __restrict__ part, int nparts) {
+    double acc = 0.0, cnt = 0.0;
     for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256) {
+        const int64_t l = lab[r];
+        if (l < 0 || l >= C) continue;
         const float* xr = x + r * C;
         float m = -INFINITY;
         for (int c = 0; c < C; ++c) m = fmaxf(m, xr[c]);
         float s = 0.f;
         for (int c = 0; c < C; ++c) s += expf(xr[c] - m);
-        int l = (int)lab[r];
         acc += (double)(logf(s) + m - xr[l]);
+        cnt += 1.0;
     }
     block_sum_to(acc, part + blockIdx.x);
+    __syncthreads();
+    block_sum_to(cnt, part + nparts + blockIdx.x);
+}
+
+// loss = sum / count; count (the number of pixels with a valid label) also goes to `valid` for the backward pass
+__global__ void finish_ce_kernel(const double* __restrict__ part, int nparts, float* __restrict__ loss, float* __restrict__ valid) {
+    __shared__ double sm[512];
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) { s += part[i]; c += part[nparts + i]; }
+    sm[threadIdx.x] = s;
+    sm[256 + threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0, n = 0.0;
+        for (int i = 0; i < 256; ++i) { t += sm[i]; n += sm[256 + i]; }
+        *loss = n > 0.0 ? (float)(t / n) : 0.f;
+        if (valid) *valid = (float)n;
+    }
 }
 
 __global__ void ce_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ lab, size_t rows, int C,
-                              const float* __restrict__ gscale, float w, float* __restrict__ dx) {
-    const float g = (gscale ? *gscale : 1.f) * w;
+                              const float* __restrict__ gscale, float w, const float* __restrict__ valid,
+                              float* __restrict__ dx) {
+    const float n = valid ? *valid : (float)rows;
+    const float g = (gscale ? *gscale : 1.f) * (n > 0.f ? w / n : 0.f);
     for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256) {
         const float* xr = x + r * C;
+        const int64_t l64 = lab[r];
+        if (l64 < 0 || l64 >= C) {
+            float* dr = dx + r * C;
+            for (int c = 0; c < C; ++c) dr[c] = 0.f;
+            continue;
+        }
         float v[MAXC];
         float m = -INFINITY;
         for (int c = 0; c < C; ++c) { v[c] = xr[c]; m = fmaxf(m, v[c]); }
         float s = 0.f;
         for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - m); s += v[c]; }
         float inv = 1.f / s;
-        int l = (int)lab[r];
+        const int l = (int)l64;
         float* dr = dx + r * C;
         for (int c = 0; c < C; ++c) dr[c] = (v[c] * inv - (c == l ? 1.f : 0.f)) * g;
     }
@@ -249,27 +281,27 @@ extern "C" int sscg_confusion_hist(const int64_t* label_true, const int64_t* lab
 
 extern "C" size_t sscg_loss_workspace(int64_t n) {
     (void)n;
-    return (size_t)LOSS_BLOCKS * sizeof(double);
+    return (size_t)2 * LOSS_BLOCKS * sizeof(double);   // cross entropy keeps (sum, count) partials
 }
 
-extern "C" int sscg_ce_fwd(const float* logits, const int64_t* labels, int64_t rows, int C, float* loss, void* ws,
-                           size_t ws_bytes, void* stream) {
+extern "C" int sscg_ce_fwd(const float* logits, const int64_t* labels, int64_t rows, int C, float* loss, float* valid,
+                           void* ws, size_t ws_bytes, void* stream) {
     if (!logits || !labels || !loss || rows <= 0 || C <= 0 || C > MAXC) return SSCG_ERR_BAD_ARG;
     if (!ws || ws_bytes < sscg_loss_workspace(rows)) return SSCG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int nb = ew_blocks(rows, LOSS_BLOCKS);
     double* part = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, labels, (size_t)rows, C, part);
-    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)rows, loss);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, labels, (size_t)rows, C, part, nb);
+    hipLaunchKernelGGL(finish_ce_kernel, dim3(1), dim3(256), 0, st, part, nb, loss, valid);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
 
 extern "C" int sscg_ce_bwd(const float* logits, const int64_t* labels, int64_t rows, int C, const float* gscale, float w,
-                           float* dx, void* stream) {
+                           const float* valid, float* dx, void* stream) {
     if (!logits || !labels || !dx || rows <= 0 || C <= 0 || C > MAXC) return SSCG_ERR_BAD_ARG;
     hipLaunchKernelGGL(ce_bwd_kernel, dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, logits, labels, (size_t)rows,
-                       C, gscale, w / (float)rows, dx);
+                       C, gscale, w, valid, dx);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

@@ -66,6 +66,19 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     }
 }
 
+// y = x + sigma * x * n,  n ~ N(0,1): two hashes per element -> Box-Muller (utils.GaussianNoise, relative noise)
+__global__ void gauss_noise_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float sigma, uint64_t seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t r1 = mix64to32(seed * 0x2545f4914f6cdd1dull + 2 * (uint64_t)i);
+        const uint32_t r2 = mix64to32(seed * 0x2545f4914f6cdd1dull + 2 * (uint64_t)i + 1);
+        const float u1 = ((float)(r1 >> 8) + 1.0f) * (1.0f / 16777216.0f);    // (0, 1]
+        const float u2 = (float)(r2 >> 8) * (1.0f / 16777216.0f);             // [0, 1)
+        const float z = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+        const float v = x[i];
+        y[i] = v + sigma * v * z;
+    }
+}
+
 // one thread per (n, oy, ox, c)
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int N,
                                    int H, int W, int C, int P, int Q) {
@@ -285,6 +298,13 @@ extern "C" int sscg_dropout(const float* x, float* y, int64_t n, float p, uint64
     if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return SSCG_ERR_BAD_ARG;
     hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n, p,
                        1.f / (1.f - p), seed);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_gauss_noise(const float* x, float* y, int64_t n, float sigma, uint64_t seed, void* stream) {
+    if (!x || !y || n <= 0 || sigma < 0.f) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gauss_noise_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n, sigma, seed);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

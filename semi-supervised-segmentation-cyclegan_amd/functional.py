@@ -408,6 +408,14 @@ def dropout(x, p, seed):
     return y
 
 
+def gauss_noise(x, sigma, seed):
+    """utils.GaussianNoise.forward on the device: x + sigma * x * N(0, 1) (utils.py:133-139)."""
+    _need_hip(x)
+    y = torch.empty_like(x, memory_format=torch.preserve_format)
+    check(lib.sscg_gauss_noise(x.data_ptr(), y.data_ptr(), x.numel(), float(sigma), int(seed), _stream()), "sscg_gauss_noise")
+    return y
+
+
 def pool_out_size(h):
     """MaxPool2d(3, 2, 1, ceil_mode=True) output size (torch rule: last window must start inside input+left pad)."""
     o = -((-(h + 2 - 3)) // 2) + 1
@@ -694,20 +702,25 @@ class ConvTranspose2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # gradient wrt x = forward of the mirrored conv applied to dy
             dx = conv2d_fwd(dy, w, None, stride, pad, 1)
-        if ctx.needs_input_grad[1]:
-            # mirrored conv has input dy (as "x") and output-gradient x (as "dy")
-            acc = _acc_target(ctx.wref)
-            if acc is not None:
-                conv2d_wgrad(dy, x, w.shape, stride, pad, 1, out=acc, accumulate=True)
-            else:
-                dw = conv2d_wgrad(dy, x, w.shape, stride, pad, 1)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            n, k, p, q = dy.shape
-            acc = _acc_target(ctx.bref)
-            if acc is not None:
-                colsum(n * p * q, k, dy, out=acc, accumulate=True)
-            else:
-                db = colsum(n * p * q, k, dy)
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        wacc = _acc_target(ctx.wref) if want_w else None
+        bacc = _acc_target(ctx.bref) if want_b else None
+        n, k, p, q = dy.shape
+
+        def arena_grads():      # as Conv2dFn: a parameter's gradient kernels always run on ITS side lane (fixed accumulation order)
+            if wacc is not None:
+                # mirrored conv has input dy (as "x") and output-gradient x (as "dy")
+                conv2d_wgrad(dy, x, w.shape, stride, pad, 1, out=wacc, accumulate=True)
+            if bacc is not None:
+                colsum(n * p * q, k, dy, out=bacc, accumulate=True)
+
+        if wacc is not None or bacc is not None:
+            run_on_side_stream(dy.device, (x, dy), arena_grads, lane=getattr(ctx.wref, "_sscg_lane", 0))
+        if want_w and wacc is None:
+            dw = conv2d_wgrad(dy, x, w.shape, stride, pad, 1)
+        if want_b and bacc is None:
+            db = colsum(n * p * q, k, dy)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -741,17 +754,27 @@ class NormActFn(torch.autograd.Function):
         want_g = gamma is not None and ctx.needs_input_grad[1]
         dgamma = dbeta = None
         ret_g = ret_b = None
+        gacc = bacc = None
         if want_g:
-            dgamma = _acc_target(ctx.gref)
-            dbeta = _acc_target(ctx.betaref)
-            if dgamma is None or dbeta is None:
-                dgamma = torch.empty_like(gamma)
-                dbeta = torch.empty_like(gamma)
-                fill_(dgamma, 0.0)
-                fill_(dbeta, 0.0)
+            gacc = _acc_target(ctx.gref)
+            bacc = _acc_target(ctx.betaref)
+            dgamma = torch.empty_like(gamma)
+            dbeta = torch.empty_like(gamma)
+            fill_(dgamma, 0.0)
+            fill_(dbeta, 0.0)
+            if gacc is None or bacc is None:
+                gacc = bacc = None
                 ret_g, ret_b = dgamma, dbeta
         dx, dres = norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad,
                             want_dres=has_res and ctx.needs_input_grad[3], dgamma=dgamma, dbeta=dbeta)
+        if gacc is not None:
+            # The sums were produced beside dx on this stream; their accumulation into the optimiser's arena runs on the
+            # parameter's own side lane, like every other gradient of that parameter (two forward lanes may both reach
+            # this layer: a read-modify-write of the arena slice from two streams would lose updates).
+            def arena_grads():
+                check(lib.sscg_add(gacc.data_ptr(), dgamma.data_ptr(), gacc.data_ptr(), gacc.numel(), _stream()), "sscg_add")
+                check(lib.sscg_add(bacc.data_ptr(), dbeta.data_ptr(), bacc.data_ptr(), bacc.numel(), _stream()), "sscg_add")
+            run_on_side_stream(dy.device, (dgamma, dbeta), arena_grads, lane=getattr(ctx.gref, "_sscg_lane", 0))
         if not ctx.needs_input_grad[0]:
             dx = None
         return dx, ret_g, ret_b, dres, None, None, None, None, None, None, None, None
@@ -910,19 +933,20 @@ class CrossEntropyFn(torch.autograd.Function):
         if labels.numel() != n * h * w or labels.dtype != torch.int64:
             raise _lib.SscgError("labels must be int64 with N*H*W elements")
         loss = _scalar(logits.device)
+        valid = _scalar(logits.device)      # pixels with a label in [0, C): the divisor of the mean (all of them in the reference)
         ws = _loss_ws(logits.device)
-        check(lib.sscg_ce_fwd(logits.data_ptr(), labels.data_ptr(), n * h * w, c, loss.data_ptr(), ws.data_ptr(), ws.numel(),
-                              _stream()), "sscg_ce_fwd")
-        ctx.save_for_backward(logits, labels)
+        check(lib.sscg_ce_fwd(logits.data_ptr(), labels.data_ptr(), n * h * w, c, loss.data_ptr(), valid.data_ptr(), ws.data_ptr(),
+                              ws.numel(), _stream()), "sscg_ce_fwd")
+        ctx.save_for_backward(logits, labels, valid)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        logits, labels = ctx.saved_tensors
+        logits, labels, valid = ctx.saved_tensors
         n, c, h, w = logits.shape
         dx = torch.empty_like(logits, memory_format=CL)
-        check(lib.sscg_ce_bwd(logits.data_ptr(), labels.data_ptr(), n * h * w, c, g.data_ptr(), 1.0, dx.data_ptr(), _stream()),
-              "sscg_ce_bwd")
+        check(lib.sscg_ce_bwd(logits.data_ptr(), labels.data_ptr(), n * h * w, c, g.data_ptr(), 1.0, valid.data_ptr(),
+                              dx.data_ptr(), _stream()), "sscg_ce_bwd")
         return dx, None
 
 

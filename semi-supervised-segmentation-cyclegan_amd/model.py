@@ -23,6 +23,13 @@ from .arch import define_Dis, define_Gen, set_grad
 from .optim import FusedAdam
 from .utils import CLASSES, make_one_hot
 
+def _select_device(args):
+    """The reference puts everything on gpu_ids[0] (arch/ops.py:31-34, utils.py:221-227).  Kernels are launched on the
+    CURRENT device's stream, so that device is made current once, here - `--gpu_ids 1` then works as in the reference."""
+    if getattr(args, "gpu_ids", None):
+        torch.cuda.set_device(int(args.gpu_ids[0]))
+
+
 LOSS_KEYS = ("img_dis_loss", "gt_dis_loss", "cycle_img_dis_loss", "img_gen_loss", "gt_gen_loss", "img_cycle_loss",
              "gt_cycle_loss", "lab_loss_CE", "lab_loss_MSE")
 
@@ -30,6 +37,7 @@ LOSS_KEYS = ("img_dis_loss", "gt_dis_loss", "cycle_img_dis_loss", "img_gen_loss"
 class semisuper_cycleGAN(object):
     def __init__(self, args, data_parallel=None):
         self.args = args
+        _select_device(args)
         self.n_channels = CLASSES[args.dataset]                     # model.py:205-210
         C, ids = self.n_channels, args.gpu_ids
         drop = not args.no_dropout
@@ -41,10 +49,13 @@ class semisuper_cycleGAN(object):
         gen = args.gen_net if honour else 'deeplab'
         dis = args.dis_net if honour else 'pixel'
         self.variants = set(v for v in str(getattr(args, "variants", "") or "").split(",") if v)
-        unknown = self.variants - {"l1_cycle", "lab_gt_dis"}
+        unknown = self.variants - {"l1_cycle", "lab_gt_dis", "gauss_noise"}
         if unknown:
-            raise ValueError("unknown --variants %s (perceptual loss needs VGG16 weights; the Gaussian-noise branch is dead code, "
-                             "model.py:486-488)" % sorted(unknown))
+            raise ValueError("unknown --variants %s (the perceptual loss needs pretrained VGG16 weights)" % sorted(unknown))
+        # model.py:281,486-488: `if torch.rand(1) < 0.0` never fires, but draws one number from torch's CPU generator per
+        # step (the stream DataLoader shuffling also draws from).  The draw is kept; the variant raises the threshold to 1.
+        self.gauss_noise = utils.GaussianNoise(sigma=0.2)
+        self.noise_prob = 1.0 if "gauss_noise" in self.variants else 0.0
         self.Gis = define_Gen(input_nc=C, output_nc=3, ngf=args.ngf, netG=gen, norm=args.norm, use_dropout=drop, gpu_ids=ids)
         self.Gsi = define_Gen(input_nc=3, output_nc=C, ngf=args.ngf, netG=gen, norm=args.norm, use_dropout=drop, gpu_ids=ids)
         self.Di = define_Dis(input_nc=3, ndf=args.ndf, netD=dis, n_layers_D=3, norm=args.norm, gpu_ids=ids)
@@ -249,6 +260,9 @@ class semisuper_cycleGAN(object):
         set_grad([self.Di, self.Ds], True)
         set_grad([self.old_Di], self.as_written)   # old_Di is in no optimiser: its wgrad only exists in the as-written graph
         self.d_optimizer.zero_grad()
+        if torch.rand(1) < self.noise_prob:                                          # :486 (threshold 0.0 in the reference)
+            fake_img = self.gauss_noise(fake_img.detach())                           # :487
+            fake_gt = self.gauss_noise(fake_gt.detach())                             # :488
         recon_img_p = self.pools[0]([recon_img.detach()])[0]                         # :490
         fake_img_p = self.pools[1]([fake_img.detach()])[0]                           # :491
         fake_gt_p = self.pools[2]([fake_gt.detach()])[0]                             # :493
@@ -299,7 +313,7 @@ class semisuper_cycleGAN(object):
         (the real datasets / transforms of data_utils are outside this build's scope)."""
         if loaders is None:
             from .data import synthetic_loaders
-            loaders = synthetic_loaders(args, self.n_channels)
+            loaders = synthetic_loaders(args, self.n_channels, rank=self.dp.rank if self.dp is not None else 0)
         labeled_loader, unlabeled_loader, val_loader = loaders
         rank0 = self.dp is None or self.dp.rank == 0
         done = 0
@@ -350,14 +364,18 @@ class semisuper_cycleGAN(object):
 class supervised_model(object):
     """DeepLab Gsi + CrossEntropy + Adam(0.9, 0.999) (model.py:33-199; BASELINE config 1)."""
 
-    def __init__(self, args):
+    def __init__(self, args, data_parallel=None):
         self.args = args
+        _select_device(args)
         self.n_channels = CLASSES[args.dataset]
         self.Gsi = define_Gen(input_nc=3, output_nc=self.n_channels, ngf=args.ngf, netG='deeplab', norm=args.norm,
                               use_dropout=not args.no_dropout, gpu_ids=args.gpu_ids)
         utils.print_networks([self.Gsi], ['Gsi'])
         self.crop = (args.crop_height, args.crop_width)
         self.gsi_optimizer = FusedAdam(self.Gsi.parameters(), lr=args.lr, betas=(0.9, 0.999))   # model.py:69
+        self.dp = data_parallel
+        if self.dp is not None:
+            self.dp.attach_one(self.gsi_optimizer, [self.Gsi])
         self.running_metrics_val = utils.runningScore(self.n_channels, args.dataset)
         if not os.path.isdir(args.checkpoint_dir):
             os.makedirs(args.checkpoint_dir, exist_ok=True)
@@ -378,14 +396,34 @@ class supervised_model(object):
         out = F.upsample_bilinear(self.Gsi(l_img), self.crop)
         loss = F.cross_entropy(out, l_gt.reshape(l_gt.shape[0], l_gt.shape[2], l_gt.shape[3]))
         loss.backward()
+        if self.dp is not None:
+            F.SideStream.join(l_img.device)
+            self.dp.sync_grads(self.gsi_optimizer)
         self.gsi_optimizer.step()
         return loss.detach()
 
+    @torch.no_grad()
+    def evaluate(self, val_loader):
+        """model.py:145-162.  The reference interpolates to a hard-coded 512x512 (`interp_val`, model.py:63,152), which only
+        works for a 512x512 crop; the crop size is used here, as the semi-supervised driver does."""
+        self.Gsi.eval()
+        self.running_metrics_val.reset()
+        for val_img, val_gt, _ in val_loader:
+            val_img, val_gt = utils.cuda([val_img, val_gt], self.args.gpu_ids)
+            outputs = F.softmax2d(F.upsample_bilinear(self.Gsi(val_img), self.crop))
+            self.running_metrics_val.update_device(val_gt.squeeze(1), F.argmax_index(outputs))
+        score, class_iou = self.running_metrics_val.get_scores()
+        self.running_metrics_val.reset()
+        self.Gsi.train()
+        return score["Mean IoU : \t"], class_iou
+
     def train(self, args, loaders=None, max_steps=None):
+        rank = self.dp.rank if self.dp is not None else 0
         if loaders is None:
             from .data import synthetic_loaders
-            loaders = synthetic_loaders(args, self.n_channels)
+            loaders = synthetic_loaders(args, self.n_channels, rank=rank)
         labeled_loader = loaders[0]
+        val_loader = loaders[2] if len(loaders) > 2 else None
         history, done = [], 0
         for epoch in range(self.start_epoch, args.epochs):
             self.Gsi.train()
@@ -393,8 +431,18 @@ class supervised_model(object):
                 l_img, l_gt = utils.cuda([l_img, l_gt], args.gpu_ids)
                 loss = float(self.step(l_img, l_gt))
                 history.append(loss)
-                print("Epoch: (%3d) (%5d/%5d) | Crossentropy Loss:%.2e" % (epoch, i + 1, len(labeled_loader), loss))
+                if rank == 0:
+                    print("Epoch: (%3d) (%5d/%5d) | Crossentropy Loss:%.2e" % (epoch, i + 1, len(labeled_loader), loss))
                 done += 1
                 if max_steps is not None and done >= max_steps:
                     return history
+            if val_loader is not None:                                              # model.py:145-197
+                miou, class_iou = self.evaluate(val_loader)
+                if rank == 0:
+                    print("The mIoU for the epoch is: ", miou)
+                if miou >= self.best_iou and rank == 0:
+                    self.best_iou = miou
+                    utils.save_checkpoint({'epoch': epoch + 1, 'Gsi': self.Gsi.state_dict(),
+                                           'gsi_optimizer': self.gsi_optimizer.state_dict(), 'best_iou': self.best_iou,
+                                           'class_iou': class_iou}, '%s/latest_supervised_model.ckpt' % (self.args.checkpoint_dir))
         return history

@@ -42,6 +42,15 @@ class DataParallel:
                 if getattr(t, "_sscg_grad", None) is None:   # arena-resident parameters were broadcast above
                     dist.broadcast(t.data, 0)
 
+    def attach_one(self, opt, nets):
+        """Single-optimiser drivers (supervised_model)."""
+        opt.world_size = self.world_size
+        broadcast_flat(opt.arena)
+        for net in nets:
+            for t in list(net.parameters()) + list(net.buffers()):
+                if getattr(t, "_sscg_grad", None) is None:
+                    dist.broadcast(t.data, 0)
+
     def sync_grads(self, opt):
         allreduce_flat(opt.grad)
 

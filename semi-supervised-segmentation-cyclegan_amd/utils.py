@@ -52,6 +52,22 @@ class Sample_from_Pool(object):
         return out
 
 
+class GaussianNoise(object):
+    """utils.GaussianNoise (utils.py:116-140): x + sigma * x.detach() * N(0,1) in training mode - the (dead) noise branch of
+    the discriminator step, model.py:486-488.  Device-resident: the reference moves the batch to the CPU first."""
+
+    def __init__(self, sigma=0.1, is_relative_detach=True):
+        self.sigma, self.is_relative_detach, self.training = sigma, is_relative_detach, True
+        self._calls = 0
+
+    def __call__(self, x):
+        if self.training and self.sigma != 0:
+            self._calls += 1
+            seed = (torch.initial_seed() * 0x9E3779B1 + self._calls) & 0x7FFFFFFFFFFFFFF
+            return F.gauss_noise(x.detach(), self.sigma, seed)
+        return x
+
+
 class LambdaLR():
     """Linear decay to zero after `decay_epoch` (utils.py:434-441)."""
 

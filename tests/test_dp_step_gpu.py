@@ -1,0 +1,153 @@
+"""The data-parallel TRAINING STEP at world_size 2: two ranks share GPU 0 and exchange gradients over gloo
+- the same `parallel.DataParallel` / `semisuper_cycleGAN.step` code path the 8-GPU run drives over RCCL (attach +
+broadcast, asynchronous generator all-reduce overlapped with the discriminator step, deferred generator update,
+synchronous discriminator all-reduce, 1/world folded into Adam).
+
+Checked: (1) attach() makes rank 1 start from rank 0's weights; (2) after two steps on different per-rank batches the
+weights of both ranks are bit-identical; (3) they equal a single-process lockstep simulation - two replicas, gradients
+summed, Adam applied with grad_scale 1/2 - i.e. the step on the concatenated gradient with per-replica BatchNorm."""
+import contextlib
+import io
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import PKG_NAME, ROOT, load_sub
+
+pytestmark = pytest.mark.gpu
+
+C, H, B, STEPS = 21, 64, 2, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def _make(md, FX, dp, overlap=True):
+    args = FX.make_args(dataset="voc2012", crop_height=H, crop_width=H, batch_size=B, gpu_ids=[0],
+                        checkpoint_dir="/tmp/sscg_test_ckpt_dp", as_written=True)
+    args.overlap_d = overlap
+    return _quiet(md.semisuper_cycleGAN, args, data_parallel=dp)
+
+
+def _load_keyed(m, FX):
+    for k, sd in FX.semisup_state_dicts(C, torch.float32, "dp").items():
+        getattr(m, k).load_state_dict(sd, strict=True)
+
+
+def _state(m):
+    torch.cuda.synchronize()
+    return {"g": m.g_optimizer.arena.detach().cpu(), "d": m.d_optimizer.arena.detach().cpu(),
+            "bn_mean": m.Gsi.state_dict()["layer3.5.bn2.running_mean"].detach().cpu(),
+            "bn_var": m.Gis.state_dict()["layer2.1.bn1.running_var"].detach().cpu()}
+
+
+def _worker(rank, world, port, outdir):
+    import importlib
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      SSCG_DP_SHARED_GPU="1", SSCG_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    par = importlib.import_module(PKG_NAME + ".parallel")
+    md = importlib.import_module(PKG_NAME + ".model")
+    from oracle import fixtures as FX
+    torch.cuda.set_device(0)
+    dp = par.DataParallel(backend="gloo")
+    torch.manual_seed(100 + rank)               # every rank draws ITS OWN initial weights: attach() must overwrite rank 1's
+    m = _make(md, FX, dp)
+    after_attach = {"g": m.g_optimizer.arena.detach().cpu()[::1009].clone(), "d": m.d_optimizer.arena.detach().cpu().clone(),
+                    "old": next(m.old_Gis.parameters()).detach().cpu().clone()}
+    _load_keyed(m, FX)
+    np.random.seed(0)
+    losses = []
+    for s in range(STEPS):
+        l_img, l_gt, unl_img = FX.step_batch("dp/r%d" % rank, s, C, H, H, B)
+        out = m.step(l_img.cuda(), l_gt.cuda(), unl_img.cuda())
+        m.sync_losses()
+        losses.append({k: float(v) for k, v in out.items()})
+    st = _state(m)
+    st.update(after_attach=after_attach, losses=losses)
+    torch.save(st, os.path.join(outdir, "rank%d.pt" % rank))
+    dp.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+class _Deferred:
+    """Turns an optimiser's step() into a no-op until apply() - the simulation needs both replicas' gradients first."""
+
+    def __init__(self, opt):
+        self.opt, self.real = opt, opt.step
+        opt.step = lambda closure=None: None
+
+    def apply(self):
+        self.real()
+
+
+def test_dp_step_world_size_2_shared_gpu(dev, tmp_path):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0, "rank process failed (exit code %s)" % p.exitcode
+    r0 = torch.load(str(tmp_path / "rank0.pt"))
+    r1 = torch.load(str(tmp_path / "rank1.pt"))
+    # (1) broadcast from rank 0 at attach time
+    for k in ("g", "d", "old"):
+        assert torch.equal(r0["after_attach"][k], r1["after_attach"][k]), "attach(): rank 1 does not hold rank 0's %s weights" % k
+    # (2) both ranks hold the same weights after two steps on different batches
+    assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["d"], r1["d"])
+    assert not torch.equal(r0["bn_mean"], r1["bn_mean"])          # BatchNorm statistics stay per rank
+    assert r0["losses"][0]["lab_loss_CE"] != r1["losses"][0]["lab_loss_CE"]
+    # (3) lockstep simulation in this process
+    md = load_sub("model")
+    from oracle import fixtures as FX
+    reps = []
+    for r in range(2):
+        m = _make(md, FX, None)
+        _load_keyed(m, FX)
+        for opt in (m.g_optimizer, m.d_optimizer):
+            opt.world_size = 2                                     # grad_scale 1/2 inside the Adam kernel, as under DP
+        reps.append((m, _Deferred(m.g_optimizer), _Deferred(m.d_optimizer)))
+    np.random.seed(0)
+    sim_losses = [[], []]
+    for s in range(STEPS):
+        for r, (m, _, _) in enumerate(reps):
+            l_img, l_gt, unl_img = FX.step_batch("dp/r%d" % r, s, C, H, H, B)
+            out = m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev))
+            m.sync_losses()
+            sim_losses[r].append({k: float(v) for k, v in out.items()})
+        torch.cuda.synchronize()
+        for name in ("g_optimizer", "d_optimizer"):
+            total = getattr(reps[0][0], name).grad + getattr(reps[1][0], name).grad      # what the sum all-reduce leaves on every rank
+            for m, _, _ in reps:
+                getattr(m, name).grad.copy_(total)
+        for _, g, d in reps:
+            g.apply()
+            d.apply()
+    sim = _state(reps[0][0])
+    for k in ("g", "d", "bn_mean", "bn_var"):
+        diff = float((sim[k].double() - r0[k].double()).abs().max() / r0[k].double().abs().max())
+        print("lockstep vs DP rank 0, %s: max rel diff %.3e (bitwise %s)" % (k, diff, torch.equal(sim[k], r0[k])))
+        assert diff < 1e-6, k
+    for s in range(STEPS):
+        for k, v in r0["losses"][s].items():
+            assert abs(sim_losses[0][s][k] - v) <= 1e-5 * abs(v), (s, k, sim_losses[0][s][k], v)
+        for k, v in r1["losses"][s].items():
+            assert abs(sim_losses[1][s][k] - v) <= 1e-5 * abs(v), (s, k, sim_losses[1][s][k], v)

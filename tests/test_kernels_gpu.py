@@ -272,6 +272,47 @@ def test_softmax_ce_losses(C, F, dev):
     assert rel_err(xg2.grad, xr2.grad) < 1e-5
 
 
+def test_cross_entropy_ignores_out_of_range_labels(F, dev):
+    """Labels outside [0, C) (255 'void', -100) follow nn.CrossEntropyLoss's ignore_index semantics: excluded from the mean,
+    zero gradient, no out-of-bounds read.  label_onehot writes an all-zero row for them."""
+    g = torch.Generator().manual_seed(21)
+    C = 21
+    x = torch.randn(2, C, 16, 16, generator=g, dtype=torch.float64)
+    lab = torch.randint(0, C, (2, 16, 16), generator=g)
+    lab[0, :4] = 255
+    lab[1, 5, :] = -100
+    ref_lab = lab.clone()
+    ref_lab[(lab < 0) | (lab >= C)] = -100
+    xr = x.clone().requires_grad_(True)
+    lr_ = TF.cross_entropy(xr, ref_lab, ignore_index=-100)
+    lr_.backward()
+    xg = gpu(x, dev).requires_grad_(True)
+    lg = F.cross_entropy(xg, lab.to(dev))
+    assert rel_err(lg, lr_) < 1e-6
+    lg.backward()
+    assert rel_err(xg.grad, xr.grad) < 1e-5
+    assert float(xg.grad[0, :, :4].abs().max()) == 0.0
+    oh = F.label_onehot(lab.unsqueeze(1).to(dev), C).cpu()
+    assert float(oh[0, :, :4].abs().max()) == 0.0 and float(oh.sum()) == float(((lab >= 0) & (lab < C)).sum())
+
+
+def test_gauss_noise_statistics(F, dev):
+    """utils.GaussianNoise (utils.py:116-140): y = x + sigma * x * n with n ~ N(0, 1); torch's generator cannot be matched, so
+    the relative noise (y/x - 1)/sigma is checked for zero mean, unit variance, determinism per seed."""
+    x = torch.full((4, 3, 128, 128), 2.0, device=dev)
+    y1, y2, y3 = F.gauss_noise(x, 0.2, 77), F.gauss_noise(x, 0.2, 77), F.gauss_noise(x, 0.2, 78)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    z = ((y1 / x - 1.0) / 0.2).double().cpu()
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+    assert abs(float((z ** 3).mean())) < 0.05 and abs(float((z ** 4).mean()) - 3.0) < 0.15
+    utils = __import__("conftest").load_sub("utils")
+    gn = utils.GaussianNoise(sigma=0.2)
+    a, b = gn(x), gn(x)
+    assert not torch.equal(a, b)            # a fresh draw per call
+    gn.training = False
+    assert gn(x) is x
+
+
 def test_mse_l1_weighted(F, dev):
     g = torch.Generator().manual_seed(8)
     a = torch.randn(2, 3, 32, 32, generator=g, dtype=torch.float64)
