@@ -7,12 +7,13 @@
  * (reference file:line).  INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
  *
  * Conventions
- *   - plain C: device pointers + sizes, no torch types.  All tensors fp32, channels-last
- *     (NHWC: [N][H][W][C]); conv weights [K][R][S][C] (= torch `[K,C,R,S]` in channels_last);
- *     labels int64.
+ *   - plain C: device pointers + sizes, no torch types.  Tensors are channels-last (NHWC: [N][H][W][C]); conv weights
+ *     [K][R][S][C] (= torch `[K,C,R,S]` in channels_last); labels int64.  Activations and conv weights are fp32
+ *     (SSCG_F32, the reference's dtype and BASELINE config 2) or bfloat16 (SSCG_BF16, BASELINE configs 3/5): entry points
+ *     that touch them take `void*` plus a dtype code.  Statistics, losses, biases, weight gradients, optimiser state: fp32.
  *   - `stream` is a hipStream_t passed as void*.  Calls are asynchronous and stream ordered, re-entrant,
- *     allocate nothing and keep no mutable global state; scratch memory is caller provided (`ws`) and
- *     sized by the matching *_workspace() query.
+ *     allocate nothing and keep no mutable state (the two sscg_debug_* tuning hooks excepted: process-wide, test-only,
+ *     not thread safe); scratch memory is caller provided (`ws`) and sized by the matching *_workspace() query.
  *   - return value: 0 = ok, <0 = library error (SSCG_ERR_*), >0 = hipError_t.  Never throws/aborts.
  */
 #ifndef SSCG_H
@@ -24,7 +25,11 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 5
+#define SSCG_ABI_VERSION 6
+
+/* element types of activation / weight tensors */
+#define SSCG_F32 0
+#define SSCG_BF16 1
 
 #define SSCG_ERR_BAD_ARG (-1)
 #define SSCG_ERR_UNSUPPORTED (-2)
@@ -50,38 +55,55 @@ typedef struct sscg_conv_desc {
     int32_t pad_mode;   /* SSCG_PAD_* (reflect: forward and wgrad only) */
     int32_t act;        /* fused epilogue activation of the forward */
     float slope;        /* LeakyReLU slope */
+    int32_t x_dtype;    /* SSCG_F32 / SSCG_BF16 of the [N][H][W][C] tensor (forward input, dgrad output, wgrad x) */
+    int32_t w_dtype;    /* ... of the weight operand handed to forward ([K][R][S][C]) / dgrad ([C][R][S][K]) */
+    int32_t y_dtype;    /* ... of the [N][P][Q][K] tensor (forward output, dgrad / wgrad dy) */
+    int32_t precision;  /* fp32 tensors only: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = operands rounded to bf16
+                         * (RNE) between LDS and the matrix cores, v_mfma_f32_32x32x16_bf16, fp32 accumulation */
 } sscg_conv_desc;
+/* Supported dtype combinations.  forward: (x, w) both fp32 -> y fp32|bf16 (fp32 MFMA kernel: stems and few-channel
+ * inputs); (x, w) both bf16 with C % 64 == 0 -> y fp32|bf16 (bf16 MFMA kernel, bf16 LDS tiles).  dgrad: the same with
+ * (dy, wt) as the operands and dx as the result (K % 64 == 0 for bf16).  wgrad: x, dy each fp32|bf16, dw fp32. */
 
 /* nn.Conv2d forward: arch/ops.py:43,49,68; arch/generators.py:85,90,325,331,336,373,388,415;
  * arch/discriminators.py:45,58,70-75.  y = act(conv(x, w) + bias); bias may be NULL. */
 size_t sscg_conv2d_fwd_workspace(const sscg_conv_desc* d);   /* split-K scratch for few-channel heads; may be 0 */
-int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws,
+int sscg_conv2d_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* ws,
                     size_t ws_bytes, void* stream);
+
+/* Forward with the statistics of the normalisation layer that follows fused into the epilogue ("Conv + InstanceNorm /
+ * BatchNorm" blocks, arch/ops.py:40-57, arch/generators.py:345-365): besides y, per-tile column sums of y and y^2 (fp64,
+ * taken from the fp32 accumulators) go to `stats`; sscg_norm_stats_from_conv turns them into mean / rstd (and the
+ * running-statistics update) without reading y again.  The output rows are viewed as G groups of L rows (G*L = N*P*Q).
+ * sscg_conv2d_fwd_stats_bytes returns 0 when the fusion does not apply to this geometry (then use sscg_norm_stats). */
+size_t sscg_conv2d_fwd_stats_bytes(const sscg_conv_desc* d, int G, int64_t L);
+size_t sscg_conv2d_fwd_stats_workspace(const sscg_conv_desc* d);
+int sscg_conv2d_fwd_stats(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int G, int64_t L,
+                          void* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream);
+int sscg_norm_stats_from_conv(const sscg_conv_desc* d, const void* stats, int G, int64_t L, float eps, float* mean, float* rstd,
+                              float* running_mean, float* running_var, float momentum, void* stream);
 
 /* Data gradient of the same conv (autograd of model.py:472,539), and nn.ConvTranspose2d forward
  * (arch/ops.py:55-56): dx = act(dgrad(dy, wt) + bias).  `wt` = weight re-laid as [C][R][S][K]
  * by sscg_weight_krsc_to_crsk.  bias NULL / act NONE for a pure gradient. */
 size_t sscg_conv2d_dgrad_workspace(const sscg_conv_desc* d);
-int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const float* wt, const float* bias, float* dx,
+int sscg_conv2d_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx,
                       int act, float slope, void* ws, size_t ws_bytes, void* stream);
 
-/* Weight gradient: dw = beta*dw + wgrad(x, dy); dw is [K][R][S][C]. */
+/* Weight gradient: dw = beta*dw + wgrad(x, dy); dw is fp32 [K][R][S][C]. */
 size_t sscg_conv2d_wgrad_workspace(const sscg_conv_desc* d);
-int sscg_conv2d_wgrad(const sscg_conv_desc* d, const float* x, const float* dy, float* dw, float beta, void* ws,
+int sscg_conv2d_wgrad(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws,
                       size_t ws_bytes, void* stream);
 
-int sscg_weight_krsc_to_crsk(const float* w, float* wt, int K, int RS, int C, void* stream);
+/* [K][RS][C] -> [C][RS][K]; source and destination dtypes may differ (fp32 master weight -> bf16 operand copy) */
+int sscg_weight_krsc_to_crsk(const void* w, int w_dtype, void* wt, int wt_dtype, int K, int RS, int C, void* stream);
+/* dst[i] = (dst_dtype) src[i] */
+int sscg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 
 /* out[c] = beta*out[c] + sum_r x[r][c]  (bias gradient).  ws: sscg_colsum_workspace bytes. */
 size_t sscg_colsum_workspace(int64_t rows, int cols);
-int sscg_colsum(const float* x, float* out, int64_t rows, int cols, float beta, void* ws, size_t ws_bytes, void* stream);
+int sscg_colsum(const void* x, int dtype, float* out, int64_t rows, int cols, float beta, void* ws, size_t ws_bytes, void* stream);
 
-/* Arithmetic of the convolution contractions on the matrix-core tiles (forward, data gradient, weight gradient):
- * 0 (default) = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products);
- * 1 = operands rounded to bfloat16 (RNE) on their way out of LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation.
- * Tensors stay fp32 in HBM either way (BASELINE configs 3/5 name bf16; the headline config is fp32).  Process-wide. */
-int sscg_set_conv_precision(int mode);
-int sscg_get_conv_precision(void);
 /* tuning/test hook: bits 0..7 force the forward/dgrad tile configuration (0xff = keep the heuristic), bits 8..15 the
  * split-K factor (0 = planner, 1 = never split, n > 1 = every tile cut in n); -1 restores the defaults */
 int sscg_debug_set_conv_cfg(int cfg);
@@ -98,42 +120,43 @@ size_t sscg_norm_stats_workspace(int G, int64_t L, int C);
  * running = (1-momentum)*running + momentum*batch (running_var from the unbiased batch variance), applied once per
  * group in the order g = 0..G-1.  G > 1 with running statistics is BatchNorm2d over G batches stacked along N in one
  * launch ("grouped"): bit-identical to G successive forwards of the layer, each on its own batch. */
-int sscg_norm_stats(const float* x, int G, int64_t L, int C, float eps, float* mean, float* rstd,
+int sscg_norm_stats(const void* x, int dtype, int G, int64_t L, int C, float eps, float* mean, float* rstd,
                     float* running_mean, float* running_var, float momentum, void* ws, size_t ws_bytes, void* stream);
-/* y = act((x-mean)*rstd*gamma + beta + residual); gamma/beta/residual nullable (gamma,beta are [C]). */
-int sscg_norm_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                    const float* residual, float* y, int G, int64_t L, int C, int act, float slope, void* stream);
+/* y = act((x-mean)*rstd*gamma + beta + residual); gamma/beta/residual nullable (gamma,beta are [C]).
+ * x, residual, y share `dtype`. */
+int sscg_norm_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const void* residual, void* y, int dtype, int G, int64_t L, int C, int act, float slope, void* stream);
 /* eval-mode BatchNorm: mean = running_mean, rstd = 1/sqrt(running_var + eps) */
 int sscg_rstd_from_var(const float* var, float* rstd, int n, float eps, void* stream);
 /* backward of norm_apply (+ of the statistics): dx always; dres (= masked dy) if non-NULL;
  * dgamma/dbeta accumulate (+=) if non-NULL.  `y` (the forward output) supplies the activation mask.
  * With stats_grad == 0 the statistics are treated as constants (eval-mode BN). */
 size_t sscg_norm_bwd_workspace(int G, int64_t L, int C);
-int sscg_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd,
-                  const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int G, int64_t L, int C,
-                  int act, float slope, int stats_grad, void* ws, size_t ws_bytes, void* stream);
+int sscg_norm_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
+                  const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int dtype, int G, int64_t L, int C,
+                  int act, float slope, int stats_grad, void* ws, size_t ws_bytes, void* stream);   /* dy, x, y, dx, dres share `dtype` */
 
 /* ------------------------------------------------------------------ pointwise / pooling / resize */
 /* standalone activation (nn.ReLU / nn.LeakyReLU / nn.Tanh not adjacent to a norm) */
-int sscg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream);
-int sscg_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, void* stream);
+int sscg_act_fwd(const void* x, void* y, int dtype, int64_t n, int act, float slope, void* stream);
+int sscg_act_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n, int act, float slope, void* stream);
 /* y = a + b */
-int sscg_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+int sscg_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
 /* nn.Dropout(0.5) in training mode (arch/ops.py:66): y = x * keep / (1-p); keep is derived from a
  * counter-based hash of (seed, element index), so backward can regenerate it. */
-int sscg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+int sscg_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, void* stream);
 /* utils.GaussianNoise (utils.py:116-140; call site model.py:486-488): y = x + sigma * x * n, n ~ N(0, 1) drawn from a
  * counter-based hash of (seed, element index) through Box-Muller. */
 int sscg_gauss_noise(const float* x, float* y, int64_t n, float sigma, uint64_t seed, void* stream);
 /* nn.MaxPool2d(3, 2, 1, ceil_mode=True) (arch/generators.py:394); idx = window position 0..8 of the first max */
-int sscg_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, int P, int Q, void* stream);
-int sscg_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, int P, int Q, void* stream);
+int sscg_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int N, int H, int W, int C, int P, int Q, void* stream);
+int sscg_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int N, int H, int W, int C, int P, int Q, void* stream);
 /* nn.Upsample(size, mode='bilinear', align_corners=True) (model.py:268, calls :390-392,:413-415) */
 int sscg_upsample_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, void* stream);
 int sscg_upsample_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, void* stream);
 /* nn.ReflectionPad2d as a materialised copy (only for callers that cannot fold it) */
-int sscg_reflect_pad(const float* x, float* y, int N, int H, int W, int C, int pad, void* stream);
-int sscg_reflect_pad_bwd(const float* dy, float* dx, int N, int H, int W, int C, int pad, void* stream);
+int sscg_reflect_pad(const void* x, void* y, int dtype, int N, int H, int W, int C, int pad, void* stream);
+int sscg_reflect_pad_bwd(const void* dy, void* dx, int dtype, int N, int H, int W, int C, int pad, void* stream);
 /* layout plumbing at the NCHW boundary of the reference's module interface */
 int sscg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
 int sscg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
@@ -184,9 +207,11 @@ int sscg_weighted_sum(const float* const* terms, const float* w, int n, float* o
 
 /* ------------------------------------------------------------------ optimiser (K14)
  * torch.optim.Adam (model.py:286-287; steps :474,:542): eps 1e-8, no weight decay, no amsgrad.
- * One launch over a flat arena; grad is multiplied by grad_scale first (1/world_size under data parallel). */
-int sscg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
-                   double beta2, double eps, int step, float grad_scale, void* stream);
+ * One launch over a flat arena; grad is multiplied by grad_scale first (1/world_size under data parallel).
+ * `param_bf16` (nullable): a bfloat16 shadow of the parameter arena, rewritten in the same pass - the operand copy the bf16
+ * convolutions read (the fp32 arena stays the master copy). */
+int sscg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, int64_t n, double lr,
+                   double beta1, double beta2, double eps, int step, float grad_scale, void* stream);
 int sscg_fill(float* x, int64_t n, float v, void* stream);
 
 #ifdef __cplusplus

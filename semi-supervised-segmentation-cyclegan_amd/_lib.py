@@ -9,7 +9,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
+
+F32, BF16 = 0, 1     # SSCG_F32 / SSCG_BF16
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZEROS, PAD_REFLECT = 0, 1
@@ -24,6 +26,7 @@ class ConvDesc(C.Structure):
         ("P", C.c_int32), ("Q", C.c_int32),
         ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
         ("pad_mode", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
+        ("x_dtype", C.c_int32), ("w_dtype", C.c_int32), ("y_dtype", C.c_int32), ("precision", C.c_int32),
     ]
 
 
@@ -39,34 +42,37 @@ SIGNATURES = {
     "sscg_abi_version": (_i, []),
     "sscg_conv2d_fwd_workspace": (_sz, [_dp]),
     "sscg_conv2d_fwd": (_i, [_dp, _p, _p, _p, _p, _p, _sz, _p]),
+    "sscg_conv2d_fwd_stats_bytes": (_sz, [_dp, _i, _i64]),
+    "sscg_conv2d_fwd_stats_workspace": (_sz, [_dp]),
+    "sscg_conv2d_fwd_stats": (_i, [_dp, _p, _p, _p, _p, _i, _i64, _p, _sz, _p, _sz, _p]),
+    "sscg_norm_stats_from_conv": (_i, [_dp, _p, _i, _i64, _f, _p, _p, _p, _p, _f, _p]),
     "sscg_conv2d_dgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_dgrad": (_i, [_dp, _p, _p, _p, _p, _i, _f, _p, _sz, _p]),
     "sscg_conv2d_wgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_wgrad": (_i, [_dp, _p, _p, _p, _f, _p, _sz, _p]),
-    "sscg_weight_krsc_to_crsk": (_i, [_p, _p, _i, _i, _i, _p]),
+    "sscg_weight_krsc_to_crsk": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "sscg_cast": (_i, [_p, _i, _p, _i, _i64, _p]),
     "sscg_colsum_workspace": (_sz, [_i64, _i]),
-    "sscg_colsum": (_i, [_p, _p, _i64, _i, _f, _p, _sz, _p]),
-    "sscg_set_conv_precision": (_i, [_i]),
-    "sscg_get_conv_precision": (_i, []),
+    "sscg_colsum": (_i, [_p, _i, _p, _i64, _i, _f, _p, _sz, _p]),
     "sscg_debug_set_conv_cfg": (_i, [_i]),
     "sscg_debug_set_wgrad_plan": (_i, [_i, _i]),
     "sscg_norm_stats_workspace": (_sz, [_i, _i64, _i]),
-    "sscg_norm_stats": (_i, [_p, _i, _i64, _i, _f, _p, _p, _p, _p, _f, _p, _sz, _p]),
-    "sscg_norm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _f, _p]),
+    "sscg_norm_stats": (_i, [_p, _i, _i, _i64, _i, _f, _p, _p, _p, _p, _f, _p, _sz, _p]),
+    "sscg_norm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _p]),
     "sscg_rstd_from_var": (_i, [_p, _p, _i, _f, _p]),
     "sscg_norm_bwd_workspace": (_sz, [_i, _i64, _i]),
-    "sscg_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
-    "sscg_act_fwd": (_i, [_p, _p, _i64, _i, _f, _p]),
-    "sscg_act_bwd": (_i, [_p, _p, _p, _i64, _i, _f, _p]),
-    "sscg_add": (_i, [_p, _p, _p, _i64, _p]),
-    "sscg_dropout": (_i, [_p, _p, _i64, _f, C.c_uint64, _p]),
+    "sscg_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
+    "sscg_act_fwd": (_i, [_p, _p, _i, _i64, _i, _f, _p]),
+    "sscg_act_bwd": (_i, [_p, _p, _p, _i, _i64, _i, _f, _p]),
+    "sscg_add": (_i, [_p, _p, _p, _i, _i64, _p]),
+    "sscg_dropout": (_i, [_p, _p, _i, _i64, _f, C.c_uint64, _p]),
     "sscg_gauss_noise": (_i, [_p, _p, _i64, _f, C.c_uint64, _p]),
-    "sscg_maxpool3x3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "sscg_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "sscg_maxpool3x3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "sscg_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "sscg_upsample_bilinear_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sscg_upsample_bilinear_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "sscg_reflect_pad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
-    "sscg_reflect_pad_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "sscg_reflect_pad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "sscg_reflect_pad_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sscg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "sscg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "sscg_softmax_fwd": (_i, [_p, _p, _i64, _i, _p]),
@@ -84,7 +90,7 @@ SIGNATURES = {
     "sscg_l1_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
     "sscg_l1_bwd": (_i, [_p, _p, _i64, _p, _f, _p, _p]),
     "sscg_weighted_sum": (_i, [C.POINTER(_p), C.POINTER(_f), _i, _p, _p]),
-    "sscg_adam_step": (_i, [_p, _p, _p, _p, _i64, C.c_double, C.c_double, C.c_double, C.c_double, _i, _f, _p]),
+    "sscg_adam_step": (_i, [_p, _p, _p, _p, _p, _i64, C.c_double, C.c_double, C.c_double, C.c_double, _i, _f, _p]),
     "sscg_fill": (_i, [_p, _i64, _f, _p]),
 }
 

@@ -19,6 +19,7 @@ class PixelDiscriminator(nn.Module):
             Conv2d(input_nc, ndf, 1, 1, 0), LeakyReLU(0.2, True),
             Conv2d(ndf, ndf * 2, 1, 1, 0, bias=use_bias), nl(ndf * 2), LeakyReLU(0.2, True),
             Conv2d(ndf * 2, 1, 1, 1, 0, bias=use_bias))
+        self.dis_model[-1].head = True
 
     def forward(self, input):
         return self.dis_model(input)
@@ -38,6 +39,7 @@ class NLayerDiscriminator(nn.Module):
         prev, mult = mult, min(2 ** n_layers, 8)
         layers.append(conv_norm_lrelu(ndf * prev, ndf * mult, 4, 1, 1, norm_layer=nl, bias=use_bias))
         layers.append(Conv2d(ndf * mult, 1, 4, 1, 1))
+        layers[-1].head = True
         self.dis_model = FusedSequential(*layers)
 
     def forward(self, input):
@@ -54,6 +56,7 @@ class FCDiscriminator(nn.Module):
         self.conv3 = Conv2d(ndf * 2, ndf * 4, 4, 2, 1)
         self.conv4 = Conv2d(ndf * 4, ndf * 8, 4, 2, 1)
         self.classifier = Conv2d(ndf * 8, 1, 4, 2, 1)
+        self.classifier.head = True
 
     def forward(self, x):
         for conv in (self.conv1, self.conv2, self.conv3, self.conv4):

@@ -9,7 +9,7 @@ from torch import nn
 from .. import functional as F
 from .._lib import ACT_RELU
 from .ops import (BatchNorm2d, Conv2d, FusedSequential, ReflectionPad2d, ResidualBlock, Tanh, as_norm_layer,
-                  conv_norm_relu, dconv_norm_relu, get_norm_layer, init_network)
+                  conv_norm_act, conv_norm_relu, dconv_norm_relu, get_norm_layer, init_network)
 
 
 class ResnetGenerator(nn.Module):
@@ -28,6 +28,7 @@ class ResnetGenerator(nn.Module):
                 dconv_norm_relu(ngf * 2, ngf, 3, 2, 1, 1, norm_layer=nl, bias=bias),
                 ReflectionPad2d(3),
                 Conv2d(ngf, output_nc, 7)]
+        seq[-1].head = True
         if not softmax:   # softmax=True only drops the Tanh; no softmax layer is added (arch/generators.py:81-91)
             seq.append(Tanh())
         self.res_model = FusedSequential(*seq)
@@ -58,11 +59,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         x, shortcut = F.split(x)           # the block input feeds conv1 and the shortcut: their gradients meet in sscg_add
-        out = self.bn1(self.conv1(x), ACT_RELU)
-        out = self.bn2(self.conv2(out), ACT_RELU)
-        out = self.conv3(out)
+        out = conv_norm_act(self.conv1, self.bn1, x, ACT_RELU)
+        out = conv_norm_act(self.conv2, self.bn2, out, ACT_RELU)
         res = shortcut if self.downsample is None else self.downsample(shortcut)
-        return self.bn3(out, ACT_RELU, 0.0, residual=res)
+        return conv_norm_act(self.conv3, self.bn3, out, ACT_RELU, 0.0, residual=res)
 
 
 class Classifier_Module(nn.Module):
@@ -73,6 +73,8 @@ class Classifier_Module(nn.Module):
         super().__init__()
         self.conv2d_list = nn.ModuleList(
             [Conv2d(2048, num_classes, 3, 1, p, d, bias=True) for d, p in zip(dilation_series, padding_series)])
+        for conv in self.conv2d_list:
+            conv.head = True          # the network's output: fp32 also in bf16 mode
 
     def forward(self, x):
         a, b = F.split(x)
@@ -107,7 +109,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*stage)
 
     def stem(self, x):
-        x = self.bn1(self.conv1(x), ACT_RELU)
+        x = conv_norm_act(self.conv1, self.bn1, x, ACT_RELU)
         return F.MaxPoolFn.apply(x)      # MaxPool2d(3, 2, 1, ceil_mode=True), arch/generators.py:394
 
     def forward(self, x):

@@ -31,17 +31,30 @@ class Conv2d(nn.Module):
         with torch.no_grad():
             self.weight.copy_(torch.empty(w.shape).normal_(0.0, 0.02))
 
-    def forward(self, x, reflect=0, act=ACT_NONE, slope=0.0):
+    head = False     # a network's last conv: its output stays fp32 in bf16 mode (set by the network constructors)
+
+    def _geometry(self, x, reflect):
+        """(x, pad, pad_mode) with nn.ReflectionPad2d folded into the conv's loader where possible."""
         if reflect:
             if self.padding != 0:
                 raise SscgError("reflection padding folds only into an unpadded conv")
             if torch.is_grad_enabled() and x.requires_grad:
                 # the frozen generators are the reference's only reflect users (model.py:225-228); a training
                 # caller gets a materialised pad whose adjoint is a separate kernel
-                x = ReflectPadFn.apply(x, reflect)
-                return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, PAD_ZEROS, act, slope)
-            return F.conv2d(x, self.weight, self.bias, self.stride, reflect, self.dilation, PAD_REFLECT, act, slope)
-        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, PAD_ZEROS, act, slope)
+                return ReflectPadFn.apply(x, reflect), 0, PAD_ZEROS
+            return x, reflect, PAD_REFLECT
+        return x, self.padding, PAD_ZEROS
+
+    def forward(self, x, reflect=0, act=ACT_NONE, slope=0.0):
+        x, pad, mode = self._geometry(x, reflect)
+        return F.conv2d(x, self.weight, self.bias, self.stride, pad, self.dilation, mode, act, slope, out_f32=self.head)
+
+    def forward_stats(self, x, spec, reflect=0):
+        """Convolution + the batch statistics of the normalisation layer described by `spec` (norm.stat_spec()), produced
+        by the conv's epilogue.  Returns (y, (mean, rstd) or None)."""
+        x, pad, mode = self._geometry(x, reflect)
+        y, mean, rstd = F.conv2d_norm_stats(x, self.weight, self.bias, self.stride, pad, self.dilation, mode, spec)
+        return y, ((mean, rstd) if mean is not None else None)
 
     def extra_repr(self):
         return "%d, %d, k=%d, s=%d, p=%d, d=%d" % (self.in_channels, self.out_channels, self.kernel_size, self.stride,
@@ -88,8 +101,11 @@ class InstanceNorm2d(nn.Module):
         super().__init__()
         self.num_features, self.eps = num_features, eps
 
-    def forward(self, x, act=ACT_NONE, slope=0.0, residual=None):
-        return F.instance_norm_act(x, act, slope, residual, self.eps)
+    def stat_spec(self):
+        return (True, self.eps, None, None, 0.0)
+
+    def forward(self, x, act=ACT_NONE, slope=0.0, residual=None, stats=None):
+        return F.instance_norm_act(x, act, slope, residual, self.eps, stats=stats)
 
 
 _BATCH_GROUPS = [1]
@@ -143,12 +159,19 @@ class BatchNorm2d(nn.Module):
     def batches_tracked(self):
         return int(self.num_batches_tracked) + self._pending
 
-    def forward(self, x, act=ACT_NONE, slope=0.0, residual=None):
+    def stat_spec(self):
+        """What a conv epilogue needs to produce this layer's statistics; None in eval mode (running statistics are used)."""
+        if not self.training:
+            return None
+        groups = _BATCH_GROUPS[0]
+        return (False if groups == 1 else int(groups), self.eps, self.running_mean, self.running_var, self.momentum)
+
+    def forward(self, x, act=ACT_NONE, slope=0.0, residual=None, stats=None):
         groups = _BATCH_GROUPS[0]
         if self.training:
             self._pending += groups
         return F.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                self.momentum, self.eps, act, slope, residual, groups=groups)
+                                self.momentum, self.eps, act, slope, residual, groups=groups, stats=stats)
 
 
 class _Act(nn.Module):
@@ -214,6 +237,18 @@ def _is_norm(m):
     return isinstance(m, (InstanceNorm2d, BatchNorm2d))
 
 
+def conv_norm_act(conv, norm, x, act=ACT_NONE, slope=0.0, residual=None, reflect=0):
+    """The reference's fusion unit (arch/ops.py:40-57; Bottleneck conv+bn pairs, arch/generators.py:345-365):
+    conv -> norm [+ residual] -> activation.  The norm's batch statistics come out of the conv's epilogue when the library
+    can fuse them (sscg_conv2d_fwd_stats); the output is then read once (normalise) instead of twice."""
+    spec = norm.stat_spec() if (F.FUSE_STATS[0] and isinstance(conv, Conv2d)) else None
+    if spec is None:
+        y = conv(x, reflect=reflect) if isinstance(conv, Conv2d) else conv(x)
+        return norm(y, act, slope, residual=residual)
+    y, stats = conv.forward_stats(x, spec, reflect)
+    return norm(y, act, slope, residual=residual, stats=stats)
+
+
 class FusedSequential(nn.Sequential):
     """nn.Sequential whose forward folds [ReflectionPad2d] Conv [Norm] [Activation] [+residual] runs into fused launches."""
 
@@ -235,12 +270,11 @@ class FusedSequential(nn.Sequential):
                 nxt = mods[i + 1] if i + 1 < n else None
                 nx2 = mods[i + 2] if i + 2 < n else None
                 if _is_norm(nxt):
-                    x = m(x, reflect=reflect) if isinstance(m, Conv2d) else m(x)
                     if isinstance(nx2, _Act):
-                        x = nxt(x, nx2.code, nx2.slope)
+                        x = conv_norm_act(m, nxt, x, nx2.code, nx2.slope, reflect=reflect)
                         i += 3
                     else:
-                        x = nxt(x)
+                        x = conv_norm_act(m, nxt, x, reflect=reflect)
                         i += 2
                 elif isinstance(nxt, _Act):
                     x = m(x, reflect, nxt.code, nxt.slope) if isinstance(m, Conv2d) else m(x, nxt.code, nxt.slope)
@@ -352,8 +386,7 @@ class ResidualBlock(nn.Module):
             h = mods[k](h)
             k += 1
         conv, norm = mods[k + 1], mods[k + 2]
-        h = conv(h, reflect=1)
-        return norm(h, ACT_NONE, 0.0, residual=shortcut)
+        return conv_norm_act(conv, norm, h, ACT_NONE, 0.0, residual=shortcut, reflect=1)
 
 
 def set_grad(nets, requires_grad=False):

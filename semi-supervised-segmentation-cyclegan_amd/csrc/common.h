@@ -7,6 +7,51 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---- element access for tensors that are fp32 or bfloat16 in HBM (arithmetic is always fp32)
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<__bf16>(const __bf16* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<__bf16>(__bf16* p, float v) { *p = (__bf16)v; }
+// four consecutive elements (16 bytes of fp32 / 8 bytes of bf16; the address must be aligned to that)
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float v[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float v[4]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <> __device__ __forceinline__ void ld4<__bf16>(const __bf16* p, float v[4]) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float v[4]) {
+    const f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+}
+template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, const float v[4]) {
+    const bf16x4 t = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = t;
+}
+// eight consecutive elements (bf16: one 16-byte access)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float v[8]) { ld4<float>(p, v); ld4<float>(p + 4, v + 4); }
+template <> __device__ __forceinline__ void ld8<__bf16>(const __bf16* p, float v[8]) {
+    const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float v[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float v[8]) { st4<float>(p, v); st4<float>(p + 4, v + 4); }
+template <> __device__ __forceinline__ void st8<__bf16>(__bf16* p, const float v[8]) {
+    bf16x8_t t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8_t*>(p) = t;
+}
 
 #define SSCG_OK 0
 #define SSCG_ERR_BAD_ARG (-1)

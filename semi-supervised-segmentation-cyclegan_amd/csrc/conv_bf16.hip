@@ -1,0 +1,824 @@
+// bfloat16 convolutions for BASELINE configs 3/5 (Cityscapes, "bf16"): activations and conv weights live in HBM as
+// bf16, the LDS tiles are bf16, the contraction is v_mfma_f32_32x32x16_bf16 with fp32 accumulation; bias, activation,
+// split-K partial sums and every weight gradient stay fp32 (the optimiser's master weights and moments are fp32).
+//
+// Same three products as conv_igemm.hip / conv_wgrad.hip (reference call sites: arch/ops.py:43,49,55-56,68;
+// arch/generators.py:325-336,373,388,415; arch/discriminators.py:45,58,70-75 and their autograd, model.py:472,539):
+//   forward / data gradient / ConvTranspose forward : D[m][n] = sum_k A[m][k] * B[n][k]   ("KC": both operands k-contiguous)
+//   weight gradient                                 : D[m][n] = sum_p A[p][m] * B[p][n]   (operands strided along p)
+//
+// One k-tile is 64 bf16 = 128 bytes per row - byte for byte the LDS image of the fp32 kernel's 32-float k-tile, so the
+// LDS-DMA staging (`global_load_lds_dwordx4`: 8 lanes x 16 B per row, lane-linear LDS image, XOR swizzle of the 16-byte
+// slot with (row >> 1) & 7 applied to the SOURCE address and to the fragment read alike) carries over unchanged, and a
+// lane's ds_read_b128 is now a complete 8-element MFMA operand: no per-fragment convert, half the HBM/L2/LDS bytes and
+// 1/16 of the matrix-core cycles of the fp32 walk.
+//
+// The weight gradient's operands are contiguous along the OUTPUT axes (channels) and strided along the reduction
+// (pixels), but a bf16 MFMA operand is 8 consecutive k of one row: the loader transposes 4-pixel x 8-channel pieces in
+// registers (16-bit interleaves) and writes [channel][pixel] rows, after which the contraction loop is the forward's.
+#include "common.h"
+#include "sscg_internal.h"
+
+namespace {
+
+constexpr int BK = 64;                     // bf16 elements per k-tile (128-byte rows)
+typedef __bf16 bf16;
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+// 256 B of zeros: the source of LDS-DMA lanes that fall into padding / outside the tile
+__device__ float sscg_zero_page16[64];
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct K16Params {
+    const bf16* __restrict__ src;    // A source (input for fwd, dy for dgrad), NHWC bf16
+    const bf16* __restrict__ wgt;    // [Ng][wKtot] bf16
+    const float* __restrict__ bias;  // [Ng] or null
+    void* __restrict__ dst;          // [M][Ng] bf16 or fp32
+    int out_bf16;
+    int M, Ng, Ktot, Cs;
+    int SH, SW, OH, OW;
+    int R, S;
+    int stride, pad, dil, pad_x;
+    int wKtot;
+    int wt_ky0, wt_kx0, wt_step, wt_S;
+    int o_step, o_a, o_b, o_W, o_HW;
+    int pad_mode, act;
+    float slope;
+    int tiles_n, tiles;
+    int splits, ksplit, full_tiles, m_tail0;
+    float* __restrict__ part;        // [splits][M - m_tail0][Ng] fp32 when splits > 1
+    // per-tile column statistics of the fp32 accumulators (fused norm statistics): [tiles_m][2][Ng][2] doubles or null
+    double* __restrict__ stats;
+    int stat_L;                      // rows per normalisation group (a tile spans at most two groups: stat_L >= BM)
+};
+
+__device__ __forceinline__ void store_out(void* dst, size_t idx, float v, int out_bf16) {
+    if (out_bf16) reinterpret_cast<bf16*>(dst)[idx] = (bf16)v;
+    else reinterpret_cast<float*>(dst)[idx] = v;
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int PA = BM / 32;           // 32 rows per loader pass (8 lanes x 16 B per row)
+    constexpr int PB = BN / 32;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16* As = reinterpret_cast<bf16*>(smem_raw);                   // [2][BM][64]
+    bf16* Bs = As + 2 * BM * BK;                                    // [2][BN][64]
+    int* tapinfo = reinterpret_cast<int*>(Bs + 2 * BN * BK);        // [R*S]: (dy << 16) | dx
+    int* wtapinfo = tapinfo + (p.R * p.S > 0 ? p.R * p.S : 1);      // [R*S]: tap index inside the weight row
+
+    const int tid = threadIdx.x;
+    int split = 0, tile;
+    bool partial = false;
+    if ((int)blockIdx.x < p.full_tiles) {
+        tile = xcd_remap(blockIdx.x, p.full_tiles);
+    } else {
+        const int ntail = p.tiles - p.full_tiles;
+        const int t = xcd_remap(blockIdx.x - p.full_tiles, gridDim.x - p.full_tiles);
+        split = t / ntail;
+        tile = p.full_tiles + (t - split * ntail);
+        partial = p.splits > 1;
+    }
+    const int tile_n = tile % p.tiles_n;
+    const int tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    for (int t = tid; t < p.R * p.S; t += 256) {
+        const int ky = t / p.S;
+        const int kx = t - ky * p.S;
+        tapinfo[t] = ((ky * p.dil) << 16) | (kx * p.dil);
+        wtapinfo[t] = (p.wt_ky0 + ky * p.wt_step) * p.wt_S + p.wt_kx0 + kx * p.wt_step;
+    }
+
+    const int r0 = tid >> 3;                        // row inside a pass
+    const int kq = (tid & 7) ^ swz(r0);             // 16-byte k slot this lane fetches: lands at LDS slot tid & 7 of row r0
+    const int wave_id = tid >> 6;
+
+    const bf16* arow[PA];
+    int ay0[PA], ax0[PA];
+    bool aok[PA];
+#pragma unroll
+    for (int ps = 0; ps < PA; ++ps) {
+        const int m = m0 + r0 + ps * 32;
+        aok[ps] = m < p.M;
+        const int mm = aok[ps] ? m : 0;
+        const int img = mm / (p.OH * p.OW);
+        const int rem = mm - img * (p.OH * p.OW);
+        const int oy = rem / p.OW;
+        const int ox = rem - oy * p.OW;
+        arow[ps] = p.src + (size_t)img * p.SH * p.SW * p.Cs;
+        if (MODE == MODE_FWD) {
+            ay0[ps] = oy * p.stride - p.pad;
+            ax0[ps] = ox * p.stride - p.pad_x;
+        } else {
+            ay0[ps] = oy + p.pad;
+            ax0[ps] = ox + p.pad_x;
+        }
+    }
+    const bf16* brow[PB];
+    bool bok[PB];
+#pragma unroll
+    for (int ps = 0; ps < PB; ++ps) {
+        const int n = n0 + r0 + ps * 32;
+        bok[ps] = n < p.Ng;
+        brow[ps] = p.wgt + (size_t)(bok[ps] ? n : 0) * p.wKtot + kq * 8;
+    }
+    __syncthreads();              // tapinfo visible
+
+    const bool reflect = p.pad_mode == 1;
+    auto locate = [&](int ps, int tdy, int tdx, int& pix) -> bool {
+        bool ok = aok[ps];
+        int sy, sx;
+        if (MODE == MODE_FWD) {
+            sy = ay0[ps] + tdy;
+            sx = ax0[ps] + tdx;
+            int ry = sy < 0 ? -sy : sy;
+            int rx = sx < 0 ? -sx : sx;
+            ry = ry >= p.SH ? 2 * (p.SH - 1) - ry : ry;
+            rx = rx >= p.SW ? 2 * (p.SW - 1) - rx : rx;
+            sy = reflect ? ry : sy;
+            sx = reflect ? rx : sx;
+        } else {
+            const int ty = ay0[ps] - tdy;
+            const int tx = ax0[ps] - tdx;
+            if (p.stride == 1) {
+                sy = ty; sx = tx;
+            } else if (p.stride == 2) {
+                sy = ty >> 1; sx = tx >> 1;
+                ok = ok && (((ty | tx) & 1) == 0);
+            } else {
+                sy = ty / p.stride; sx = tx / p.stride;
+                ok = ok && (ty >= 0) && (tx >= 0) && (sy * p.stride == ty) && (sx * p.stride == tx);
+            }
+        }
+        ok = ok && ((unsigned)sy < (unsigned)p.SH) && ((unsigned)sx < (unsigned)p.SW);
+        pix = ok ? sy * p.SW + sx : 0;
+        return ok;
+    };
+
+    const int nk_all = p.Ktot / BK;                          // Cs % 64 == 0: a k-tile never straddles a tap
+    const int kt0 = partial ? split * p.ksplit : 0;
+    const int kt1 = partial ? min(nk_all, kt0 + p.ksplit) : nk_all;
+    const int f_nchunk = p.Cs / BK;
+    int f_tap = kt0 / f_nchunk;
+    int f_chunk = kt0 - f_tap * f_nchunk;
+    int f_k = 0;
+    const bf16* aptr[PA];
+    unsigned f_okbits = 0;
+    int dma_buf = 0;
+    const bf16* zero = reinterpret_cast<const bf16*>(sscg_zero_page16);
+
+    auto set_tap = [&](int tap) {
+        const int ti = tapinfo[tap];
+        const int tdy = ti >> 16, tdx = ti & 0xffff;
+        f_k = wtapinfo[tap] * p.Cs;
+        f_okbits = 0;
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            int pix;
+            const bool ok = locate(ps, tdy, tdx, pix);
+            f_okbits |= ok ? (1u << ps) : 0u;
+            aptr[ps] = arow[ps] + (size_t)pix * p.Cs + kq * 8;
+        }
+    };
+    set_tap(f_tap < p.R * p.S ? f_tap : 0);
+    f_k += f_chunk * BK;
+
+    auto load_tile = [&]() {
+        if (f_chunk == f_nchunk) {       // wave-uniform: next tap
+            f_chunk = 0;
+            ++f_tap;
+            set_tap(f_tap < p.R * p.S ? f_tap : 0);
+        }
+        const int coff = f_chunk * BK;
+        bf16* la = As + dma_buf * BM * BK + wave_id * 512;       // wave w stages rows 8w .. 8w+7 of every 32-row pass
+        bf16* lb = Bs + dma_buf * BN * BK + wave_id * 512;
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            const bf16* g = ((f_okbits >> ps) & 1u) ? aptr[ps] + coff : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(la + ps * 2048), 16, 0, 0);
+        }
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) {
+            const bf16* g = bok[ps] ? brow[ps] + f_k : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lb + ps * 2048), 16, 0, 0);
+        }
+        dma_buf ^= 1;
+        ++f_chunk;
+        f_k += BK;
+    };
+
+    const int lane = tid & 63;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int wm = wave_id / WN;
+    const int wn = wave_id % WN;
+    const int row_w = wm * TM * 32;
+    const int col_w = wn * TN * 32;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = kt1 - kt0;
+    if (nk > 0) load_tile();
+    __syncthreads();
+    const int sw = swz(li);                    // rows row_w + i*32 + li: (row >> 1) & 7 == (li >> 1) & 7
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bf16* a = As + buf * BM * BK + (row_w + li) * BK;
+        const bf16* b = Bs + buf * BN * BK + (col_w + li) * BK;
+        // MFMA kk contracts k = 16 kk .. 16 kk + 15 of the tile: lane half h supplies the 8 elements of slot 2 kk + h
+        bf16x8 fa[4][TM], fb[4][TN];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int off = ((kk * 2 + lh) ^ sw) * 8;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[kk][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * BK + off);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[kk][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * BK + off);
+        }
+        if (kt + 1 < nk) load_tile();          // the copies of tile kt+1 land under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // Fused normalisation statistics (InstanceNorm / BatchNorm of the layer that follows, arch/ops.py:40-57): column sums of
+    // x and x^2 over this tile's rows, taken from the fp32 accumulators (+ bias), in fp64; a tile may straddle ONE group
+    // boundary (rows m < gb belong to the tile's first group, the rest to the next one).
+    const bool want_stats = p.stats != nullptr && !partial;
+    int gb = 0x7fffffff;
+    if (want_stats) {
+        const int g0 = m0 / p.stat_L;
+        gb = (g0 + 1) * p.stat_L;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + col_w + j * 32 + li;
+        const bool nok = n < p.Ng;
+        const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+        double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.M && nok) {
+                    if (partial) {
+                        p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc[i][j][e];
+                    } else {
+                        const float pre = acc[i][j][e] + bv;
+                        if (want_stats) {
+                            const double d = (double)pre;
+                            if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
+                        }
+                        size_t row = (size_t)m;
+                        if (p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
+                            const int img = m / (p.OH * p.OW);
+                            const int rem = m - img * (p.OH * p.OW);
+                            const int oi = rem / p.OW;
+                            const int oj = rem - oi * p.OW;
+                            row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+                        }
+                        store_out(p.dst, row * p.Ng + n, sscg_act(pre, p.act, p.slope), p.out_bf16);
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            // the two lane halves hold different rows of the same column
+            s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+            s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+            if (lh == 0 && nok) {
+                // record (tile_m, wm): [ (tile_m * WM + wm) ][2 groups][Ng][2]
+                double* rec = p.stats + ((size_t)(tile_m * WM + wm) * 2) * p.Ng * 2;
+                rec[(size_t)n * 2] = s0; rec[(size_t)n * 2 + 1] = q0;
+                rec[((size_t)p.Ng + n) * 2] = s1; rec[((size_t)p.Ng + n) * 2 + 1] = q1;
+            }
+        }
+    }
+}
+
+// y[i] = act(sum_s part[s][i] + bias[i % Ng]) (fixed order => deterministic)
+__global__ __launch_bounds__(256) void k16_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, void* __restrict__ y,
+                                                          int out_bf16, size_t n, int Ng, int splits, int act, float slope) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
+    if (bias) s += bias[(int)(i % Ng)];
+    store_out(y, i, sscg_act(s, act, slope), out_bf16);
+}
+
+// ---- host-side plan
+enum { CFG_128x128 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_128x64 = 3 };
+const int C16_BM[4] = {128, 64, 128, 128};
+const int C16_BN[4] = {128, 64, 32, 64};
+
+int choose16(long M, int Ng) {
+    if (Ng <= 32) return CFG_128x32;
+    const long t128 = (long)cdiv(M, 128) * cdiv(Ng, 128);
+    if (Ng >= 128 && t128 >= 384) return CFG_128x128;
+    if (Ng <= 64 && cdiv(M, 128) >= 384) return CFG_128x64;
+    return CFG_64x64;
+}
+
+struct K16Split { int splits, ksplit, full_tiles, m_tail0; };
+
+// Which tiles are cut along K (same policy as conv_igemm.hip): few-channel heads on few rows split every tile; 64x64
+// launches split only the tail beyond the last whole round of 256 workgroups.
+K16Split plan16_raw(long M, int Ng, int Ktot);
+
+// stat_L > 0: the launch also produces normalisation statistics; the rows of split tiles are summed separately as ONE
+// extra group of records, so they must lie in one normalisation group (else the launch is not split).
+K16Split plan16(long M, int Ng, int Ktot, long stat_L = 0) {
+    K16Split r = plan16_raw(M, Ng, Ktot);
+    if (stat_L > 0 && r.splits > 1 && (r.full_tiles == 0 || r.m_tail0 / stat_L != (M - 1) / stat_L)) {
+        const int cfg = choose16(M, Ng);
+        r.splits = 1; r.ksplit = Ktot / BK;
+        r.full_tiles = cdiv(M, C16_BM[cfg]) * cdiv(Ng, C16_BN[cfg]); r.m_tail0 = (int)M;
+    }
+    return r;
+}
+
+K16Split plan16_raw(long M, int Ng, int Ktot) {
+    const int nk = Ktot / BK;
+    const int cfg = choose16(M, Ng);
+    const int bm = C16_BM[cfg], bn = C16_BN[cfg];
+    const int tiles_m = cdiv(M, bm), tiles_n = cdiv(Ng, bn);
+    const int tiles = tiles_m * tiles_n;
+    K16Split r = {1, nk, tiles, (int)M};
+    if (Ng <= 32) {
+        if (tiles >= 256 || nk < 16) return r;
+        int s = cdiv(512, tiles);
+        if (s > nk / 4) s = nk / 4;
+        if (s > 32) s = 32;
+        if (s < 2) return r;
+        r.ksplit = cdiv(nk, s);
+        r.splits = cdiv(nk, r.ksplit);
+        r.full_tiles = 0; r.m_tail0 = 0;
+        return r;
+    }
+    if (cfg != CFG_64x64 || nk < 8 || tiles > 2300) return r;
+    const int q = tiles / 256;
+    const int full_m = (q * 256) / tiles_n;
+    const int tail = tiles - full_m * tiles_n;
+    if (tail <= 0 || tail > 208) return r;
+    int s = 256 / tail;
+    if (s > 8) s = 8;
+    if (s > nk / 4) s = nk / 4;
+    if (s < 2) return r;
+    r.ksplit = cdiv(nk, s);
+    r.splits = cdiv(nk, r.ksplit);
+    r.full_tiles = full_m * tiles_n;
+    r.m_tail0 = full_m * bm;
+    return r;
+}
+
+size_t split16_bytes(const K16Split& sp, long M, int Ng) {
+    return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+int launch16(const K16Params& p0, hipStream_t st) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    K16Params p = p0;
+    p.tiles_n = cdiv(p.Ng, BN);
+    const int tiles_m = cdiv(p.M, BM);
+    p.tiles = tiles_m * p.tiles_n;
+    const size_t smem = (size_t)(2 * BM * BK + 2 * BN * BK) * sizeof(bf16) + (size_t)(p.R * p.S > 0 ? p.R * p.S : 1) * 8;
+    auto kern = conv16_kernel<MODE, WM, WN, TM, TN>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
+    const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
+    SSCG_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        const size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
+        const size_t esz = p.out_bf16 ? 2 : 4;
+        void* yt = reinterpret_cast<char*>(p.dst) + (size_t)p.m_tail0 * p.Ng * esz;
+        hipLaunchKernelGGL(k16_reduce_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, p.part, p.bias, yt, p.out_bf16, n, p.Ng,
+                           p.splits, p.act, p.slope);
+        SSCG_LAUNCH_CHECK();
+    }
+    return SSCG_OK;
+}
+
+template <int MODE>
+int dispatch16(const K16Params& p, hipStream_t st) {
+    switch (choose16(p.M, p.Ng)) {
+        case CFG_128x128: return launch16<MODE, 2, 2, 2, 2>(p, st);
+        case CFG_64x64: return launch16<MODE, 2, 2, 1, 1>(p, st);
+        case CFG_128x32: return launch16<MODE, 4, 1, 1, 1>(p, st);
+        case CFG_128x64: return launch16<MODE, 2, 2, 2, 1>(p, st);
+        default: return SSCG_ERR_BAD_ARG;
+    }
+}
+
+void dense_taps(K16Params& p) {
+    p.pad_x = p.pad; p.wKtot = p.Ktot;
+    p.wt_ky0 = 0; p.wt_kx0 = 0; p.wt_step = 1; p.wt_S = p.S;
+    p.o_step = 1; p.o_a = 0; p.o_b = 0; p.o_W = 0; p.o_HW = 0;
+}
+
+bool dgrad16_by_parity(const sscg_conv_desc* d) { return d->stride == 2 && d->dil == 1 && d->pad_mode == 0; }
+
+}  // namespace
+
+// ---- entry points used by conv_igemm.hip's dispatch (same argument meaning as the public sscg_conv2d_* functions)
+bool sscg_conv16_fwd_applies(const sscg_conv_desc* d) {
+    return d->x_dtype == SSCG_BF16 && d->w_dtype == SSCG_BF16 && d->C % BK == 0;
+}
+
+bool sscg_conv16_dgrad_applies(const sscg_conv_desc* d) {
+    return d->y_dtype == SSCG_BF16 && d->w_dtype == SSCG_BF16 && d->K % BK == 0;
+}
+
+// geometry of the statistics records of a forward launch (records = [tiles_m * wm][2 groups][K][2] doubles)
+bool sscg_conv16_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* wm, int* tiles_n, int* splits, int* full_tiles, int* m_tail0) {
+    const long M = (long)d->N * d->P * d->Q;
+    const int cfg = choose16(M, d->K);
+    if (cfg == CFG_128x32 || L < C16_BM[cfg]) return false;
+    *bm = C16_BM[cfg];
+    *wm = 2;
+    *tiles_n = cdiv(d->K, C16_BN[cfg]);
+    K16Split sp = plan16(M, d->K, d->R * d->S * d->C, L);
+    *splits = sp.splits; *full_tiles = sp.full_tiles; *m_tail0 = sp.m_tail0;
+    return true;
+}
+
+size_t sscg_conv16_fwd_workspace(const sscg_conv_desc* d, long stat_L) {
+    const long M = (long)d->N * d->P * d->Q;
+    return split16_bytes(plan16(M, d->K, d->R * d->S * d->C, stat_L), M, d->K);
+}
+
+size_t sscg_conv16_dgrad_workspace(const sscg_conv_desc* d) {
+    if (dgrad16_by_parity(d)) return 0;
+    const long M = (long)d->N * d->H * d->W;
+    return split16_bytes(plan16(M, d->C, d->R * d->S * d->K), M, d->C);
+}
+
+int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
+                    void* ws, size_t ws_bytes, hipStream_t st) {
+    K16Params p = {};
+    p.src = reinterpret_cast<const bf16*>(x); p.wgt = reinterpret_cast<const bf16*>(w); p.bias = bias; p.dst = y;
+    p.out_bf16 = d->y_dtype == SSCG_BF16;
+    p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Cs = d->C; p.Ktot = d->R * d->S * d->C;
+    p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope;
+    p.stats = stats; p.stat_L = (int)stat_L;
+    dense_taps(p);
+    K16Split sp = plan16(p.M, p.Ng, p.Ktot, stats ? stat_L : 0);
+    if (sp.splits > 1 && (!ws || ws_bytes < split16_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
+    p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
+    p.part = reinterpret_cast<float*>(ws);
+    return dispatch16<MODE_FWD>(p, st);
+}
+
+int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
+                      void* ws, size_t ws_bytes, hipStream_t st) {
+    K16Params p = {};
+    p.src = reinterpret_cast<const bf16*>(dy); p.wgt = reinterpret_cast<const bf16*>(wt); p.bias = bias; p.dst = dx;
+    p.out_bf16 = d->x_dtype == SSCG_BF16;
+    p.M = d->N * d->H * d->W; p.Ng = d->C; p.Cs = d->K; p.Ktot = d->R * d->S * d->K;
+    p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.pad_mode = 0; p.act = act; p.slope = slope;
+    dense_taps(p);
+    if (dgrad16_by_parity(d)) {
+        // stride 2: four parity classes, each a stride-1 data gradient over its sub-lattice of taps (conv_igemm.hip)
+        p.splits = 1; p.ksplit = 0; p.part = nullptr;
+        p.stride = 1; p.wt_step = 2; p.wt_S = d->S;
+        p.o_step = 2; p.o_W = d->W; p.o_HW = d->H * d->W;
+        for (int a = 0; a < 2; ++a) {
+            for (int b = 0; b < 2; ++b) {
+                const int Ha = (d->H - a + 1) / 2, Wb = (d->W - b + 1) / 2;
+                if (Ha <= 0 || Wb <= 0) continue;
+                const int ky0 = (a + d->pad) & 1, kx0 = (b + d->pad) & 1;
+                K16Params q = p;
+                q.R = ky0 < d->R ? (d->R - ky0 + 1) / 2 : 0;
+                q.S = kx0 < d->S ? (d->S - kx0 + 1) / 2 : 0;
+                if (q.R == 0 || q.S == 0) { q.R = 0; q.S = 0; }
+                q.pad = (a + d->pad - ky0) / 2;
+                q.pad_x = (b + d->pad - kx0) / 2;
+                q.wt_ky0 = ky0; q.wt_kx0 = kx0;
+                q.o_a = a; q.o_b = b;
+                q.OH = Ha; q.OW = Wb;
+                q.M = d->N * Ha * Wb;
+                q.Ktot = q.R * q.S * q.Cs;
+                int rc = dispatch16<MODE_DGRAD>(q, st);
+                if (rc) return rc;
+            }
+        }
+        return SSCG_OK;
+    }
+    K16Split sp = plan16(p.M, p.Ng, p.Ktot);
+    if (sp.splits > 1 && (!ws || ws_bytes < split16_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
+    p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
+    p.part = reinterpret_cast<float*>(ws);
+    return dispatch16<MODE_DGRAD>(p, st);
+}
+
+// =====================================================================================================================
+// weight gradient, both operands bf16:  dW[k][tap][c] = sum_p dy[p][k] * x[src(p, tap)][c]   (fp32 out)
+namespace {
+
+constexpr int BKP = 64;      // pixels per k-step
+
+struct Wg16Params {
+    const bf16* __restrict__ x;
+    const bf16* __restrict__ dy;
+    float* __restrict__ out;      // dw (splits == 1) or workspace [splits][Kc][Ng]
+    int Kc, Ng, C;
+    int H, W, P, Q, S;
+    int stride, pad, dil, pad_mode;
+    int npix, chunk;
+    int tiles_n, tiles, splits;
+    float beta;
+    FastDiv div_pq, div_q;
+};
+
+// 8 pixels x 8 channels (eight 16-byte rows, channel pairs packed in words) -> 8 channels x 8 pixels (eight 16-byte rows)
+struct U4 { uint32_t v[4]; };
+__device__ __forceinline__ void transpose_8x8(const U4 r[8], U4 out[8]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {          // word w of a row = channels 2w (low half), 2w+1 (high half)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {   // pixel pair (2jj, 2jj+1)
+            out[2 * w].v[jj] = (r[2 * jj].v[w] & 0xffffu) | (r[2 * jj + 1].v[w] << 16);
+            out[2 * w + 1].v[jj] = (r[2 * jj].v[w] >> 16) | (r[2 * jj + 1].v[w] & 0xffff0000u);
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad16_kernel(Wg16Params p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    static_assert(WM * WN == 4 && BM + BN <= 256, "4 waves per workgroup; one 8x8 piece per thread");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16* As = reinterpret_cast<bf16*>(smem_raw);      // [2][BM][64]: row = output channel k, 64 pixels contiguous
+    bf16* Bs = As + 2 * BM * BKP;                       // [2][BN][64]: row = (tap, c)
+
+    const int tid = threadIdx.x;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / p.tiles;
+    const int tl = lin - split * p.tiles;
+    const int tile_n = tl % p.tiles_n;
+    const int tile_m = tl / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int p_begin = split * p.chunk;
+    const int p_end = min(p.npix, p_begin + p.chunk);
+    const bool reflect = p.pad_mode == 1;
+
+    // One piece per thread: 8 pixels (block pb of the k-step) x 8 channels (group grp).  Eight consecutive lanes hold the
+    // eight pixel blocks of one channel group: a global load instruction reads 8 x 16 B = one 128-byte line per pixel row
+    // and eight channel groups, a ds_write_b128 lane group fills one whole 128-byte LDS row (conflict free).
+    const bool active = tid < BM + BN;
+    const bool isA = tid < BM;                  // wave-uniform: BM, BN are multiples of 64
+    const int qq = isA ? tid : tid - BM;
+    const int grp = qq >> 3;
+    const int pb = qq & 7;
+    bool col_ok = false;
+    const bf16* base = p.dy;
+    int tdy = 0, tdx = 0;
+    if (active) {
+        if (isA) {
+            const int m = m0 + grp * 8;
+            col_ok = m < p.Kc;
+            base = p.dy + (col_ok ? m : 0);
+        } else {
+            const int n = n0 + grp * 8;
+            col_ok = n < p.Ng;
+            const int nn = col_ok ? n : 0;
+            const int tap = nn / p.C;
+            const int c = nn - tap * p.C;
+            const int ky = tap / p.S;
+            const int kx = tap - ky * p.S;
+            tdy = ky * p.dil - p.pad;
+            tdx = kx * p.dil - p.pad;
+            base = p.x + c;
+        }
+    }
+
+    U4 stage[8];
+    auto load_tile = [&](int pt) {
+        if (!active) return;
+        const int pix0 = pt + pb * 8;
+        if (isA) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pix = pix0 + j;
+                const bool ok = col_ok && pix < p_end;
+                const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)(ok ? pix : 0) * p.Kc);
+                stage[j].v[0] = ok ? v.x : 0u; stage[j].v[1] = ok ? v.y : 0u;
+                stage[j].v[2] = ok ? v.z : 0u; stage[j].v[3] = ok ? v.w : 0u;
+            }
+        } else {
+            // decode the first pixel, then walk (ox, oy, img) incrementally
+            const int pp = pix0 < p_end ? pix0 : 0;
+            int img = fd_div(pp, p.div_pq);
+            const int rem = pp - img * (p.P * p.Q);
+            int oy = fd_div(rem, p.div_q);
+            int ox = rem - oy * p.Q;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bool ok = col_ok && (pix0 + j) < p_end;
+                int sy = oy * p.stride + tdy;
+                int sx = ox * p.stride + tdx;
+                int ry = sy < 0 ? -sy : sy;
+                int rx = sx < 0 ? -sx : sx;
+                ry = ry >= p.H ? 2 * (p.H - 1) - ry : ry;
+                rx = rx >= p.W ? 2 * (p.W - 1) - rx : rx;
+                sy = reflect ? ry : sy;
+                sx = reflect ? rx : sx;
+                ok = ok && ((unsigned)sy < (unsigned)p.H) && ((unsigned)sx < (unsigned)p.W);
+                const size_t off = ok ? (size_t)((img * p.H + sy) * p.W + sx) * p.C : 0;
+                const uint4 v = *reinterpret_cast<const uint4*>(base + off);
+                stage[j].v[0] = ok ? v.x : 0u; stage[j].v[1] = ok ? v.y : 0u;
+                stage[j].v[2] = ok ? v.z : 0u; stage[j].v[3] = ok ? v.w : 0u;
+                ++ox;
+                if (ox == p.Q) { ox = 0; ++oy; if (oy == p.P) { oy = 0; ++img; } }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (!active) return;
+        U4 out[8];
+        transpose_8x8(stage, out);
+        bf16* img = isA ? As + buf * BM * BKP : Bs + buf * BN * BKP;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int row = grp * 8 + c;
+            uint4 w = {out[c].v[0], out[c].v[1], out[c].v[2], out[c].v[3]};
+            *reinterpret_cast<uint4*>(img + row * BKP + ((pb ^ swz(row)) * 8)) = w;
+        }
+    };
+
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int row_w = wm * TM * 32;
+    const int col_w = wn * TN * 32;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nsteps = (p_end - p_begin + BKP - 1) / BKP;
+    if (nsteps > 0) {
+        load_tile(p_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int sw = swz(li);
+    for (int it = 0; it < nsteps; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nsteps) load_tile(p_begin + (it + 1) * BKP);      // global loads fly under the MFMAs
+        const bf16* a = As + buf * BM * BKP + (row_w + li) * BKP;
+        const bf16* b = Bs + buf * BN * BKP + (col_w + li) * BKP;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int off = ((kk * 2 + lh) ^ sw) * 8;
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * BKP + off);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * BKP + off);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < nsteps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = p.out + (size_t)split * p.Kc * p.Ng;
+    const bool direct = (p.splits == 1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + col_w + j * 32 + li;
+        if (n >= p.Ng) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.Kc) {
+                    const size_t o = (size_t)m * p.Ng + n;
+                    float v = acc[i][j][e];
+                    if (direct && p.beta != 0.f) v += p.beta * out[o];
+                    out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+struct Wg16Plan { int cfg, bm, bn, splits, chunk; };
+
+// Split of the pixel range: enough workgroups for ~3 rounds of the 256 CUs, at least 4 k-steps each.
+Wg16Plan plan_wg16(const sscg_conv_desc* d) {
+    Wg16Plan pl;
+    const int Kc = d->K, Ng = d->R * d->S * d->C;
+    const long npix = (long)d->N * d->P * d->Q;
+    const long steps = cdiv(npix, BKP);
+    pl.cfg = (Kc >= 128 && Ng >= 128 && (long)cdiv(Kc, 128) * cdiv(Ng, 128) >= 8) ? 0 : 1;
+    pl.bm = pl.bn = pl.cfg == 0 ? 128 : 64;
+    const long tiles = (long)cdiv(Kc, pl.bm) * cdiv(Ng, pl.bn);
+    long s = cdiv(768, tiles);
+    if (s > steps / 4) s = steps / 4;
+    if (s > 1024) s = 1024;
+    if (s < 1) s = 1;
+    const long steps_per = cdiv(steps, s);
+    pl.chunk = (int)(steps_per * BKP);
+    pl.splits = cdiv(npix, pl.chunk);
+    return pl;
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_wg16(Wg16Params p, int splits, hipStream_t st) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    p.tiles_n = cdiv(p.Ng, BN);
+    p.tiles = cdiv(p.Kc, BM) * p.tiles_n;
+    p.splits = splits;
+    const size_t smem = (size_t)(2 * BM * BKP + 2 * BN * BKP) * sizeof(bf16);
+    auto kern = wgrad16_kernel<WM, WN, TM, TN>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles * splits), dim3(256), smem, st, p);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+}  // namespace
+
+bool sscg_wgrad16_applies(const sscg_conv_desc* d) {
+    return d->x_dtype == SSCG_BF16 && d->y_dtype == SSCG_BF16 && d->K % 8 == 0 && d->C % 8 == 0 && d->K >= 32 &&
+           (long)d->R * d->S * d->C >= 32;
+}
+
+size_t sscg_wgrad16_workspace(const sscg_conv_desc* d) {
+    Wg16Plan pl = plan_wg16(d);
+    return pl.splits > 1 ? (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float) : 0;
+}
+
+int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, size_t ws_bytes, hipStream_t st) {
+    Wg16Plan pl = plan_wg16(d);
+    const size_t need = sscg_wgrad16_workspace(d);
+    if (need > 0 && (!ws || ws_bytes < need)) return SSCG_ERR_WORKSPACE;
+    Wg16Params p = {};
+    p.x = reinterpret_cast<const bf16*>(x); p.dy = reinterpret_cast<const bf16*>(dy);
+    p.out = pl.splits > 1 ? reinterpret_cast<float*>(ws) : dw;
+    p.Kc = d->K; p.Ng = d->R * d->S * d->C; p.C = d->C;
+    p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.S = d->S;
+    p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.pad_mode = d->pad_mode;
+    p.npix = d->N * d->P * d->Q; p.chunk = pl.chunk;
+    p.beta = pl.splits > 1 ? 0.f : beta;
+    p.div_pq = make_fastdiv(d->P * d->Q);
+    p.div_q = make_fastdiv(d->Q);
+    int rc = pl.cfg == 0 ? launch_wg16<2, 2, 2, 2>(p, pl.splits, st) : launch_wg16<2, 2, 1, 1>(p, pl.splits, st);
+    if (rc) return rc;
+    if (pl.splits > 1) return sscg_wgrad_reduce(reinterpret_cast<const float*>(ws), dw, (size_t)d->K * p.Ng, pl.splits, beta, st);
+    return SSCG_OK;
+}

@@ -26,8 +26,6 @@
 #include "common.h"
 #include "sscg_internal.h"
 
-int sscg_conv_precision = 0;     // 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulation (sscg_set_conv_precision); read by conv_wgrad.hip
-
 namespace {
 
 #ifndef SSCG_BK
@@ -46,7 +44,9 @@ struct KcParams {
     const float* __restrict__ src;   // A source (input for fwd, dy for dgrad)
     const float* __restrict__ wgt;   // [Ng][Ktot]
     const float* __restrict__ bias;  // [Ng] or null
-    float* __restrict__ dst;         // [M][Ng]
+    void* __restrict__ dst;          // [M][Ng] fp32 or bf16 (out_bf16)
+    int out_bf16;
+    int precision;                   // host side: 1 = bf16 contraction of the fp32 tiles (sscg_conv_desc.precision)
     int M, Ng, Ktot, Cs;
     int SH, SW;   // source spatial
     int OH, OW;   // destination spatial (row decode)
@@ -66,7 +66,15 @@ struct KcParams {
     int full_tiles; // tiles [0, full_tiles) are computed whole by one workgroup each; the rest ("tail") are split
     int m_tail0;    // first output row of the tail tiles
     float* __restrict__ part;  // [splits][M - m_tail0][Ng] when splits > 1
+    // fused normalisation statistics (see conv_bf16.hip): records [tile_m * WM + wave_row][2 groups][Ng][2] doubles, or null
+    double* __restrict__ stats;
+    int stat_L;
 };
+
+__device__ __forceinline__ void store_out(void* dst, size_t idx, float v, int out_bf16) {
+    if (out_bf16) reinterpret_cast<__bf16*>(dst)[idx] = (__bf16)v;
+    else reinterpret_cast<float*>(dst)[idx] = v;
+}
 
 // 256 B of zeros: the source of LDS-DMA lanes that fall into padding / outside the tile
 __device__ float sscg_zero_page[64];
@@ -476,27 +484,39 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
                         const int oj = rem - oi * p.OW;
                         row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
                     }
-                    p.dst[row * p.Ng + n] = sscg_act(acc4[r] + bv, p.act, p.slope);
+                    store_out(p.dst, row * p.Ng + n, sscg_act(acc4[r] + bv, p.act, p.slope), p.out_bf16);
                 }
             }
         }
         return;
     }
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // Fused statistics of the normalisation layer that follows (arch/ops.py:40-57; arch/generators.py:345-365): fp64 column
+    // sums of y and y^2 over this tile's rows; rows m >= gb belong to the next normalisation group (a tile straddles at most
+    // one group boundary: stat_L >= BM).
+    const bool want_stats = p.stats != nullptr && !partial;
+    int gb = 0x7fffffff;
+    if (want_stats) gb = (m0 / p.stat_L + 1) * p.stat_L;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + col_w + j * 32 + li;
-        if (n >= p.Ng) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const bool nok = n < p.Ng;
+        const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+        double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < p.M) {
+                if (m < p.M && nok) {
                     if (partial) {
                         p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc[i][j][e];
                     } else {
+                        const float pre = acc[i][j][e] + bv;
+                        if (want_stats) {
+                            const double d = (double)pre;
+                            if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
+                        }
                         size_t row = (size_t)m;
                         if (p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
                             const int img = m / (p.OH * p.OW);
@@ -505,9 +525,18 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
                             const int oj = rem - oi * p.OW;
                             row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
                         }
-                        p.dst[row * p.Ng + n] = sscg_act(acc[i][j][e] + bv, p.act, p.slope);
+                        store_out(p.dst, row * p.Ng + n, sscg_act(pre, p.act, p.slope), p.out_bf16);
                     }
                 }
+            }
+        }
+        if (want_stats) {
+            s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);      // the lane halves hold different rows of a column
+            s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+            if (lh == 0 && nok) {
+                double* rec = p.stats + ((size_t)(tile_m * WM + wm) * 2) * p.Ng * 2;
+                rec[(size_t)n * 2] = s0; rec[(size_t)n * 2 + 1] = q0;
+                rec[((size_t)p.Ng + n) * 2] = s1; rec[((size_t)p.Ng + n) * 2 + 1] = q1;
             }
         }
     }
@@ -516,7 +545,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
 // y[i] = act(sum_s part[s][i] + bias[i % Ng])   (fixed order => deterministic); V floats per thread
 template <int V>
 __global__ __launch_bounds__(256) void kc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                         float* __restrict__ y, size_t n, int Ng, int splits, int act, float slope) {
+                                                         void* __restrict__ y, int out_bf16, size_t n, int Ng, int splits, int act, float slope) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (i >= n) return;
     typedef float vec_t __attribute__((ext_vector_type(V)));
@@ -524,13 +553,20 @@ __global__ __launch_bounds__(256) void kc_reduce_kernel(const float* __restrict_
 #pragma unroll 8
     for (int k = 0; k < splits; ++k) s += *reinterpret_cast<const vec_t*>(part + (size_t)k * n + i);
     const int c = (int)(i % Ng);
+    float o[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         float v = s[e];
         if (bias) v += bias[c + e];     // V == 4 only when Ng % 4 == 0: the V channels are consecutive
-        s[e] = sscg_act(v, act, slope);
+        o[e] = sscg_act(v, act, slope);
     }
-    *reinterpret_cast<vec_t*>(y + i) = s;
+    if (out_bf16) {
+        __bf16* yb = reinterpret_cast<__bf16*>(y) + i;
+        if constexpr (V == 4) st4<__bf16>(yb, o); else st1<__bf16>(yb, o[0]);
+    } else {
+        float* yf = reinterpret_cast<float*>(y) + i;
+        if constexpr (V == 4) st4<float>(yf, o); else st1<float>(yf, o[0]);
+    }
 }
 
 // ---- host-side plan: tile configuration + split-K of the tail
@@ -559,7 +595,21 @@ struct KcSplit { int splits, ksplit, full_tiles, m_tail0; };
 //  * 64x64-tile launches: only the TAIL - the tiles beyond the last whole round of 256 workgroups.  The DeepLab
 //    stride-8 maps give 8712 rows -> 548 tiles: 512 whole tiles (2 per CU) + 36 tail tiles cut in 7, so every CU gets
 //    2 1/7 tiles of work instead of 2 or 3 (71 % balance), and only 6.5 % of the output goes through partial sums.
-static KcSplit plan_kc_split(int M, int Ng, int Ktot, int Cs) {
+static KcSplit plan_kc_split_raw(int M, int Ng, int Ktot, int Cs);
+
+// stat_L > 0: the launch also produces normalisation statistics.  Split tiles write partial sums, not results, so their
+// rows are summed separately (one extra group of records): they must all lie in ONE normalisation group.
+static KcSplit plan_kc_split(int M, int Ng, int Ktot, int Cs, long stat_L = 0) {
+    KcSplit r = plan_kc_split_raw(M, Ng, Ktot, Cs);
+    if (stat_L > 0 && r.splits > 1 && (r.full_tiles == 0 || r.m_tail0 / stat_L != (M - 1) / stat_L)) {
+        const int cfg = kc_choose_cfg(M, Ng, Ktot, Cs);
+        r.splits = 1; r.ksplit = (Ktot + BK - 1) / BK;
+        r.full_tiles = cdiv(M, KC_BM[cfg]) * cdiv(Ng, KC_BN[cfg]); r.m_tail0 = M;
+    }
+    return r;
+}
+
+static KcSplit plan_kc_split_raw(int M, int Ng, int Ktot, int Cs) {
     const int nk = (Ktot + BK - 1) / BK;
     const int cfg = kc_choose_cfg(M, Ng, Ktot, Cs);
     const int bm = KC_BM[cfg], bn = KC_BN[cfg];
@@ -625,13 +675,13 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     SSCG_LAUNCH_CHECK();
     if (p.splits > 1) {
         size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
-        float* yt = p.dst + (size_t)p.m_tail0 * p.Ng;
+        void* yt = reinterpret_cast<char*>(p.dst) + (size_t)p.m_tail0 * p.Ng * (p.out_bf16 ? 2 : 4);
         if (p.Ng % 4 == 0 && (((size_t)yt | (size_t)p.part) & 15) == 0)
-            hipLaunchKernelGGL(kc_reduce_kernel<4>, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st, p.part, p.bias, yt, n, p.Ng,
-                               p.splits, p.act, p.slope);
+            hipLaunchKernelGGL(kc_reduce_kernel<4>, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st, p.part, p.bias, yt, p.out_bf16, n,
+                               p.Ng, p.splits, p.act, p.slope);
         else
-            hipLaunchKernelGGL(kc_reduce_kernel<1>, dim3(cdiv((long)n, 256)), dim3(256), 0, st, p.part, p.bias, yt, n, p.Ng,
-                               p.splits, p.act, p.slope);
+            hipLaunchKernelGGL(kc_reduce_kernel<1>, dim3(cdiv((long)n, 256)), dim3(256), 0, st, p.part, p.bias, yt, p.out_bf16, n,
+                               p.Ng, p.splits, p.act, p.slope);
         SSCG_LAUNCH_CHECK();
     }
     return SSCG_OK;
@@ -640,19 +690,19 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
 template <int MODE, int VEC, bool FAST>
 int dispatch_kc(const KcParams& p, hipStream_t st) {
     switch (kc_choose_cfg(p.M, p.Ng, p.Ktot, p.Cs)) {
-        case 0: if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, false, true>(p, st);
+        case 0: if (p.precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, false, true>(p, st);
                 return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST>(p, st);
-        case 1: if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 2, 1, VEC, FAST, 2, false, true>(p, st);
+        case 1: if (p.precision == 1) return launch_kc<MODE, 2, 2, 2, 1, VEC, FAST, 2, false, true>(p, st);
                 return launch_kc<MODE, 2, 2, 2, 1, VEC, FAST>(p, st);
-        case 2: if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 1, 2, VEC, FAST, 2, false, true>(p, st);
+        case 2: if (p.precision == 1) return launch_kc<MODE, 2, 2, 1, 2, VEC, FAST, 2, false, true>(p, st);
                 return launch_kc<MODE, 2, 2, 1, 2, VEC, FAST>(p, st);
-        case 3: if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, false, true>(p, st);
+        case 3: if (p.precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, false, true>(p, st);
                 return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST>(p, st);
-        case 4: if (sscg_conv_precision == 1) return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST, 2, false, true>(p, st);
+        case 4: if (p.precision == 1) return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST, 2, false, true>(p, st);
                 return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST>(p, st);
         case 5: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 1>(p, st);   // 128x128, single LDS image (experimental)
-        case 6: if constexpr (FAST) { if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
-        case 7: if constexpr (FAST) { if (sscg_conv_precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
+        case 6: if constexpr (FAST) { if (p.precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
+        case 7: if constexpr (FAST) { if (p.precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
         case 8: if constexpr (FAST) return launch_kc<MODE, 4, 1, 2, 1, VEC, FAST, 2, true, false, true>(p, st); else return SSCG_ERR_UNSUPPORTED;   // 256 x (<= 4): 4x4x1 MFMA
         default: return SSCG_ERR_BAD_ARG;
     }
@@ -666,14 +716,6 @@ int dispatch_mode(const KcParams& p, hipStream_t st) {
 }
 
 }  // namespace
-
-extern "C" int sscg_set_conv_precision(int mode) {
-    if (mode != 0 && mode != 1) return SSCG_ERR_BAD_ARG;
-    sscg_conv_precision = mode;
-    return SSCG_OK;
-}
-
-extern "C" int sscg_get_conv_precision(void) { return sscg_conv_precision; }
 
 extern "C" int sscg_debug_set_conv_cfg(int cfg) {
     if (cfg < 0) { sscg_force_conv_cfg = -1; sscg_force_conv_split = 0; return SSCG_OK; }
@@ -694,10 +736,13 @@ static bool dgrad_by_parity(const sscg_conv_desc* d) {
     return sscg_force_conv_cfg < 0 && d->stride == 2 && d->dil == 1 && d->pad_mode == 0 && d->K % BK == 0;
 }
 
+static bool dt_ok(int dt) { return dt == SSCG_F32 || dt == SSCG_BF16; }
+
 static int check_desc(const sscg_conv_desc* d) {
     if (!d) return SSCG_ERR_BAD_ARG;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0) return SSCG_ERR_BAD_ARG;
     if (d->stride <= 0 || d->dil <= 0 || d->pad < 0) return SSCG_ERR_BAD_ARG;
+    if (!dt_ok(d->x_dtype) || !dt_ok(d->w_dtype) || !dt_ok(d->y_dtype) || (d->precision != 0 && d->precision != 1)) return SSCG_ERR_BAD_ARG;
     int P = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
     int Q = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
     if (P != d->P || Q != d->Q) return SSCG_ERR_BAD_ARG;
@@ -711,32 +756,122 @@ static int check_desc(const sscg_conv_desc* d) {
 
 extern "C" size_t sscg_conv2d_fwd_workspace(const sscg_conv_desc* d) {
     if (!d) return 0;
+    if (sscg_conv16_fwd_applies(d)) return sscg_conv16_fwd_workspace(d, 0);
     return kc_split_bytes(plan_kc_split(d->N * d->P * d->Q, d->K, d->R * d->S * d->C, d->C), d->N * d->P * d->Q, d->K);
 }
 
 extern "C" size_t sscg_conv2d_dgrad_workspace(const sscg_conv_desc* d) {
     if (!d) return 0;
+    if (sscg_conv16_dgrad_applies(d)) return sscg_conv16_dgrad_workspace(d);
     if (dgrad_by_parity(d)) return 0;
     return kc_split_bytes(plan_kc_split(d->N * d->H * d->W, d->C, d->R * d->S * d->K, d->K), d->N * d->H * d->W, d->C);
 }
 
-extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const float* w, const float* bias,
-                               float* y, void* ws, size_t ws_bytes, void* stream) {
+// ---- fused normalisation statistics: layout of the `stats` buffer = [tiles_m * WM records][2][K][2] doubles, then the
+// records of the split-K rows [xrec][K][2]
+struct StatPlan { int tiles_m, bm, wm, valid_tiles, xrec, xgroup; long m_tail0; size_t main_bytes, bytes; };
+
+static bool fwd_stats_plan(const sscg_conv_desc* d, int G, long L, StatPlan* sp) {
+    const long M = (long)d->N * d->P * d->Q;
+    if (G <= 0 || L <= 0 || (long)G * L != M || d->act != SSCG_ACT_NONE || d->K <= 32) return false;
+    int splits;
+    if (sscg_conv16_fwd_applies(d)) {
+        int full_tiles, m_tail0, tiles_n;
+        if (!sscg_conv16_stats_geometry(d, L, &sp->bm, &sp->wm, &tiles_n, &splits, &full_tiles, &m_tail0)) return false;
+        sp->tiles_m = cdiv(M, sp->bm);
+        sp->valid_tiles = splits > 1 ? full_tiles / tiles_n : sp->tiles_m;
+        sp->m_tail0 = splits > 1 ? m_tail0 : M;
+    } else {
+        if (d->x_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return false;
+        const int Ktot = d->R * d->S * d->C;
+        const int cfg = kc_choose_cfg((int)M, d->K, Ktot, d->C);
+        if (cfg == 8) return false;
+        sp->bm = KC_BM[cfg];
+        sp->wm = (cfg == 4) ? 4 : 2;
+        if (L < sp->bm) return false;
+        KcSplit ks = plan_kc_split((int)M, d->K, Ktot, d->C, L);
+        sp->tiles_m = cdiv(M, sp->bm);
+        const int tiles_n = cdiv(d->K, KC_BN[cfg]);
+        splits = ks.splits;
+        sp->valid_tiles = splits > 1 ? ks.full_tiles / tiles_n : sp->tiles_m;
+        sp->m_tail0 = splits > 1 ? ks.m_tail0 : M;
+    }
+    sp->xrec = sp->m_tail0 < M ? sscg_colstats_records(M - sp->m_tail0, d->K, d->y_dtype) : 0;
+    sp->xgroup = sp->m_tail0 < M ? (int)(sp->m_tail0 / L) : -1;
+    sp->main_bytes = (size_t)sp->tiles_m * sp->wm * 2 * d->K * 2 * sizeof(double);
+    sp->bytes = sp->main_bytes + (size_t)sp->xrec * d->K * 2 * sizeof(double);
+    return true;
+}
+
+extern "C" size_t sscg_conv2d_fwd_stats_bytes(const sscg_conv_desc* d, int G, int64_t L) {
+    StatPlan sp;
+    if (!d || check_desc(d) != SSCG_OK || !fwd_stats_plan(d, G, (long)L, &sp)) return 0;
+    return sp.bytes;
+}
+
+extern "C" size_t sscg_conv2d_fwd_stats_workspace(const sscg_conv_desc* d) {
+    if (!d) return 0;
+    // the split plan of a statistics launch is a subset of the plain launch's
+    return sscg_conv2d_fwd_workspace(d);
+}
+
+static int conv_fwd_impl(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
+                         void* ws, size_t ws_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return SSCG_ERR_BAD_ARG;
-    KcParams p;
-    p.src = x; p.wgt = w; p.bias = bias; p.dst = y;
+    if (sscg_conv16_fwd_applies(d)) return sscg_conv16_fwd(d, x, w, bias, y, stats, stat_L, ws, ws_bytes, (hipStream_t)stream);
+    if (d->x_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return SSCG_ERR_UNSUPPORTED;
+    KcParams p = {};
+    p.src = reinterpret_cast<const float*>(x); p.wgt = reinterpret_cast<const float*>(w); p.bias = bias; p.dst = y;
+    p.out_bf16 = d->y_dtype == SSCG_BF16; p.precision = d->precision;
     p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Cs = d->C; p.Ktot = d->R * d->S * d->C;
     p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope; p.tiles_n = 0; p.tiles = 0;
+    p.stats = stats; p.stat_L = (int)stat_L;
     kc_dense_taps(p);
-    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs);
+    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs, stats ? stat_L : 0);
     if (sp.splits > 1 && (!ws || ws_bytes < kc_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
     return dispatch_mode<MODE_FWD>(p, (hipStream_t)stream);
+}
+
+extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias,
+                               void* y, void* ws, size_t ws_bytes, void* stream) {
+    return conv_fwd_impl(d, x, w, bias, y, nullptr, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int sscg_conv2d_fwd_stats(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int G,
+                                     int64_t L, void* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    StatPlan sp;
+    if (!fwd_stats_plan(d, G, (long)L, &sp)) return SSCG_ERR_UNSUPPORTED;
+    if (!stats || stats_bytes < sp.bytes) return SSCG_ERR_WORKSPACE;
+    rc = conv_fwd_impl(d, x, w, bias, y, reinterpret_cast<double*>(stats), (long)L, ws, ws_bytes, stream);
+    if (rc) return rc;
+    if (sp.xrec > 0) {   // rows that went through split-K: summed from the finished output (a few % of the tensor)
+        const size_t esz = d->y_dtype == SSCG_BF16 ? 2 : 4;
+        const long M = (long)d->N * d->P * d->Q;
+        rc = sscg_colstats_launch(reinterpret_cast<const char*>(y) + (size_t)sp.m_tail0 * d->K * esz, d->y_dtype, M - sp.m_tail0, d->K,
+                                  reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + sp.main_bytes), (hipStream_t)stream);
+    }
+    return rc;
+}
+
+extern "C" int sscg_norm_stats_from_conv(const sscg_conv_desc* d, const void* stats, int G, int64_t L, float eps, float* mean,
+                                         float* rstd, float* running_mean, float* running_var, float momentum, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    StatPlan sp;
+    if (!stats || !mean || !rstd || !fwd_stats_plan(d, G, (long)L, &sp)) return SSCG_ERR_BAD_ARG;
+    if ((running_mean != nullptr) != (running_var != nullptr)) return SSCG_ERR_BAD_ARG;
+    const double* main = reinterpret_cast<const double*>(stats);
+    const double* xr = reinterpret_cast<const double*>(reinterpret_cast<const char*>(stats) + sp.main_bytes);
+    return sscg_finalize_conv_stats(main, sp.valid_tiles, sp.bm, sp.wm, xr, sp.xrec, sp.xgroup, G, (long)L, d->K, eps, mean, rstd,
+                                    running_mean, running_var, momentum, (hipStream_t)stream);
 }
 
 // Data gradient (and ConvTranspose2d forward): dx[n][iy][ix][c] = sum_{ky,kx,k} dy[n][oy][ox][k] * wt[c][ky][kx][k]
@@ -744,14 +879,17 @@ extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const float* x, const fl
 // Zero padding only: reflection padding is used by the reference exclusively inside the frozen
 // generators (arch/generators.py:73,84,89 via model.py:225-228), which never see a backward pass;
 // the Python layer materialises the pad for any other caller.
-extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const float* wt, const float* bias,
-                                 float* dx, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias,
+                                 void* dx, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dy || !wt || !dx) return SSCG_ERR_BAD_ARG;
     if (d->pad_mode != 0) return SSCG_ERR_UNSUPPORTED;
-    KcParams p;
-    p.src = dy; p.wgt = wt; p.bias = bias; p.dst = dx;
+    if (sscg_conv16_dgrad_applies(d)) return sscg_conv16_dgrad(d, dy, wt, bias, dx, act, slope, ws, ws_bytes, (hipStream_t)stream);
+    if (d->y_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return SSCG_ERR_UNSUPPORTED;
+    KcParams p = {};
+    p.src = reinterpret_cast<const float*>(dy); p.wgt = reinterpret_cast<const float*>(wt); p.bias = bias; p.dst = dx;
+    p.out_bf16 = d->x_dtype == SSCG_BF16; p.precision = d->precision;
     p.M = d->N * d->H * d->W; p.Ng = d->C; p.Cs = d->K; p.Ktot = d->R * d->S * d->K;
     p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
@@ -794,26 +932,35 @@ extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const float* dy, const
 }
 
 // [K][RS][C] -> [C][RS][K] (weights are a few MB; one pass per optimiser step per conv that needs dgrad)
-__global__ void krsc_to_crsk_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int RS, int C) {
+template <typename S, typename D>
+__global__ void krsc_to_crsk_kernel(const S* __restrict__ w, D* __restrict__ wt, int K, int RS, int C) {
     __shared__ float t[32][33];
     const int rs = blockIdx.z;
     const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int r = ty; r < 32; r += 8) {
         int k = k0 + r, c = c0 + tx;
-        t[r][tx] = (k < K && c < C) ? w[((size_t)k * RS + rs) * C + c] : 0.f;
+        t[r][tx] = (k < K && c < C) ? ld1<S>(w + ((size_t)k * RS + rs) * C + c) : 0.f;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         int c = c0 + r, k = k0 + tx;
-        if (k < K && c < C) wt[((size_t)c * RS + rs) * K + k] = t[tx][r];
+        if (k < K && c < C) st1<D>(wt + ((size_t)c * RS + rs) * K + k, t[tx][r]);
     }
 }
 
-extern "C" int sscg_weight_krsc_to_crsk(const float* w, float* wt, int K, int RS, int C, void* stream) {
-    if (!w || !wt || K <= 0 || RS <= 0 || C <= 0) return SSCG_ERR_BAD_ARG;
+extern "C" int sscg_weight_krsc_to_crsk(const void* w, int w_dtype, void* wt, int wt_dtype, int K, int RS, int C, void* stream) {
+    if (!w || !wt || K <= 0 || RS <= 0 || C <= 0 || !dt_ok(w_dtype) || !dt_ok(wt_dtype)) return SSCG_ERR_BAD_ARG;
     dim3 grid(cdiv(C, 32), cdiv(K, 32), RS);
-    hipLaunchKernelGGL(krsc_to_crsk_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, K, RS, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (w_dtype == SSCG_F32 && wt_dtype == SSCG_F32)
+        hipLaunchKernelGGL((krsc_to_crsk_kernel<float, float>), grid, dim3(256), 0, st, (const float*)w, (float*)wt, K, RS, C);
+    else if (w_dtype == SSCG_F32)
+        hipLaunchKernelGGL((krsc_to_crsk_kernel<float, __bf16>), grid, dim3(256), 0, st, (const float*)w, (__bf16*)wt, K, RS, C);
+    else if (wt_dtype == SSCG_F32)
+        hipLaunchKernelGGL((krsc_to_crsk_kernel<__bf16, float>), grid, dim3(256), 0, st, (const __bf16*)w, (float*)wt, K, RS, C);
+    else
+        hipLaunchKernelGGL((krsc_to_crsk_kernel<__bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)w, (__bf16*)wt, K, RS, C);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

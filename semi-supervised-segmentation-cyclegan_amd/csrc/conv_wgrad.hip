@@ -15,15 +15,13 @@
 #include "common.h"
 #include "sscg_internal.h"
 
-extern int sscg_conv_precision;   // conv_igemm.hip
-
 namespace {
 
 constexpr int BKP = 32;  // pixels per k-step
 
 struct WgParams {
-    const float* __restrict__ x;
-    const float* __restrict__ dy;
+    const void* __restrict__ x;       // fp32 or bf16 (kernel template TX)
+    const void* __restrict__ dy;      // fp32 or bf16 (kernel template TY)
     float* __restrict__ out;  // dw (splits == 1) or workspace [splits][Kc][Ng]
     int Kc;                   // output channels (GEMM M)
     int Ng;                   // R*S*C (GEMM N)
@@ -43,9 +41,13 @@ struct WgParams {
 // 256 B of zeros: the source of masked LDS-DMA lanes (device code is not linked across translation units)
 __device__ float sscg_zero_page[64];
 
-template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false, bool BF16 = false>
+// TX / TY: element types of x / dy in HBM (the LDS image and the contraction are fp32 either way; bf16 operands are widened by
+// the register-staged loader - the mixed pairs are the layers at a network's fp32 boundary: stems read fp32 images, heads emit
+// fp32 logits, everything between is bf16 and runs on conv_bf16.hip)
+template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false, bool BF16 = false, typename TX = float, typename TY = float>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     static_assert(!DMA || (VA == 4 && VB == 4), "LDS-DMA staging needs 16-byte granules");
+    static_assert(!DMA || (sizeof(TX) == 4 && sizeof(TY) == 4), "LDS-DMA copies fp32 tiles");
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     // register staging pads the rows; LDS-DMA writes lane-linear, i.e. the unpadded [pixel][channel] image, which the
@@ -98,8 +100,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     float rb[PB][VB];
     unsigned okmask = 0;   // applied at LDS-store time: the staged registers stay untouched under the MFMAs
 
-    const float* dyc = p.dy + (a_col_ok ? ma : 0);      // this thread's dy column
-    const float* xc = p.x + cch;                        // this thread's x channel group
+    const TY* dyc = reinterpret_cast<const TY*>(p.dy) + (a_col_ok ? ma : 0);      // this thread's dy column
+    const TX* xc = reinterpret_cast<const TX*>(p.x) + cch;                        // this thread's x channel group
     const bool reflect = p.pad_mode == 1;
 
     int dma_buf = 0;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
             for (int ps = 0; ps < PA; ++ps) {
                 const int pix = pt + ra0 + ps * RA;
                 const bool ok = a_col_ok && pix < p_end;
-                const float* g = ok ? dyc + (size_t)pix * p.Kc : sscg_zero_page;
+                const void* g = ok ? (const void*)(dyc + (size_t)pix * p.Kc) : (const void*)sscg_zero_page;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(la + ps * RA * LDA), 16, 0, 0);
             }
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
                 sy = reflect ? ry : sy;
                 sx = reflect ? rx : sx;
                 ok = ok && ((unsigned)sy < (unsigned)p.H) && ((unsigned)sx < (unsigned)p.W);
-                const float* g = ok ? xc + (size_t)((img * p.H + sy) * p.W + sx) * p.C : sscg_zero_page;
+                const void* g = ok ? (const void*)(xc + (size_t)((img * p.H + sy) * p.W + sx) * p.C) : (const void*)sscg_zero_page;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(lb + ps * RB * LDB), 16, 0, 0);
             }
@@ -147,14 +149,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
             const int pix = pt + ra0 + ps * RA;
             const bool ok = a_col_ok && pix < p_end;
             okmask |= ok ? (1u << ps) : 0u;
-            const float* g = dyc + (size_t)(ok ? pix : 0) * p.Kc;
-            if constexpr (VA == 4) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ra[ps][e] = v[e];
-            } else {
-                ra[ps][0] = *g;
-            }
+            const TY* g = dyc + (size_t)(ok ? pix : 0) * p.Kc;
+            if constexpr (VA == 4) ld4<TY>(g, ra[ps]);
+            else ra[ps][0] = ld1<TY>(g);
         }
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
@@ -176,14 +173,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
             ok = ok && ((unsigned)sy < (unsigned)p.H) && ((unsigned)sx < (unsigned)p.W);
             okmask |= ok ? (1u << (16 + ps)) : 0u;
             const int spix = ok ? (img * p.H + sy) * p.W + sx : 0;
-            const float* g = xc + (size_t)spix * p.C;
-            if constexpr (VB == 4) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rb[ps][e] = v[e];
-            } else {
-                rb[ps][0] = *g;
-            }
+            const TX* g = xc + (size_t)spix * p.C;
+            if constexpr (VB == 4) ld4<TX>(g, rb[ps]);
+            else rb[ps][0] = ld1<TX>(g);
         }
     };
 
@@ -395,7 +387,7 @@ WgPlan plan_wgrad(const sscg_conv_desc* d) {
     return pl;
 }
 
-template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false, bool BF16 = false>
+template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false, bool BF16 = false, typename TX = float, typename TY = float>
 int launch_wg(WgParams p, int splits, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -404,7 +396,7 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
     p.tiles = tiles_m * p.tiles_n;
     p.splits = splits;
     size_t smem = (size_t)(2 * BKP * (DMA ? BM : BM + 4) + 2 * BKP * (DMA ? BN : BN + 4)) * sizeof(float);
-    auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VA, VB, DMA, BF16>;
+    auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VA, VB, DMA, BF16, TX, TY>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -415,18 +407,36 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
 }
 
 template <int VA, int VB>
-int dispatch_wg(const WgParams& p, const WgPlan& pl, hipStream_t st) {
+int dispatch_wg(const WgParams& p, const WgPlan& pl, int precision, hipStream_t st) {
     switch (pl.cfg) {
-        case 0: if (sscg_conv_precision == 1) return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4), true>(p, pl.splits, st);
+        case 0: if (precision == 1) return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4), true>(p, pl.splits, st);
                 return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);   // LDS-DMA staging when vectorisable
-        case 1: if (sscg_conv_precision == 1) return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4), true>(p, pl.splits, st);
+        case 1: if (precision == 1) return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4), true>(p, pl.splits, st);
                 return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);
-        case 2: if (sscg_conv_precision == 1) return launch_wg<1, 4, 1, 1, VA, VB, false, true>(p, pl.splits, st);
+        case 2: if (precision == 1) return launch_wg<1, 4, 1, 1, VA, VB, false, true>(p, pl.splits, st);
                 return launch_wg<1, 4, 1, 1, VA, VB>(p, pl.splits, st);
-        case 3: if (sscg_conv_precision == 1) return launch_wg<4, 1, 1, 1, VA, VB, false, true>(p, pl.splits, st);
+        case 3: if (precision == 1) return launch_wg<4, 1, 1, 1, VA, VB, false, true>(p, pl.splits, st);
                 return launch_wg<4, 1, 1, 1, VA, VB>(p, pl.splits, st);
         default: return SSCG_ERR_BAD_ARG;
     }
+}
+
+// mixed element types (one operand bf16): register-staged tiles, bf16 contraction (the bf16 operand is exact in it)
+template <int VA, int VB, typename TX, typename TY>
+int dispatch_wg_mixed(const WgParams& p, const WgPlan& pl, hipStream_t st) {
+    switch (pl.cfg) {   // only the few-channel tile classes occur with mixed types (stems: C < 32; heads: K <= 32)
+        case 2: return launch_wg<1, 4, 1, 1, VA, VB, false, true, TX, TY>(p, pl.splits, st);
+        case 3: return launch_wg<4, 1, 1, 1, VA, VB, false, true, TX, TY>(p, pl.splits, st);
+        default: return SSCG_ERR_UNSUPPORTED;
+    }
+}
+
+template <typename TX, typename TY>
+int dispatch_wg_types(const WgParams& p, const WgPlan& pl, bool va4, bool vb4, hipStream_t st) {
+    if (va4 && vb4) return dispatch_wg_mixed<4, 4, TX, TY>(p, pl, st);
+    if (va4) return dispatch_wg_mixed<4, 1, TX, TY>(p, pl, st);
+    if (vb4) return dispatch_wg_mixed<1, 4, TX, TY>(p, pl, st);
+    return dispatch_wg_mixed<1, 1, TX, TY>(p, pl, st);
 }
 
 }  // namespace
@@ -453,14 +463,16 @@ constexpr int THIN_MAX = 32;
 constexpr int THIN_BLOCKS = 1024;
 
 struct ThinParams {
-    const float* __restrict__ wide;   // [npix][Wd]
-    const float* __restrict__ thin;   // [npix][T]
+    const void* __restrict__ wide;    // [npix][Wd]  (TW)
+    const void* __restrict__ thin;    // [npix][T]   (TT)
     float* __restrict__ part;         // [blocks][T][Wd]
     int npix, Wd, T;
 };
 
-template <int T>
+template <int T, typename TW, typename TT>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(ThinParams p) {
+    const TW* wide = reinterpret_cast<const TW*>(p.wide);
+    const TT* thin = reinterpret_cast<const TT*>(p.thin);
     constexpr int TB = T < 4 ? T : 4;              // thin channels combined per LDS round (keeps the block at <= 16 KB)
     extern __shared__ float red[];                 // [lanes][TB][Wd]
     const int wq = p.Wd / 4;                       // threads across the wide channels
@@ -476,23 +488,25 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(ThinParams p) {
         const int stride = lanes * gridDim.x;
         int px = blockIdx.x * lanes + pl;
         for (; px + stride < p.npix; px += 2 * stride) {       // two pixels in flight per thread
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wide + (size_t)px * p.Wd + q * 4);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(p.wide + (size_t)(px + stride) * p.Wd + q * 4);
-            const float* th0 = p.thin + (size_t)px * T;
-            const float* th1 = p.thin + (size_t)(px + stride) * T;
+            float w0[4], w1[4];
+            ld4<TW>(wide + (size_t)px * p.Wd + q * 4, w0);
+            ld4<TW>(wide + (size_t)(px + stride) * p.Wd + q * 4, w1);
+            const TT* th0 = thin + (size_t)px * T;
+            const TT* th1 = thin + (size_t)(px + stride) * T;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const float v0 = th0[t], v1 = th1[t];
+                const float v0 = ld1<TT>(th0 + t), v1 = ld1<TT>(th1 + t);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(v1, w1[e], fmaf(v0, w0[e], acc[t][e]));
             }
         }
         if (px < p.npix) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wide + (size_t)px * p.Wd + q * 4);
-            const float* th0 = p.thin + (size_t)px * T;
+            float w0[4];
+            ld4<TW>(wide + (size_t)px * p.Wd + q * 4, w0);
+            const TT* th0 = thin + (size_t)px * T;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const float v0 = th0[t];
+                const float v0 = ld1<TT>(th0 + t);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(v0, w0[e], acc[t][e]);
             }
@@ -542,28 +556,47 @@ bool thin_wgrad_applies(const sscg_conv_desc* d) {
     return T <= THIN_MAX && Wd % 4 == 0 && Wd <= 256 && Wd >= 16 && (long)d->N * d->H * d->W >= 65536;
 }
 
-template <int T>
-void launch_thin(const ThinParams& p, int blocks, size_t smem, hipStream_t st) {
-    hipLaunchKernelGGL(thin_wgrad_kernel<T>, dim3(blocks), dim3(256), smem, st, p);
+template <int T, typename TW, typename TT>
+int launch_thin(const ThinParams& p, int blocks, size_t smem, hipStream_t st) {
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(thin_wgrad_kernel<T, TW, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((thin_wgrad_kernel<T, TW, TT>), dim3(blocks), dim3(256), smem, st, p);
+    return SSCG_OK;
 }
 
-int thin_wgrad(const sscg_conv_desc* d, const float* x, const float* dy, float* dw, float beta, void* ws, hipStream_t st) {
+template <typename TW, typename TT>
+int launch_thin_T(const ThinParams& p, size_t smem, hipStream_t st) {
+    switch (p.T) {
+        case 1: return launch_thin<1, TW, TT>(p, THIN_BLOCKS, smem, st);
+        case 2: return launch_thin<2, TW, TT>(p, THIN_BLOCKS, smem, st);
+        case 3: return launch_thin<3, TW, TT>(p, THIN_BLOCKS, smem, st);
+        case 4: return launch_thin<4, TW, TT>(p, THIN_BLOCKS, smem, st);
+        case 20: return launch_thin<20, TW, TT>(p, THIN_BLOCKS, smem, st);
+        case 21: return launch_thin<21, TW, TT>(p, THIN_BLOCKS, smem, st);
+        default: return SSCG_ERR_UNSUPPORTED;
+    }
+}
+
+int thin_wgrad(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, hipStream_t st) {
     const bool thin_is_k = d->K <= d->C;
     ThinParams p;
     p.T = thin_is_k ? d->K : d->C;
     p.Wd = thin_is_k ? d->C : d->K;
     p.wide = thin_is_k ? x : dy;
     p.thin = thin_is_k ? dy : x;
+    const int wide_dt = thin_is_k ? d->x_dtype : d->y_dtype, thin_dt = thin_is_k ? d->y_dtype : d->x_dtype;
     p.part = reinterpret_cast<float*>(ws);
     p.npix = d->N * d->H * d->W;
     const int lanes = 256 / (p.Wd / 4);
     const size_t smem = (size_t)lanes * (p.T < 4 ? p.T : 4) * p.Wd * sizeof(float);
-    switch (p.T) {
-#define SSCG_THIN_CASE(n) case n: { if (smem > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(thin_wgrad_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; } launch_thin<n>(p, THIN_BLOCKS, smem, st); break; }
-        SSCG_THIN_CASE(1) SSCG_THIN_CASE(2) SSCG_THIN_CASE(3) SSCG_THIN_CASE(4) SSCG_THIN_CASE(20) SSCG_THIN_CASE(21)
-#undef SSCG_THIN_CASE
-        default: return SSCG_ERR_UNSUPPORTED;
-    }
+    int rc;
+    if (wide_dt == SSCG_F32 && thin_dt == SSCG_F32) rc = launch_thin_T<float, float>(p, smem, st);
+    else if (wide_dt == SSCG_BF16 && thin_dt == SSCG_F32) rc = launch_thin_T<__bf16, float>(p, smem, st);   // the fp32 side is a network input / head output
+    else if (wide_dt == SSCG_BF16 && thin_dt == SSCG_BF16) rc = launch_thin_T<__bf16, __bf16>(p, smem, st);
+    else rc = SSCG_ERR_UNSUPPORTED;
+    if (rc) return rc;
     SSCG_LAUNCH_CHECK();
     hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3(cdiv(p.T * p.Wd, 4)), dim3(256), 0, st, p.part, dw, THIN_BLOCKS, p.T, p.Wd,
                        d->K, d->C, beta);
@@ -575,30 +608,43 @@ bool thin_wgrad_supported_T(int T) { return T == 1 || T == 2 || T == 3 || T == 4
 
 }  // namespace
 
+int sscg_wgrad_reduce(const float* ws, float* dw, size_t n, int splits, float beta, hipStream_t st) {
+    if (n % 4 == 0 && ((size_t)dw & 15) == 0 && ((size_t)ws & 15) == 0)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st, ws, dw, n, splits, beta);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(cdiv((long)n, 256)), dim3(256), 0, st, ws, dw, n, splits, beta);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+static bool wg_dt_ok(int dt) { return dt == SSCG_F32 || dt == SSCG_BF16; }
+
 extern "C" size_t sscg_conv2d_wgrad_workspace(const sscg_conv_desc* d) {
     if (!d) return 0;
     if (thin_wgrad_applies(d) && thin_wgrad_supported_T(d->K < d->C ? d->K : d->C))
         return (size_t)THIN_BLOCKS * d->K * d->C * sizeof(float);
+    if (sscg_wgrad16_applies(d)) return sscg_wgrad16_workspace(d);
     WgPlan pl = plan_wgrad(d);
     if (pl.splits <= 1) return 0;
     return (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float);
 }
 
 // dw = beta * dw + wgrad(x, dy);  dw is [K][R][S][C].  ws must hold sscg_conv2d_wgrad_workspace(d) bytes.
-extern "C" int sscg_conv2d_wgrad(const sscg_conv_desc* d, const float* x, const float* dy, float* dw, float beta,
+extern "C" int sscg_conv2d_wgrad(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta,
                                  void* ws, size_t ws_bytes, void* stream) {
     if (!d || !x || !dy || !dw) return SSCG_ERR_BAD_ARG;
-    if (d->N <= 0 || d->C <= 0 || d->K <= 0) return SSCG_ERR_BAD_ARG;
+    if (d->N <= 0 || d->C <= 0 || d->K <= 0 || !wg_dt_ok(d->x_dtype) || !wg_dt_ok(d->y_dtype)) return SSCG_ERR_BAD_ARG;
     if ((long)d->N * d->H * d->W * (long)d->C >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
     if ((long)d->N * d->P * d->Q * (long)d->K >= (1L << 31)) return SSCG_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
     if (thin_wgrad_applies(d) && thin_wgrad_supported_T(d->K < d->C ? d->K : d->C)) {
         if (!ws || ws_bytes < sscg_conv2d_wgrad_workspace(d)) return SSCG_ERR_WORKSPACE;
-        return thin_wgrad(d, x, dy, dw, beta, ws, (hipStream_t)stream);
+        return thin_wgrad(d, x, dy, dw, beta, ws, st);
     }
+    if (sscg_wgrad16_applies(d)) return sscg_wgrad16(d, x, dy, dw, beta, ws, ws_bytes, st);
     WgPlan pl = plan_wgrad(d);
     size_t need = pl.splits > 1 ? (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float) : 0;
     if (need > 0 && (!ws || ws_bytes < need)) return SSCG_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
     WgParams p;
     p.x = x; p.dy = dy;
     p.out = pl.splits > 1 ? reinterpret_cast<float*>(ws) : dw;
@@ -611,21 +657,19 @@ extern "C" int sscg_conv2d_wgrad(const sscg_conv_desc* d, const float* x, const 
     p.div_q = make_fastdiv(d->Q);
     const bool va4 = (d->K % 4 == 0), vb4 = (d->C % 4 == 0);
     int rc;
-    if (va4 && vb4) rc = dispatch_wg<4, 4>(p, pl, st);
-    else if (va4) rc = dispatch_wg<4, 1>(p, pl, st);
-    else if (vb4) rc = dispatch_wg<1, 4>(p, pl, st);
-    else rc = dispatch_wg<1, 1>(p, pl, st);
-    if (rc) return rc;
-    if (pl.splits > 1) {
-        size_t n = (size_t)d->K * p.Ng;
-        if (n % 4 == 0 && ((size_t)dw & 15) == 0 && ((size_t)ws & 15) == 0)
-            hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st,
-                               reinterpret_cast<const float*>(ws), dw, n, pl.splits, beta);
-        else
-            hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(cdiv((long)n, 256)), dim3(256), 0, st,
-                               reinterpret_cast<const float*>(ws), dw, n, pl.splits, beta);
-        SSCG_LAUNCH_CHECK();
+    if (d->x_dtype == SSCG_F32 && d->y_dtype == SSCG_F32) {
+        if (va4 && vb4) rc = dispatch_wg<4, 4>(p, pl, d->precision, st);
+        else if (va4) rc = dispatch_wg<4, 1>(p, pl, d->precision, st);
+        else if (vb4) rc = dispatch_wg<1, 4>(p, pl, d->precision, st);
+        else rc = dispatch_wg<1, 1>(p, pl, d->precision, st);
+    } else if (d->x_dtype == SSCG_F32) {
+        rc = dispatch_wg_types<float, __bf16>(p, pl, va4, vb4, st);
+    } else if (d->y_dtype == SSCG_F32) {
+        rc = dispatch_wg_types<__bf16, float>(p, pl, va4, vb4, st);
+    } else {
+        rc = SSCG_ERR_UNSUPPORTED;     // both bf16 with fewer than 32 channels on a side: no layer of the reference's nets
     }
+    if (rc) return rc;
+    if (pl.splits > 1) return sscg_wgrad_reduce(reinterpret_cast<const float*>(ws), dw, (size_t)d->K * p.Ng, pl.splits, beta, st);
     return SSCG_OK;
 }
-

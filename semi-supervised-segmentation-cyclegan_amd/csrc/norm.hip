@@ -16,9 +16,9 @@ namespace {
 enum { RM_SUM = 0, RM_STATS = 1, RM_BWD = 2 };
 
 struct RedParams {
-    const float* __restrict__ x;     // SUM/STATS: input; BWD: x (pre-norm)
-    const float* __restrict__ dy;    // BWD
-    const float* __restrict__ y;     // BWD: forward output (activation mask)
+    const void* __restrict__ x;      // SUM/STATS: input; BWD: x (pre-norm)           (fp32 or bf16: template T)
+    const void* __restrict__ dy;     // BWD
+    const void* __restrict__ y;      // BWD: forward output (activation mask)
     const float* __restrict__ mean;  // BWD [G][C]
     const float* __restrict__ rstd;  // BWD [G][C]
     double* __restrict__ part;       // [G][chunks][C][2]
@@ -37,13 +37,27 @@ __device__ __forceinline__ float act_grad(float dy, float y, int act, float slop
     return dy;
 }
 
+template <typename T, int VEC> __device__ __forceinline__ void ldv(const T* p, float v[VEC]) {
+    if constexpr (VEC == 8) ld8<T>(p, v);
+    else if constexpr (VEC == 4) ld4<T>(p, v);
+    else v[0] = ld1<T>(p);
+}
+template <typename T, int VEC> __device__ __forceinline__ void stv(T* p, const float v[VEC]) {
+    if constexpr (VEC == 8) st8<T>(p, v);
+    else if constexpr (VEC == 4) st4<T>(p, v);
+    else st1<T>(p, v[0]);
+}
+
 // block = 256 threads = RW row-lanes x CW column groups (CW power of two), VEC channels per group; a block owns the
 // channel slab blockIdx.z and the row chunk blockIdx.x of group blockIdx.y.  Rows are taken U at a time so that U
 // (3U for the backward sums) independent 16-byte loads are in flight per thread: these tensors are a few MB, the
 // kernel lives for a handful of memory latencies and nothing else hides them.
-template <int MODE, int VEC>
+template <int MODE, typename T, int VEC>
 __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
-    constexpr int U = 4;
+    constexpr int U = VEC == 8 ? 2 : 4;
+    const T* px = reinterpret_cast<const T*>(p.x);
+    const T* pdy = reinterpret_cast<const T*>(p.dy);
+    const T* py = reinterpret_cast<const T*>(p.y);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* sm = reinterpret_cast<double*>(smem_raw);  // [256][VEC][2]
     const int tid = threadIdx.x;
@@ -78,20 +92,14 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
                 const long r = r0 + (long)u * RW;
                 ok[u] = r < r_end;
                 const size_t o = base + (size_t)(ok[u] ? r : r_begin) * p.C;
-                if constexpr (VEC == 4) {
-                    f32x4 t = *reinterpret_cast<const f32x4*>(p.x + o);
+                ldv<T, VEC>(px + o, xv[u]);
+                if (MODE == RM_BWD) {
+                    ldv<T, VEC>(pdy + o, dv[u]);
+                    if (has_y) ldv<T, VEC>(py + o, yv[u]);
+                    else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) xv[u][e] = t[e];
-                    if (MODE == RM_BWD) {
-                        f32x4 a = *reinterpret_cast<const f32x4*>(p.dy + o);
-                        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                        if (has_y) b = *reinterpret_cast<const f32x4*>(p.y + o);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { dv[u][e] = a[e]; yv[u][e] = b[e]; }
+                        for (int e = 0; e < VEC; ++e) yv[u][e] = 0.f;
                     }
-                } else {
-                    xv[u][0] = p.x[o];
-                    if (MODE == RM_BWD) { dv[u][0] = p.dy[o]; yv[u][0] = has_y ? p.y[o] : 0.f; }
                 }
             }
 #pragma unroll
@@ -140,12 +148,14 @@ struct RedPlan {
     long rows_per_chunk;
 };
 
-RedPlan plan_reduce(int G, long L, int C) {
+int vec_for(int C, int dtype) { return (dtype == SSCG_BF16 && C % 8 == 0) ? 8 : ((C % 4 == 0) ? 4 : 1); }
+
+RedPlan plan_reduce(int G, long L, int C, int dtype = SSCG_F32) {
     RedPlan pl;
-    pl.vec = (C % 4 == 0) ? 4 : 1;
+    pl.vec = vec_for(C, dtype);
     const int groups = C / pl.vec;
     // 256-byte row segments per block: narrow slabs => many row lanes => few chunks => a short second stage
-    const int cw_max = pl.vec == 4 ? 16 : 64;
+    const int cw_max = pl.vec >= 4 ? 16 : 64;
     int cw = 1;
     while (cw < groups && cw < cw_max) cw <<= 1;
     pl.CW = cw;
@@ -162,22 +172,27 @@ RedPlan plan_reduce(int G, long L, int C) {
     return pl;
 }
 
+// the workspace bound covers both element types (the chunk count does not depend on the vector width)
 size_t part_bytes(int G, long L, int C) {
-    RedPlan pl = plan_reduce(G, L, C);
-    return (size_t)G * pl.chunks * C * 2 * sizeof(double);
+    const int a = plan_reduce(G, L, C, SSCG_F32).chunks, b = plan_reduce(G, L, C, SSCG_BF16).chunks;
+    return (size_t)G * (a > b ? a : b) * C * 2 * sizeof(double);
 }
 
 template <int MODE>
-int launch_reduce(RedParams p, int G, hipStream_t st) {
-    RedPlan pl = plan_reduce(G, p.L, p.C);
+int launch_reduce(RedParams p, int G, int dtype, hipStream_t st) {
+    RedPlan pl = plan_reduce(G, p.L, p.C, dtype);
     p.chunks = pl.chunks;
     p.rows_per_chunk = pl.rows_per_chunk;
     dim3 grid(pl.chunks, G, pl.slabs);
     size_t smem = (size_t)256 * pl.vec * 2 * sizeof(double);
-    if (pl.vec == 4)
-        hipLaunchKernelGGL((col_reduce_kernel<MODE, 4>), grid, dim3(256), smem, st, p, pl.CW);
-    else
-        hipLaunchKernelGGL((col_reduce_kernel<MODE, 1>), grid, dim3(256), smem, st, p, pl.CW);
+    if (dtype == SSCG_BF16) {
+        if (pl.vec == 8) hipLaunchKernelGGL((col_reduce_kernel<MODE, __bf16, 8>), grid, dim3(256), smem, st, p, pl.CW);
+        else if (pl.vec == 4) hipLaunchKernelGGL((col_reduce_kernel<MODE, __bf16, 4>), grid, dim3(256), smem, st, p, pl.CW);
+        else hipLaunchKernelGGL((col_reduce_kernel<MODE, __bf16, 1>), grid, dim3(256), smem, st, p, pl.CW);
+    } else {
+        if (pl.vec == 4) hipLaunchKernelGGL((col_reduce_kernel<MODE, float, 4>), grid, dim3(256), smem, st, p, pl.CW);
+        else hipLaunchKernelGGL((col_reduce_kernel<MODE, float, 1>), grid, dim3(256), smem, st, p, pl.CW);
+    }
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -264,13 +279,13 @@ __global__ __launch_bounds__(256) void finalize_bwd_kernel(const double* __restr
 }
 
 struct ApplyParams {
-    const float* __restrict__ x;
+    const void* __restrict__ x;
     const float* __restrict__ mean;
     const float* __restrict__ rstd;
     const float* __restrict__ gamma;
     const float* __restrict__ beta;
-    const float* __restrict__ res;
-    float* __restrict__ y;
+    const void* __restrict__ res;
+    void* __restrict__ y;
     long L;
     int C;
     int act;
@@ -280,48 +295,29 @@ struct ApplyParams {
     FastDiv div_l;   // by L
 };
 
-template <int VEC>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void norm_apply_kernel(ApplyParams p) {
     const int CG = p.C / VEC;
+    const T* px = reinterpret_cast<const T*>(p.x);
+    const T* pr = reinterpret_cast<const T*>(p.res);
+    T* py = reinterpret_cast<T*>(p.y);
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.total; i += gridDim.x * 256) {
         const int row = fd_div((int)i, p.div_cg);
         const int c = ((int)i - row * CG) * VEC;
         const int g = fd_div(row, p.div_l);
         const size_t o = (size_t)i * VEC;
         float xv[VEC], rv[VEC];
-        if constexpr (VEC == 4) {
-            f32x4 t = *reinterpret_cast<const f32x4*>(p.x + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xv[e] = t[e];
-            if (p.res) {
-                f32x4 u = *reinterpret_cast<const f32x4*>(p.res + o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rv[e] = u[e];
-            }
-        } else {
-            xv[0] = p.x[o];
-            if (p.res) rv[0] = p.res[o];
-        }
+        ldv<T, VEC>(px + o, xv);
+        if (p.res) ldv<T, VEC>(pr + o, rv);
         float out[VEC];
         // per-channel parameters as 16-byte loads (the kernel is VMEM-issue bound with one scalar load per parameter)
         float mu[VEC], rs[VEC], ga[VEC], be[VEC];
-        {
-            const size_t s = (size_t)g * p.C + c;
-            if constexpr (VEC == 4) {
-                f32x4 a = *reinterpret_cast<const f32x4*>(p.mean + s);
-                f32x4 b = *reinterpret_cast<const f32x4*>(p.rstd + s);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { mu[e] = a[e]; rs[e] = b[e]; ga[e] = 1.f; be[e] = 0.f; }
-                if (p.gamma) {
-                    f32x4 gg = *reinterpret_cast<const f32x4*>(p.gamma + c);
-                    f32x4 bb = *reinterpret_cast<const f32x4*>(p.beta + c);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ga[e] = gg[e]; be[e] = bb[e]; }
-                }
-            } else {
-                mu[0] = p.mean[s]; rs[0] = p.rstd[s];
-                ga[0] = p.gamma ? p.gamma[c] : 1.f; be[0] = p.gamma ? p.beta[c] : 0.f;
-            }
+        const size_t s = (size_t)g * p.C + c;
+        ldv<float, VEC>(p.mean + s, mu);
+        ldv<float, VEC>(p.rstd + s, rs);
+        if (p.gamma) {
+            ldv<float, VEC>(p.gamma + c, ga);
+            ldv<float, VEC>(p.beta + c, be);
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -330,25 +326,20 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(ApplyParams p) {
             if (p.res) v += rv[e];
             out[e] = sscg_act(v, p.act, p.slope);
         }
-        if constexpr (VEC == 4) {
-            f32x4 t = {out[0], out[1], out[2], out[3]};
-            *reinterpret_cast<f32x4*>(p.y + o) = t;
-        } else {
-            p.y[o] = out[0];
-        }
+        stv<T, VEC>(py + o, out);
     }
 }
 
 struct BwdApplyParams {
-    const float* __restrict__ dy;
-    const float* __restrict__ x;
-    const float* __restrict__ y;
+    const void* __restrict__ dy;
+    const void* __restrict__ x;
+    const void* __restrict__ y;
     const float* __restrict__ mean;
     const float* __restrict__ rstd;
     const float* __restrict__ gamma;
     const float* __restrict__ coef;  // [G][C][2] or null when stats are constants
-    float* __restrict__ dx;
-    float* __restrict__ dres;
+    void* __restrict__ dx;
+    void* __restrict__ dres;
     long L;
     int C;
     int act;
@@ -358,54 +349,40 @@ struct BwdApplyParams {
     FastDiv div_l;
 };
 
-template <int VEC>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdApplyParams p) {
     const int CG = p.C / VEC;
+    const T* pdy = reinterpret_cast<const T*>(p.dy);
+    const T* px = reinterpret_cast<const T*>(p.x);
+    const T* py = reinterpret_cast<const T*>(p.y);
+    T* pdx = reinterpret_cast<T*>(p.dx);
+    T* pdres = reinterpret_cast<T*>(p.dres);
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.total; i += gridDim.x * 256) {
         const int row = fd_div((int)i, p.div_cg);
         const int c = ((int)i - row * CG) * VEC;
         const int g = fd_div(row, p.div_l);
         const size_t o = (size_t)i * VEC;
         float dv[VEC], xv[VEC], yv[VEC];
-        if constexpr (VEC == 4) {
-            f32x4 a = *reinterpret_cast<const f32x4*>(p.dy + o);
-            f32x4 b = *reinterpret_cast<const f32x4*>(p.x + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { dv[e] = a[e]; xv[e] = b[e]; }
-            if (p.act != SSCG_ACT_NONE) {
-                f32x4 u = *reinterpret_cast<const f32x4*>(p.y + o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) yv[e] = u[e];
-            }
-        } else {
-            dv[0] = p.dy[o]; xv[0] = p.x[o];
-            if (p.act != SSCG_ACT_NONE) yv[0] = p.y[o];
-        }
+        ldv<T, VEC>(pdy + o, dv);
+        ldv<T, VEC>(px + o, xv);
+        if (p.act != SSCG_ACT_NONE) ldv<T, VEC>(py + o, yv);
         float gx[VEC], gr[VEC];
         float mu[VEC], rsv[VEC], ga[VEC], c1[VEC], c2[VEC];
-        {
-            const size_t s = (size_t)g * p.C + c;
-            if constexpr (VEC == 4) {
-                f32x4 b = *reinterpret_cast<const f32x4*>(p.rstd + s);
+        const size_t s = (size_t)g * p.C + c;
+        ldv<float, VEC>(p.rstd + s, rsv);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { rsv[e] = b[e]; ga[e] = 1.f; mu[e] = 0.f; c1[e] = 0.f; c2[e] = 0.f; }
-                if (p.gamma) {
-                    f32x4 gg = *reinterpret_cast<const f32x4*>(p.gamma + c);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ga[e] = gg[e];
-                }
-                if (p.coef) {
-                    f32x4 a = *reinterpret_cast<const f32x4*>(p.mean + s);
-                    f32x4 k0 = *reinterpret_cast<const f32x4*>(p.coef + s * 2);       // (c1,c2) pairs of channels c, c+1
-                    f32x4 k1 = *reinterpret_cast<const f32x4*>(p.coef + s * 2 + 4);   // ... of channels c+2, c+3
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) mu[e] = a[e];
-                    c1[0] = k0[0]; c2[0] = k0[1]; c1[1] = k0[2]; c2[1] = k0[3];
-                    c1[2] = k1[0]; c2[2] = k1[1]; c1[3] = k1[2]; c2[3] = k1[3];
-                }
+        for (int e = 0; e < VEC; ++e) { ga[e] = 1.f; mu[e] = 0.f; c1[e] = 0.f; c2[e] = 0.f; }
+        if (p.gamma) ldv<float, VEC>(p.gamma + c, ga);
+        if (p.coef) {
+            ldv<float, VEC>(p.mean + s, mu);
+            if constexpr (VEC == 1) {
+                c1[0] = p.coef[s * 2]; c2[0] = p.coef[s * 2 + 1];
             } else {
-                rsv[0] = p.rstd[s]; ga[0] = p.gamma ? p.gamma[c] : 1.f;
-                mu[0] = p.coef ? p.mean[s] : 0.f; c1[0] = p.coef ? p.coef[s * 2] : 0.f; c2[0] = p.coef ? p.coef[s * 2 + 1] : 0.f;
+                float kk[2 * VEC];          // (c1, c2) pairs of channels c .. c+VEC-1
+#pragma unroll
+                for (int q = 0; q < 2 * VEC; q += 4) ld4<float>(p.coef + s * 2 + q, kk + q);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { c1[e] = kk[2 * e]; c2[e] = kk[2 * e + 1]; }
             }
         }
 #pragma unroll
@@ -419,17 +396,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdApplyParams p) {
             }
             gx[e] = v * rsv[e] * ga[e];
         }
-        if constexpr (VEC == 4) {
-            f32x4 t = {gx[0], gx[1], gx[2], gx[3]};
-            *reinterpret_cast<f32x4*>(p.dx + o) = t;
-            if (p.dres) {
-                f32x4 u = {gr[0], gr[1], gr[2], gr[3]};
-                *reinterpret_cast<f32x4*>(p.dres + o) = u;
-            }
-        } else {
-            p.dx[o] = gx[0];
-            if (p.dres) p.dres[o] = gr[0];
-        }
+        stv<T, VEC>(pdx + o, gx);
+        if (p.dres) stv<T, VEC>(pdres + o, gr);
     }
 }
 
@@ -445,20 +413,98 @@ inline int ew_grid(size_t total) {
     return (int)b;
 }
 
+
+// ---- second stage of the statistics a convolution epilogue left behind (conv_igemm.hip / conv_bf16.hip):
+// records [rec][2 slots][C][2] doubles, rec = tile_m * RPT + wave_row; slot 0 = rows of the tile's first group
+// (group of row tile_m * BMT), slot 1 = rows of the next group; plus `xrec` records [xrec][C][2] of the rows that went
+// through split-K (all in group `xgroup`).  A block owns 64 channels; its 8 waves stride the records and are combined
+// through LDS in a fixed order (deterministic).
+struct ConvStatParams {
+    const double* __restrict__ rec;
+    const double* __restrict__ xrecs;
+    float* __restrict__ mean;
+    float* __restrict__ rstd;
+    float* __restrict__ rmean;
+    float* __restrict__ rvar;
+    int valid_tiles;     // tile rows [0, valid_tiles) wrote records
+    int BMT, RPT;        // rows per tile, records per tile
+    int xrec, xgroup;
+    int G, C;
+    long L;
+    float eps, momentum;
+};
+
+__global__ __launch_bounds__(512) void finalize_conv_stats_kernel(ConvStatParams p) {
+    __shared__ double sm[8][64][2];
+    const int cl = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool cok = c < p.C;
+    const int g0 = p.rmean ? 0 : blockIdx.y;
+    const int g1 = p.rmean ? p.G : blockIdx.y + 1;
+    for (int g = g0; g < g1; ++g) {
+        const long lo = (long)g * p.L, hi = lo + p.L;
+        int t_first = (int)((lo + p.BMT - 1) / p.BMT);
+        int t_last = (int)((hi + p.BMT - 1) / p.BMT) - 1;
+        if (t_last > p.valid_tiles - 1) t_last = p.valid_tiles - 1;
+        double s = 0.0, q = 0.0;
+        if (cok) {
+            const int n0 = (t_last - t_first + 1) * p.RPT;          // slot-0 records of the tiles that start inside the group
+            for (int k = w; k < n0; k += 8) {
+                const size_t r = (size_t)t_first * p.RPT + k;
+                const double* e = p.rec + ((r * 2 + 0) * p.C + c) * 2;
+                s += e[0]; q += e[1];
+            }
+            if (g > 0 && t_first - 1 < p.valid_tiles && t_first >= 1) {  // slot 1 of the tile that straddles the lower boundary
+                for (int k = w; k < p.RPT; k += 8) {
+                    const size_t r = (size_t)(t_first - 1) * p.RPT + k;
+                    const double* e = p.rec + ((r * 2 + 1) * p.C + c) * 2;
+                    s += e[0]; q += e[1];
+                }
+            }
+            if (p.xrec > 0 && p.xgroup == g) {
+                for (int k = w; k < p.xrec; k += 8) {
+                    const double* e = p.xrecs + ((size_t)k * p.C + c) * 2;
+                    s += e[0]; q += e[1];
+                }
+            }
+        }
+        sm[w][cl][0] = s; sm[w][cl][1] = q;
+        __syncthreads();
+        if (w == 0 && cok) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a += sm[k][cl][0]; b += sm[k][cl][1]; }
+            const int i = g * p.C + c;
+            const double m = a / (double)p.L;
+            double var = b / (double)p.L - m * m;
+            if (var < 0.0) var = 0.0;
+            p.mean[i] = (float)m;
+            p.rstd[i] = (float)(1.0 / sqrt(var + (double)p.eps));
+            if (p.rmean) {
+                const double unb = p.L > 1 ? var * (double)p.L / (double)(p.L - 1) : var;
+                p.rmean[c] = (float)((1.0 - (double)p.momentum) * (double)p.rmean[c] + (double)p.momentum * m);
+                p.rvar[c] = (float)((1.0 - (double)p.momentum) * (double)p.rvar[c] + (double)p.momentum * unb);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" size_t sscg_colsum_workspace(int64_t rows, int cols) { return part_bytes(1, rows, cols); }
 
-extern "C" int sscg_colsum(const float* x, float* out, int64_t rows, int cols, float beta, void* ws, size_t ws_bytes,
+extern "C" int sscg_colsum(const void* x, int dtype, float* out, int64_t rows, int cols, float beta, void* ws, size_t ws_bytes,
                            void* stream) {
-    if (!x || !out || rows <= 0 || cols <= 0) return SSCG_ERR_BAD_ARG;
+    if (!x || !out || rows <= 0 || cols <= 0 || (dtype != SSCG_F32 && dtype != SSCG_BF16)) return SSCG_ERR_BAD_ARG;
     if (!ws || ws_bytes < part_bytes(1, rows, cols)) return SSCG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     RedParams p = {};
     p.x = x; p.part = reinterpret_cast<double*>(ws); p.L = rows; p.C = cols;
-    int rc = launch_reduce<RM_SUM>(p, 1, st);
+    int rc = launch_reduce<RM_SUM>(p, 1, dtype, st);
     if (rc) return rc;
-    RedPlan pl = plan_reduce(1, rows, cols);
+    RedPlan pl = plan_reduce(1, rows, cols, dtype);
     hipLaunchKernelGGL(finalize_sum_kernel, dim3(cdiv(cols, FIN_CH)), dim3(256), 0, st, p.part, out, cols, pl.chunks, beta);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
@@ -466,42 +512,68 @@ extern "C" int sscg_colsum(const float* x, float* out, int64_t rows, int cols, f
 
 extern "C" size_t sscg_norm_stats_workspace(int G, int64_t L, int C) { return part_bytes(G, L, C); }
 
-extern "C" int sscg_norm_stats(const float* x, int G, int64_t L, int C, float eps, float* mean, float* rstd,
+extern "C" int sscg_norm_stats(const void* x, int dtype, int G, int64_t L, int C, float eps, float* mean, float* rstd,
                                float* running_mean, float* running_var, float momentum, void* ws, size_t ws_bytes,
                                void* stream) {
-    if (!x || !mean || !rstd || G <= 0 || L <= 0 || C <= 0) return SSCG_ERR_BAD_ARG;
+    if (!x || !mean || !rstd || G <= 0 || L <= 0 || C <= 0 || (dtype != SSCG_F32 && dtype != SSCG_BF16)) return SSCG_ERR_BAD_ARG;
     if ((running_mean != nullptr) != (running_var != nullptr)) return SSCG_ERR_BAD_ARG;
     if (!ws || ws_bytes < part_bytes(G, L, C)) return SSCG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     RedParams p = {};
     p.x = x; p.part = reinterpret_cast<double*>(ws); p.L = L; p.C = C;
-    int rc = launch_reduce<RM_STATS>(p, G, st);
+    int rc = launch_reduce<RM_STATS>(p, G, dtype, st);
     if (rc) return rc;
-    RedPlan pl = plan_reduce(G, L, C);
+    RedPlan pl = plan_reduce(G, L, C, dtype);
     hipLaunchKernelGGL(finalize_stats_kernel, dim3(cdiv(C, FIN_CH), running_mean ? 1 : G), dim3(256), 0, st, p.part, mean, rstd,
                        running_mean, running_var, G, C, pl.chunks, (long)L, eps, momentum);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
 
-extern "C" int sscg_norm_apply(const float* x, const float* mean, const float* rstd, const float* gamma,
-                               const float* beta, const float* residual, float* y, int G, int64_t L, int C, int act,
+// Column (sum, sum of squares) partials of `rows` rows in the record layout finalize_conv_stats_kernel's `xrecs` expects.
+int sscg_colstats_records(long rows, int C, int dtype) { return plan_reduce(1, rows, C, dtype).chunks; }
+
+int sscg_colstats_launch(const void* x, int dtype, long rows, int C, double* part, hipStream_t st) {
+    RedParams p = {};
+    p.x = x; p.part = part; p.L = rows; p.C = C;
+    return launch_reduce<RM_STATS>(p, 1, dtype, st);
+}
+
+int sscg_finalize_conv_stats(const double* stats, int valid_tiles, int rows_per_tile, int records_per_tile, const double* xrecs,
+                             int xrec, int xgroup, int G, long L, int C, float eps, float* mean, float* rstd, float* running_mean,
+                             float* running_var, float momentum, hipStream_t st) {
+    ConvStatParams p = {};
+    p.rec = stats; p.xrecs = xrecs; p.mean = mean; p.rstd = rstd; p.rmean = running_mean; p.rvar = running_var;
+    p.valid_tiles = valid_tiles; p.BMT = rows_per_tile; p.RPT = records_per_tile; p.xrec = xrec; p.xgroup = xgroup;
+    p.G = G; p.C = C; p.L = L; p.eps = eps; p.momentum = momentum;
+    hipLaunchKernelGGL(finalize_conv_stats_kernel, dim3(cdiv(C, 64), running_mean ? 1 : G), dim3(512), 0, st, p);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+template <typename T>
+static void launch_apply(const ApplyParams& p, int vec, hipStream_t st) {
+    if (vec == 8) hipLaunchKernelGGL((norm_apply_kernel<T, 8>), dim3(ew_grid(p.total)), dim3(256), 0, st, p);
+    else if (vec == 4) hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(ew_grid(p.total)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((norm_apply_kernel<T, 1>), dim3(ew_grid(p.total)), dim3(256), 0, st, p);
+}
+
+extern "C" int sscg_norm_apply(const void* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const void* residual, void* y, int dtype, int G, int64_t L, int C, int act,
                                float slope, void* stream) {
-    if (!x || !mean || !rstd || !y || G <= 0 || L <= 0 || C <= 0) return SSCG_ERR_BAD_ARG;
+    if (!x || !mean || !rstd || !y || G <= 0 || L <= 0 || C <= 0 || (dtype != SSCG_F32 && dtype != SSCG_BF16)) return SSCG_ERR_BAD_ARG;
     if ((gamma != nullptr) != (beta != nullptr)) return SSCG_ERR_BAD_ARG;
     ApplyParams p = {};
     p.x = x; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.res = residual; p.y = y;
     p.L = L; p.C = C; p.act = act; p.slope = slope;
-    const int vec = (C % 4 == 0) ? 4 : 1;
+    const int vec = vec_for(C, dtype);
     if ((size_t)G * L * C / vec >= ((size_t)1 << 31)) return SSCG_ERR_UNSUPPORTED;
     p.total = (uint32_t)((size_t)G * L * C / vec);
     p.div_cg = make_fastdiv(C / vec);
     p.div_l = make_fastdiv((int)L);
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4)
-        hipLaunchKernelGGL(norm_apply_kernel<4>, dim3(ew_grid(p.total)), dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL(norm_apply_kernel<1>, dim3(ew_grid(p.total)), dim3(256), 0, st, p);
+    if (dtype == SSCG_BF16) launch_apply<__bf16>(p, vec, st);
+    else launch_apply<float>(p, vec, st);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -517,10 +589,17 @@ extern "C" size_t sscg_norm_bwd_workspace(int G, int64_t L, int C) {
     return part_bytes(G, L, C) + (size_t)G * C * 2 * sizeof(float);
 }
 
-extern "C" int sscg_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd,
-                             const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int G, int64_t L,
+template <typename T>
+static void launch_bwd_apply(const BwdApplyParams& q, int vec, hipStream_t st) {
+    if (vec == 8) hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 8>), dim3(ew_grid(q.total)), dim3(256), 0, st, q);
+    else if (vec == 4) hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), dim3(ew_grid(q.total)), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(ew_grid(q.total)), dim3(256), 0, st, q);
+}
+
+extern "C" int sscg_norm_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
+                             const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int dtype, int G, int64_t L,
                              int C, int act, float slope, int stats_grad, void* ws, size_t ws_bytes, void* stream) {
-    if (!dy || !x || !mean || !rstd || !dx || G <= 0 || L <= 0 || C <= 0) return SSCG_ERR_BAD_ARG;
+    if (!dy || !x || !mean || !rstd || !dx || G <= 0 || L <= 0 || C <= 0 || (dtype != SSCG_F32 && dtype != SSCG_BF16)) return SSCG_ERR_BAD_ARG;
     if (act != SSCG_ACT_NONE && !y) return SSCG_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool need_red = stats_grad || dgamma || dbeta;
@@ -530,9 +609,9 @@ extern "C" int sscg_norm_bwd(const float* dy, const float* x, const float* y, co
         RedParams p = {};
         p.x = x; p.dy = dy; p.y = y; p.mean = mean; p.rstd = rstd;
         p.part = reinterpret_cast<double*>(ws); p.L = L; p.C = C; p.act = act; p.slope = slope;
-        int rc = launch_reduce<RM_BWD>(p, G, st);
+        int rc = launch_reduce<RM_BWD>(p, G, dtype, st);
         if (rc) return rc;
-        RedPlan pl = plan_reduce(G, L, C);
+        RedPlan pl = plan_reduce(G, L, C, dtype);
         coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + part_bytes(G, L, C));
         hipLaunchKernelGGL(finalize_bwd_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, st, p.part, coef, dgamma, dbeta, G, C,
                            pl.chunks, (long)L);
@@ -542,15 +621,13 @@ extern "C" int sscg_norm_bwd(const float* dy, const float* x, const float* y, co
     q.dy = dy; q.x = x; q.y = y; q.mean = mean; q.rstd = rstd; q.gamma = gamma;
     q.coef = stats_grad ? coef : nullptr;
     q.dx = dx; q.dres = dres; q.L = L; q.C = C; q.act = act; q.slope = slope;
-    const int vec = (C % 4 == 0) ? 4 : 1;
+    const int vec = vec_for(C, dtype);
     if ((size_t)G * L * C / vec >= ((size_t)1 << 31)) return SSCG_ERR_UNSUPPORTED;
     q.total = (uint32_t)((size_t)G * L * C / vec);
     q.div_cg = make_fastdiv(C / vec);
     q.div_l = make_fastdiv((int)L);
-    if (vec == 4)
-        hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, dim3(ew_grid(q.total)), dim3(256), 0, st, q);
-    else
-        hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(ew_grid(q.total)), dim3(256), 0, st, q);
+    if (dtype == SSCG_BF16) launch_bwd_apply<__bf16>(q, vec, st);
+    else launch_bwd_apply<float>(q, vec, st);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

@@ -12,41 +12,65 @@ inline int ew_blocks(size_t n) {
     return (int)b;
 }
 
-__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act, float slope) {
+template <typename T>
+__global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, int act, float slope) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        y[i] = sscg_act(x[i], act, slope);
+        st1<T>(y + i, sscg_act(ld1<T>(x + i), act, slope));
 }
 
-__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, size_t n,
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, size_t n,
                                int act, float slope) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float g = dy[i], v = y[i];
+        float g = ld1<T>(dy + i), v = ld1<T>(y + i);
         if (act == SSCG_ACT_RELU) g = v > 0.f ? g : 0.f;
         else if (act == SSCG_ACT_LRELU) g = v > 0.f ? g : g * slope;
         else if (act == SSCG_ACT_TANH) g = g * (1.f - v * v);
-        dx[i] = g;
+        st1<T>(dx + i, g);
     }
 }
 
-__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = a[i] + b[i];
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        st1<T>(y + i, ld1<T>(a + i) + ld1<T>(b + i));
 }
 
-// 16 bytes per lane, two independent vectors in flight per thread
-__global__ __launch_bounds__(256) void add4_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ y,
-                                                    size_t n4) {
+// 16 bytes per lane (4 fp32 / 8 bf16), two independent vectors in flight per thread
+template <typename T, int V>
+__global__ __launch_bounds__(256) void addv_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, size_t nv) {
     const size_t stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + stride < n4; i += 2 * stride) {
-        const f32x4 a0 = a[i], b0 = b[i], a1 = a[i + stride], b1 = b[i + stride];
-        y[i] = a0 + b0;
-        y[i + stride] = a1 + b1;
+    auto one = [&](size_t k, float o[V]) {
+        float u[V], w[V];
+        if constexpr (V == 8) { ld8<T>(a + k * V, u); ld8<T>(b + k * V, w); } else { ld4<T>(a + k * V, u); ld4<T>(b + k * V, w); }
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = u[e] + w[e];
+    };
+    auto put = [&](size_t k, const float o[V]) {
+        if constexpr (V == 8) st8<T>(y + k * V, o); else st4<T>(y + k * V, o);
+    };
+    for (; i + stride < nv; i += 2 * stride) {
+        float o0[V], o1[V];
+        one(i, o0);
+        one(i + stride, o1);
+        put(i, o0);
+        put(i + stride, o1);
     }
-    if (i < n4) y[i] = a[i] + b[i];
+    if (i < nv) {
+        float o0[V];
+        one(i, o0);
+        put(i, o0);
+    }
 }
 
 __global__ void fill_kernel(float* __restrict__ x, size_t n, float v) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = v;
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) st1<D>(dst + i, ld1<S>(src + i));
 }
 
 __device__ __forceinline__ uint32_t mix64to32(uint64_t z) {
@@ -57,12 +81,13 @@ __device__ __forceinline__ uint32_t mix64to32(uint64_t z) {
     return (uint32_t)(z >> 32);
 }
 
-__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float p, float scale,
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, float p, float scale,
                                uint64_t seed) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         uint32_t r = mix64to32(seed * 0x2545f4914f6cdd1dull + (uint64_t)i);
         float u = (float)(r >> 8) * (1.0f / 16777216.0f);
-        y[i] = u >= p ? x[i] * scale : 0.f;
+        st1<T>(y + i, u >= p ? ld1<T>(x + i) * scale : 0.f);
     }
 }
 
@@ -80,7 +105,8 @@ __global__ void gauss_noise_kernel(const float* __restrict__ x, float* __restric
 }
 
 // one thread per (n, oy, ox, c)
-__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int N,
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int N,
                                    int H, int W, int C, int P, int Q) {
     size_t total = (size_t)N * P * Q * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -100,16 +126,17 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
             for (int kx = 0; kx < 3; ++kx) {
                 int ix = ox * 2 - 1 + kx;
                 if ((unsigned)ix >= (unsigned)W) continue;
-                float v = x[((size_t)(n * H + iy) * W + ix) * C + c];
+                float v = ld1<T>(x + ((size_t)(n * H + iy) * W + ix) * C + c);
                 if (first || v > best) { best = v; bi = ky * 3 + kx; first = false; }
             }
         }
-        y[i] = best;
+        st1<T>(y + i, best);
         idx[i] = (uint8_t)bi;
     }
 }
 
-__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
                                    int N, int H, int W, int C, int P, int Q) {
     size_t total = (size_t)N * H * W * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -128,10 +155,10 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
                 if (ox >= Q) continue;
                 int kx = ix - (ox * 2 - 1);
                 size_t o = ((size_t)(n * P + oy) * Q + ox) * C + c;
-                if (idx[o] == ky * 3 + kx) s += dy[o];
+                if (idx[o] == ky * 3 + kx) s += ld1<T>(dy + o);
             }
         }
-        dx[i] = s;
+        st1<T>(dx + i, s);
     }
 }
 
@@ -197,7 +224,8 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restr
     }
 }
 
-__global__ void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int pad) {
+template <typename T>
+__global__ void reflect_pad_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int pad) {
     int OH = H + 2 * pad, OW = W + 2 * pad;
     size_t total = (size_t)N * OH * OW * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -215,7 +243,8 @@ __global__ void reflect_pad_kernel(const float* __restrict__ x, float* __restric
 }
 
 // adjoint of reflect_pad in gather form: every source pixel sums the (up to 3 x 3) padded positions that mirror onto it
-__global__ void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C, int pad) {
+template <typename T>
+__global__ void reflect_pad_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int pad) {
     int OH = H + 2 * pad, OW = W + 2 * pad;
     size_t total = (size_t)N * H * W * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -233,8 +262,8 @@ __global__ void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __re
         if (ix <= W - 2 && ix >= W - 1 - pad) xs[nx++] = 2 * (W - 1) - ix + pad;
         float s = 0.f;
         for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) s += dy[((size_t)(n * OH + ys[a]) * OW + xs[b]) * C + c];
-        dx[i] = s;
+            for (int b = 0; b < nx; ++b) s += ld1<T>(dy + ((size_t)(n * OH + ys[a]) * OW + xs[b]) * C + c);
+        st1<T>(dx + i, s);
     }
 }
 
@@ -260,29 +289,61 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 
 extern "C" int sscg_abi_version(void) { return SSCG_ABI_VERSION; }
 
-extern "C" int sscg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream) {
-    if (!x || !y || n <= 0) return SSCG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n, act, slope);
+#define SSCG_DT_OK(dt) ((dt) == SSCG_F32 || (dt) == SSCG_BF16)
+#define BF(p) reinterpret_cast<const __bf16*>(p)
+#define BFW(p) reinterpret_cast<__bf16*>(p)
+#define FP(p) reinterpret_cast<const float*>(p)
+#define FPW(p) reinterpret_cast<float*>(p)
+
+extern "C" int sscg_act_fwd(const void* x, void* y, int dtype, int64_t n, int act, float slope, void* stream) {
+    if (!x || !y || n <= 0 || !SSCG_DT_OK(dtype)) return SSCG_ERR_BAD_ARG;
+    if (dtype == SSCG_BF16)
+        hipLaunchKernelGGL(act_fwd_kernel<__bf16>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, BF(x), BFW(y), (size_t)n, act, slope);
+    else
+        hipLaunchKernelGGL(act_fwd_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, FP(x), FPW(y), (size_t)n, act, slope);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
 
-extern "C" int sscg_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, void* stream) {
-    if (!dy || !y || !dx || n <= 0) return SSCG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (size_t)n, act, slope);
+extern "C" int sscg_act_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n, int act, float slope, void* stream) {
+    if (!dy || !y || !dx || n <= 0 || !SSCG_DT_OK(dtype)) return SSCG_ERR_BAD_ARG;
+    if (dtype == SSCG_BF16)
+        hipLaunchKernelGGL(act_bwd_kernel<__bf16>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, BF(dy), BF(y), BFW(dx), (size_t)n, act, slope);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, FP(dy), FP(y), FPW(dx), (size_t)n, act, slope);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
 
-extern "C" int sscg_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
-    if (!a || !b || !y || n <= 0) return SSCG_ERR_BAD_ARG;
-    if (n % 4 == 0 && (((size_t)a | (size_t)b | (size_t)y) & 15) == 0) {
-        const size_t n4 = (size_t)n / 4;
-        hipLaunchKernelGGL(add4_kernel, dim3(ew_blocks((n4 + 1) / 2)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const f32x4*>(a), reinterpret_cast<const f32x4*>(b), reinterpret_cast<f32x4*>(y), n4);
+extern "C" int sscg_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream) {
+    if (!a || !b || !y || n <= 0 || !SSCG_DT_OK(dtype)) return SSCG_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool al = (((size_t)a | (size_t)b | (size_t)y) & 15) == 0;
+    if (dtype == SSCG_BF16) {
+        if (n % 8 == 0 && al) {
+            const size_t nv = (size_t)n / 8;
+            hipLaunchKernelGGL((addv_kernel<__bf16, 8>), dim3(ew_blocks((nv + 1) / 2)), dim3(256), 0, st, BF(a), BF(b), BFW(y), nv);
+        } else {
+            hipLaunchKernelGGL(add_kernel<__bf16>, dim3(ew_blocks(n)), dim3(256), 0, st, BF(a), BF(b), BFW(y), (size_t)n);
+        }
+    } else if (n % 4 == 0 && al) {
+        const size_t nv = (size_t)n / 4;
+        hipLaunchKernelGGL((addv_kernel<float, 4>), dim3(ew_blocks((nv + 1) / 2)), dim3(256), 0, st, FP(a), FP(b), FPW(y), nv);
     } else {
-        hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (size_t)n);
+        hipLaunchKernelGGL(add_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, FP(a), FP(b), FPW(y), (size_t)n);
     }
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0 || !SSCG_DT_OK(src_dtype) || !SSCG_DT_OK(dst_dtype)) return SSCG_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g(ew_blocks(n)), b(256);
+    if (src_dtype == SSCG_F32 && dst_dtype == SSCG_BF16) hipLaunchKernelGGL((cast_kernel<float, __bf16>), g, b, 0, st, FP(src), BFW(dst), (size_t)n);
+    else if (src_dtype == SSCG_BF16 && dst_dtype == SSCG_F32) hipLaunchKernelGGL((cast_kernel<__bf16, float>), g, b, 0, st, BF(src), FPW(dst), (size_t)n);
+    else if (src_dtype == SSCG_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, FP(src), FPW(dst), (size_t)n);
+    else hipLaunchKernelGGL((cast_kernel<__bf16, __bf16>), g, b, 0, st, BF(src), BFW(dst), (size_t)n);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -294,10 +355,12 @@ extern "C" int sscg_fill(float* x, int64_t n, float v, void* stream) {
     return SSCG_OK;
 }
 
-extern "C" int sscg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
-    if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return SSCG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n, p,
-                       1.f / (1.f - p), seed);
+extern "C" int sscg_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!x || !y || n <= 0 || p < 0.f || p >= 1.f || !SSCG_DT_OK(dtype)) return SSCG_ERR_BAD_ARG;
+    if (dtype == SSCG_BF16)
+        hipLaunchKernelGGL(dropout_kernel<__bf16>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, BF(x), BFW(y), (size_t)n, p, 1.f / (1.f - p), seed);
+    else
+        hipLaunchKernelGGL(dropout_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, FP(x), FPW(y), (size_t)n, p, 1.f / (1.f - p), seed);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -309,21 +372,27 @@ extern "C" int sscg_gauss_noise(const float* x, float* y, int64_t n, float sigma
     return SSCG_OK;
 }
 
-extern "C" int sscg_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, int P, int Q,
+extern "C" int sscg_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int N, int H, int W, int C, int P, int Q,
                                      void* stream) {
-    if (!x || !y || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0) return SSCG_ERR_BAD_ARG;
+    if (!x || !y || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0 || !SSCG_DT_OK(dtype)) return SSCG_ERR_BAD_ARG;
     if ((P - 1) * 2 - 1 >= H || (Q - 1) * 2 - 1 >= W) return SSCG_ERR_BAD_ARG;
     size_t total = (size_t)N * P * Q * C;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W, C, P, Q);
+    if (dtype == SSCG_BF16)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, BF(x), BFW(y), idx, N, H, W, C, P, Q);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, FP(x), FPW(y), idx, N, H, W, C, P, Q);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
 
-extern "C" int sscg_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, int P,
+extern "C" int sscg_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int N, int H, int W, int C, int P,
                                      int Q, void* stream) {
-    if (!dy || !idx || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0) return SSCG_ERR_BAD_ARG;
+    if (!dy || !idx || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0 || !SSCG_DT_OK(dtype)) return SSCG_ERR_BAD_ARG;
     size_t total = (size_t)N * H * W * C;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C, P, Q);
+    if (dtype == SSCG_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, BF(dy), idx, BFW(dx), N, H, W, C, P, Q);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, FP(dy), idx, FPW(dx), N, H, W, C, P, Q);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -354,18 +423,24 @@ extern "C" int sscg_upsample_bilinear_bwd(const float* dy, float* dx, int N, int
     return SSCG_OK;
 }
 
-extern "C" int sscg_reflect_pad(const float* x, float* y, int N, int H, int W, int C, int pad, void* stream) {
-    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || pad >= H || pad >= W) return SSCG_ERR_BAD_ARG;
+extern "C" int sscg_reflect_pad(const void* x, void* y, int dtype, int N, int H, int W, int C, int pad, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || pad >= H || pad >= W || !SSCG_DT_OK(dtype)) return SSCG_ERR_BAD_ARG;
     size_t total = (size_t)N * (H + 2 * pad) * (W + 2 * pad) * C;
-    hipLaunchKernelGGL(reflect_pad_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, pad);
+    if (dtype == SSCG_BF16)
+        hipLaunchKernelGGL(reflect_pad_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, BF(x), BFW(y), N, H, W, C, pad);
+    else
+        hipLaunchKernelGGL(reflect_pad_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, FP(x), FPW(y), N, H, W, C, pad);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
 
-extern "C" int sscg_reflect_pad_bwd(const float* dy, float* dx, int N, int H, int W, int C, int pad, void* stream) {
-    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || pad >= H || pad >= W) return SSCG_ERR_BAD_ARG;
+extern "C" int sscg_reflect_pad_bwd(const void* dy, void* dx, int dtype, int N, int H, int W, int C, int pad, void* stream) {
+    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || pad >= H || pad >= W || !SSCG_DT_OK(dtype)) return SSCG_ERR_BAD_ARG;
     size_t total = (size_t)N * H * W * C;
-    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C, pad);
+    if (dtype == SSCG_BF16)
+        hipLaunchKernelGGL(reflect_pad_bwd_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, BF(dy), BFW(dx), N, H, W, C, pad);
+    else
+        hipLaunchKernelGGL(reflect_pad_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, FP(dy), FPW(dx), N, H, W, C, pad);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

@@ -1,3 +1,28 @@
-// Internal glue: public ABI types + shared helpers.
+// Internal glue: public ABI types + host functions shared between translation units (device code is not linked
+// across files; only host-side launchers cross them).
 #pragma once
+#include <hip/hip_runtime.h>
 #include "../../include/sscg.h"
+
+// conv_bf16.hip: bf16 MFMA kernels behind sscg_conv2d_{fwd,dgrad,wgrad} (dispatch lives in conv_igemm.hip / conv_wgrad.hip)
+bool sscg_conv16_fwd_applies(const sscg_conv_desc* d);
+bool sscg_conv16_dgrad_applies(const sscg_conv_desc* d);
+bool sscg_conv16_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* wm, int* tiles_n, int* splits, int* full_tiles, int* m_tail0);
+size_t sscg_conv16_fwd_workspace(const sscg_conv_desc* d, long stat_L);
+size_t sscg_conv16_dgrad_workspace(const sscg_conv_desc* d);
+int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
+                    void* ws, size_t ws_bytes, hipStream_t st);
+int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
+                      void* ws, size_t ws_bytes, hipStream_t st);
+bool sscg_wgrad16_applies(const sscg_conv_desc* d);
+size_t sscg_wgrad16_workspace(const sscg_conv_desc* d);
+int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_wgrad.hip: dw = beta * dw + sum_s ws[s] (fixed order)
+int sscg_wgrad_reduce(const float* ws, float* dw, size_t n, int splits, float beta, hipStream_t st);
+// norm.hip: the statistics a conv epilogue left behind -> mean / rstd (+ running statistics); the rows that went through
+// split-K are summed by sscg_colstats_launch into `xrec` extra records
+int sscg_colstats_records(long rows, int C, int dtype);
+int sscg_colstats_launch(const void* x, int dtype, long rows, int C, double* part, hipStream_t st);
+int sscg_finalize_conv_stats(const double* stats, int valid_tiles, int rows_per_tile, int records_per_tile, const double* xrecs,
+                             int xrec, int xgroup, int G, long L, int C, float eps, float* mean, float* rstd, float* running_mean,
+                             float* running_var, float momentum, hipStream_t st);

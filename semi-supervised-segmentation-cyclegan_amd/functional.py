@@ -35,11 +35,27 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _need_hip(t):
+F32, BF16 = _lib.F32, _lib.BF16
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _need_hip(t, f32_only=False):
     if not t.is_cuda:
         raise _lib.SscgError("sscg kernels run on the MI355X only: got a %s tensor (no CPU fallback)" % t.device)
-    if t.dtype != torch.float32:
-        raise _lib.SscgError("fp32 tensor expected, got %s" % t.dtype)
+    if t.dtype != torch.float32 and (f32_only or t.dtype != torch.bfloat16):
+        raise _lib.SscgError("%s tensor expected, got %s" % ("fp32" if f32_only else "fp32 or bf16", t.dtype))
+
+
+def _dt(t):
+    return _DT[t.dtype]
+
+
+def _same_dtype(*ts):
+    d = ts[0].dtype
+    for t in ts[1:]:
+        if t is not None and t.dtype != d:
+            raise _lib.SscgError("operands of one element type expected, got %s and %s" % (d, t.dtype))
+    return _DT[d]
 
 
 class _Workspace:
@@ -145,6 +161,7 @@ def to_nhwc(x):
         raise _lib.SscgError("4-D tensor expected")
     if x.is_contiguous(memory_format=CL):
         return x
+    _need_hip(x, f32_only=True)      # bf16 tensors only exist inside the networks, where every kernel writes channels-last
     if not x.is_contiguous():
         x = x.contiguous()
     n, c, h, w = x.shape
@@ -155,6 +172,8 @@ def to_nhwc(x):
 
 def to_nchw(x):
     """channels-last tensor -> standard contiguous NCHW memory."""
+    if x.dtype == torch.bfloat16:
+        x = cast(x, torch.float32)
     _need_hip(x)
     if x.is_contiguous():
         return x
@@ -165,22 +184,41 @@ def to_nchw(x):
     return y
 
 
+_MODE = ["f32"]
+FUSE_STATS = [os.environ.get("SSCG_FUSE_STATS", "1") != "0"]    # norm statistics from the producing conv's epilogue (K3/K4)
+
+
 def set_conv_precision(mode):
-    """"f32" (default): exact fp32 MFMA contractions.  "bf16": the heavy (vectorised LDS-DMA) convolutions round their
-    operands to bfloat16 and contract on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors stay fp32 in HBM,
-    norms / losses / Adam stay fp32.  Process-wide (sscg_set_conv_precision)."""
-    code = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}.get(str(mode).lower())
-    if code is None:
-        raise _lib.SscgError("conv precision must be 'f32' or 'bf16', got %r" % (mode,))
-    check(lib.sscg_set_conv_precision(code), "sscg_set_conv_precision")
+    """Arithmetic of the networks (host-side policy; the library itself keeps no mode - every call carries its dtypes):
+      "f32"   (default, the reference's dtype, BASELINE config 2): fp32 tensors, exact fp32 MFMA contractions;
+      "bf16"  (BASELINE configs 3/5): activations and conv-weight operand copies are bfloat16 in HBM, bf16 LDS tiles,
+              v_mfma_f32_32x32x16_bf16 with fp32 accumulation; network inputs/outputs, norm statistics, losses, weight
+              gradients, master weights and Adam moments stay fp32;
+      "bf16c" (round-1 mode): fp32 tensors, operands rounded to bf16 between LDS and the matrix cores."""
+    m = {"f32": "f32", "fp32": "f32", "float32": "f32", "bf16": "bf16", "bfloat16": "bf16", "bf16c": "bf16c"}.get(str(mode).lower())
+    if m is None:
+        raise _lib.SscgError("conv precision must be 'f32', 'bf16' or 'bf16c', got %r" % (mode,))
+    _MODE[0] = m
 
 
 def get_conv_precision():
-    return "bf16" if lib.sscg_get_conv_precision() == 1 else "f32"
+    return _MODE[0]
 
 
 if os.environ.get("SSCG_CONV_PRECISION"):          # tools/ and ad-hoc runs; main.py / bench.py take --dtype
     set_conv_precision(os.environ["SSCG_CONV_PRECISION"])
+
+
+def cast(x, dtype):
+    """dtype conversion on the device (fp32 <-> bf16, RNE); layout (strides) preserved."""
+    _need_hip(x)
+    if x.dtype == dtype:
+        return x
+    if not (x.is_contiguous() or x.is_contiguous(memory_format=CL)):
+        x = x.contiguous()
+    y = torch.empty_like(x, dtype=dtype, memory_format=torch.preserve_format)
+    check(lib.sscg_cast(x.data_ptr(), _dt(x), y.data_ptr(), _DT[dtype], x.numel(), _stream()), "sscg_cast")
+    return y
 
 
 def conv_out_size(h, k, stride, pad, dil):
@@ -190,14 +228,20 @@ def conv_out_size(h, k, stride, pad, dil):
 _DESC_CACHE = {}
 
 
-def make_desc(xshape, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0):
+def make_desc(xshape, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0, xdt=F32, wdt=F32, ydt=F32, prec=0):
     """ConvDesc of a call, memoised (a step re-issues the same few dozen geometries thousands of times, and the host side
     of a launch is what bounds the 4-stream schedule)."""
-    key = (tuple(xshape), tuple(wshape), stride, pad, dil, pad_mode, act, slope)
+    key = (tuple(xshape), tuple(wshape), stride, pad, dil, pad_mode, act, slope, xdt, wdt, ydt, prec)
     d = _DESC_CACHE.get(key)
     if d is None:
         d = _DESC_CACHE[key] = _build_desc(xshape, wshape, stride, pad, dil, pad_mode, act, slope)
+        d.x_dtype, d.w_dtype, d.y_dtype, d.precision = xdt, wdt, ydt, prec
     return d
+
+
+def _prec():
+    """`precision` field for fp32-tensor contractions: bf16 rounding between LDS and the matrix cores in both bf16 modes."""
+    return 0 if _MODE[0] == "f32" else 1
 
 
 def _ws_bytes(d, which):
@@ -267,37 +311,92 @@ def _timed(kind, d, fn):
 
 
 # ----------------------------------------------------------------------------- raw ops
-def conv2d_fwd(x, w, bias, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0):
-    d = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, act, slope)
-    y = empty_nhwc(d.N, d.K, d.P, d.Q, x.device)
+def _fwd_operands(x, w):
+    """(weight operand, its dtype code) for a forward whose input is x: bf16 tiles when x is a bf16 activation with a
+    multiple of 64 channels, else the fp32 kernel on the fp32 master weight (stems, few-channel inputs)."""
+    if x.dtype == torch.bfloat16:
+        if x.shape[1] % 64:
+            raise _lib.SscgError("bf16 activations with %d channels: the bf16 conv kernels need a multiple of 64" % x.shape[1])
+        return weight_bf16(w), BF16
+    return w, F32
+
+
+def _out_dtype(out_f32):
+    return torch.bfloat16 if (_MODE[0] == "bf16" and not out_f32) else torch.float32
+
+
+def conv2d_fwd(x, w, bias, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0, out_f32=True, stats=None):
+    """y = act(conv(x, w) + bias).  out_f32: keep the output fp32 in bf16 mode (network heads).
+    stats = (G, L): also return the epilogue's column statistics buffer (None when the fusion does not apply)."""
+    wop, wdt = _fwd_operands(x, w)
+    ydt = _out_dtype(out_f32)
+    d = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, act, slope, _dt(x), wdt, _DT[ydt], _prec())
+    y = empty_nhwc(d.N, d.K, d.P, d.Q, x.device, ydt)
     ws = _WS.get(_ws_bytes(d, "fwd"), x.device)
-    _timed("fwd", d, lambda: check(lib.sscg_conv2d_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(),
+    if stats is not None:
+        nb = lib.sscg_conv2d_fwd_stats_bytes(C.byref(d), int(stats[0]), int(stats[1]))
+        if nb:
+            sbuf = torch.empty(nb, dtype=torch.uint8, device=x.device)
+            _timed("fwd", d, lambda: check(lib.sscg_conv2d_fwd_stats(C.byref(d), x.data_ptr(), wop.data_ptr(), _ptr(bias), y.data_ptr(),
+                                                                     int(stats[0]), int(stats[1]), sbuf.data_ptr(), nb, ws.data_ptr(),
+                                                                     ws.numel(), _stream()), "sscg_conv2d_fwd_stats"))
+            return y, (d, sbuf)
+    _timed("fwd", d, lambda: check(lib.sscg_conv2d_fwd(C.byref(d), x.data_ptr(), wop.data_ptr(), _ptr(bias), y.data_ptr(),
                                                        ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_fwd"))
-    return y
+    return (y, None) if stats is not None else y
 
 
-def weight_transposed(w):
-    """[K][R][S][C] -> [C][R][S][K] (the operand layout of sscg_conv2d_dgrad)."""
+def norm_stats_from_conv(cs, per_sample_glc, eps, running_mean=None, running_var=None, momentum=0.1):
+    """mean / rstd (and the running-statistics update) from the statistics a conv epilogue left (conv2d_fwd(..., stats=))."""
+    d, sbuf = cs
+    g, l, c = per_sample_glc
+    mean = torch.empty((g, c), dtype=torch.float32, device=sbuf.device)
+    rstd = torch.empty((g, c), dtype=torch.float32, device=sbuf.device)
+    check(lib.sscg_norm_stats_from_conv(C.byref(d), sbuf.data_ptr(), g, l, eps, mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean),
+                                        _ptr(running_var), momentum, _stream()), "sscg_norm_stats_from_conv")
+    return mean, rstd
+
+
+def weight_transposed(w, dtype=torch.float32):
+    """[K][R][S][C] -> [C][R][S][K] (the operand layout of sscg_conv2d_dgrad), as fp32 or bf16."""
     k, c, r, s = w.shape
-    wt = torch.empty((c, k, r, s), dtype=w.dtype, device=w.device, memory_format=CL)
-    check(lib.sscg_weight_krsc_to_crsk(w.data_ptr(), wt.data_ptr(), k, r * s, c, _stream()), "sscg_weight_krsc_to_crsk")
+    src = w
+    if dtype == torch.bfloat16:
+        src = weight_bf16(w)            # transposing the bf16 shadow reads half the bytes
+    wt = torch.empty((c, k, r, s), dtype=dtype, device=w.device, memory_format=CL)
+    check(lib.sscg_weight_krsc_to_crsk(src.data_ptr(), _dt(src), wt.data_ptr(), _DT[dtype], k, r * s, c, _stream()),
+          "sscg_weight_krsc_to_crsk")
     return wt
 
 
-def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0):
-    d = make_desc(xshape, wshape, stride, pad, dil)
-    dx = empty_nhwc(d.N, d.C, d.H, d.W, dy.device)
+def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0, out_dtype=torch.float32):
+    """dx = act(dgrad(dy, wt) + bias); `wt` is the transposed operand copy [C][R][S][K] (weight_transposed), fp32 for an
+    fp32 dy, bf16 for a bf16 dy."""
+    d = make_desc(xshape, wshape, stride, pad, dil, xdt=_DT[out_dtype], wdt=_dt(wt), ydt=_dt(dy), prec=_prec())
+    dx = empty_nhwc(d.N, d.C, d.H, d.W, dy.device, out_dtype)
     ws = _WS.get(_ws_bytes(d, "dgrad"), dy.device)
     _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wt.data_ptr(), _ptr(bias), dx.data_ptr(),
                                                            act, slope, ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_dgrad"))
     return dx
 
 
+def conv2d_dgrad_param(dy, w, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0, out_dtype=torch.float32):
+    """conv2d_dgrad with the transposed operand copy of parameter `w` taken from the per-parameter cache, in the element
+    type the kernel for dy reads (bf16 tiles for a bf16 dy, fp32 otherwise)."""
+    if dy.dtype == torch.bfloat16:
+        if wshape[0] % 64:
+            raise _lib.SscgError("bf16 output gradients with %d channels: the bf16 conv kernels need a multiple of 64" % wshape[0])
+        wt = _cached_wt(w, torch.bfloat16)
+    else:
+        wt = _cached_wt(w, torch.float32)
+    return conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias, act, slope, out_dtype)
+
+
 def conv2d_wgrad(x, dy, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, out=None, accumulate=False):
-    d = make_desc(x.shape, wshape, stride, pad, dil, pad_mode)
+    d = make_desc(x.shape, wshape, stride, pad, dil, pad_mode, xdt=_dt(x), ydt=_dt(dy), prec=_prec())
     if out is None:
         k, c, r, s = wshape
-        out = torch.empty((k, c, r, s), dtype=x.dtype, device=x.device, memory_format=CL)
+        out = torch.empty((k, c, r, s), dtype=torch.float32, device=x.device, memory_format=CL)
         accumulate = False
     ws = _WS.get(_ws_bytes(d, "wgrad"), x.device)
     _timed("wgrad", d, lambda: check(lib.sscg_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), out.data_ptr(),
@@ -312,7 +411,7 @@ def colsum(x2d_rows, cols, x, out=None, accumulate=False):
         accumulate = False
     nb = _cached_size(lib.sscg_colsum_workspace, x2d_rows, cols)
     ws = _WS.get(nb, x.device)
-    check(lib.sscg_colsum(x.data_ptr(), out.data_ptr(), x2d_rows, cols, 1.0 if accumulate else 0.0, ws.data_ptr(),
+    check(lib.sscg_colsum(x.data_ptr(), _dt(x), out.data_ptr(), x2d_rows, cols, 1.0 if accumulate else 0.0, ws.data_ptr(),
                           ws.numel(), _stream()), "sscg_colsum")
     return out
 
@@ -330,9 +429,13 @@ def _cached_size(fn, *args):
 
 
 def _glc(x, per_sample):
+    return _glc_shape(x.shape, per_sample)
+
+
+def _glc_shape(shape, per_sample):
     """[G][L][C] view of an NHWC tensor.  per_sample: True = InstanceNorm (G = N), False = BatchNorm (G = 1), an int
     k > 1 = BatchNorm over k batches stacked along N (G = k, each group N/k samples)."""
-    n, c, h, w = x.shape
+    n, c, h, w = shape
     if per_sample is True:
         return n, h * w, c
     k = 1 if per_sample is False else int(per_sample)
@@ -347,7 +450,7 @@ def norm_stats(x, per_sample, eps=1e-5, running_mean=None, running_var=None, mom
     rstd = torch.empty((g, c), dtype=torch.float32, device=x.device)
     nb = _cached_size(lib.sscg_norm_stats_workspace, g, l, c)
     ws = _WS.get(nb, x.device)
-    check(lib.sscg_norm_stats(x.data_ptr(), g, l, c, eps, mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean),
+    check(lib.sscg_norm_stats(x.data_ptr(), _dt(x), g, l, c, eps, mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean),
                               _ptr(running_var), momentum, ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_stats")
     return mean, rstd
 
@@ -356,7 +459,7 @@ def norm_apply(x, mean, rstd, gamma, beta, residual, per_sample, act=ACT_NONE, s
     g, l, c = _glc(x, per_sample)
     y = torch.empty_like(x, memory_format=CL)
     check(lib.sscg_norm_apply(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta), _ptr(residual),
-                              y.data_ptr(), g, l, c, act, slope, _stream()), "sscg_norm_apply")
+                              y.data_ptr(), _same_dtype(x, residual), g, l, c, act, slope, _stream()), "sscg_norm_apply")
     return y
 
 
@@ -368,7 +471,7 @@ def norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad=Tru
     nb = _cached_size(lib.sscg_norm_bwd_workspace, g, l, c)
     ws = _WS.get(nb, x.device)
     check(lib.sscg_norm_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
-                            dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), g, l, c, act, slope,
+                            dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _same_dtype(x, dy, y), g, l, c, act, slope,
                             1 if stats_grad else 0, ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_bwd")
     return dx, dres
 
@@ -381,36 +484,41 @@ def rstd_from_var(var, eps):
 
 def act_fwd(x, act, slope=0.0):
     y = torch.empty_like(x, memory_format=torch.preserve_format)
-    check(lib.sscg_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), act, slope, _stream()), "sscg_act_fwd")
+    check(lib.sscg_act_fwd(x.data_ptr(), y.data_ptr(), _dt(x), x.numel(), act, slope, _stream()), "sscg_act_fwd")
     return y
 
 
 def act_bwd(dy, y, act, slope=0.0):
     dx = torch.empty_like(y, memory_format=torch.preserve_format)
-    check(lib.sscg_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), act, slope, _stream()), "sscg_act_bwd")
+    check(lib.sscg_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), _same_dtype(y, dy), y.numel(), act, slope, _stream()), "sscg_act_bwd")
     return dx
 
 
 def add(a, b):
     y = torch.empty_like(a, memory_format=torch.preserve_format)
-    check(lib.sscg_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "sscg_add")
+    check(lib.sscg_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), _same_dtype(a, b), a.numel(), _stream()), "sscg_add")
     return y
 
 
 def fill_(x, v):
+    if x.dtype != torch.float32:
+        if v != 0.0 or (x.numel() * x.element_size()) % 4:
+            raise _lib.SscgError("fill_ of a %s tensor supports zero only" % x.dtype)
+        check(lib.sscg_fill(x.data_ptr(), x.numel() * x.element_size() // 4, 0.0, _stream()), "sscg_fill")
+        return x
     check(lib.sscg_fill(x.data_ptr(), x.numel(), float(v), _stream()), "sscg_fill")
     return x
 
 
 def dropout(x, p, seed):
     y = torch.empty_like(x, memory_format=torch.preserve_format)
-    check(lib.sscg_dropout(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _stream()), "sscg_dropout")
+    check(lib.sscg_dropout(x.data_ptr(), y.data_ptr(), _dt(x), x.numel(), p, seed, _stream()), "sscg_dropout")
     return y
 
 
 def gauss_noise(x, sigma, seed):
     """utils.GaussianNoise.forward on the device: x + sigma * x * N(0, 1) (utils.py:133-139)."""
-    _need_hip(x)
+    _need_hip(x, f32_only=True)
     y = torch.empty_like(x, memory_format=torch.preserve_format)
     check(lib.sscg_gauss_noise(x.data_ptr(), y.data_ptr(), x.numel(), float(sigma), int(seed), _stream()), "sscg_gauss_noise")
     return y
@@ -427,9 +535,9 @@ def pool_out_size(h):
 def maxpool_fwd(x):
     n, c, h, w = x.shape
     p, q = pool_out_size(h), pool_out_size(w)
-    y = empty_nhwc(n, c, p, q, x.device)
+    y = empty_nhwc(n, c, p, q, x.device, x.dtype)
     idx = torch.empty((n, c, p, q), dtype=torch.uint8, device=x.device, memory_format=CL)
-    check(lib.sscg_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), n, h, w, c, p, q, _stream()),
+    check(lib.sscg_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, p, q, _stream()),
           "sscg_maxpool3x3s2_fwd")
     return y, idx
 
@@ -437,13 +545,14 @@ def maxpool_fwd(x):
 def maxpool_bwd(dy, idx, xshape):
     n, c, h, w = xshape
     p, q = dy.shape[2], dy.shape[3]
-    dx = empty_nhwc(n, c, h, w, dy.device)
-    check(lib.sscg_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), n, h, w, c, p, q, _stream()),
+    dx = empty_nhwc(n, c, h, w, dy.device, dy.dtype)
+    check(lib.sscg_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), _dt(dy), n, h, w, c, p, q, _stream()),
           "sscg_maxpool3x3s2_bwd")
     return dx
 
 
 def upsample_fwd(x, oh, ow):
+    _need_hip(x, f32_only=True)          # the resize sits on the fp32 side of a network head (model.py:390-392)
     n, c, h, w = x.shape
     y = empty_nhwc(n, c, oh, ow, x.device)
     check(lib.sscg_upsample_bilinear_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, oh, ow, _stream()), "sscg_upsample_bilinear_fwd")
@@ -459,20 +568,21 @@ def upsample_bwd(dy, h, w):
 
 def reflect_pad(x, pad):
     n, c, h, w = x.shape
-    y = empty_nhwc(n, c, h + 2 * pad, w + 2 * pad, x.device)
-    check(lib.sscg_reflect_pad(x.data_ptr(), y.data_ptr(), n, h, w, c, pad, _stream()), "sscg_reflect_pad")
+    y = empty_nhwc(n, c, h + 2 * pad, w + 2 * pad, x.device, x.dtype)
+    check(lib.sscg_reflect_pad(x.data_ptr(), y.data_ptr(), _dt(x), n, h, w, c, pad, _stream()), "sscg_reflect_pad")
     return y
 
 
 def reflect_pad_bwd(dy, pad):
     n, c, oh, ow = dy.shape
-    dx = empty_nhwc(n, c, oh - 2 * pad, ow - 2 * pad, dy.device)
-    check(lib.sscg_reflect_pad_bwd(dy.data_ptr(), dx.data_ptr(), n, oh - 2 * pad, ow - 2 * pad, c, pad, _stream()),
+    dx = empty_nhwc(n, c, oh - 2 * pad, ow - 2 * pad, dy.device, dy.dtype)
+    check(lib.sscg_reflect_pad_bwd(dy.data_ptr(), dx.data_ptr(), _dt(dy), n, oh - 2 * pad, ow - 2 * pad, c, pad, _stream()),
           "sscg_reflect_pad_bwd")
     return dx
 
 
 def softmax_fwd(x):
+    _need_hip(x, f32_only=True)
     n, c, h, w = x.shape
     y = torch.empty_like(x, memory_format=CL)
     check(lib.sscg_softmax_fwd(x.data_ptr(), y.data_ptr(), n * h * w, c, _stream()), "sscg_softmax_fwd")
@@ -488,6 +598,7 @@ def softmax_bwd(dy, y):
 
 def argmax_onehot(x, want_index=False):
     """`x.max(1)[1]` + make_one_hot in one pass (model.py:435-437).  Returns (onehot NHWC, index [N,H,W] or None)."""
+    _need_hip(x, f32_only=True)
     x = to_nhwc(x)
     n, c, h, w = x.shape
     oh = torch.empty_like(x, memory_format=CL)
@@ -497,6 +608,7 @@ def argmax_onehot(x, want_index=False):
 
 
 def argmax_index(x):
+    _need_hip(x, f32_only=True)
     x = to_nhwc(x)
     n, c, h, w = x.shape
     idx = torch.empty((n, h, w), dtype=torch.int64, device=x.device)
@@ -562,9 +674,9 @@ def _loss_ws(device):
     return _WS.get(lib.sscg_loss_workspace(0), device)
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
-    check(lib.sscg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
-                             step, grad_scale, _stream()), "sscg_adam_step")
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, shadow_bf16=None):
+    check(lib.sscg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow_bf16), p.numel(), lr, beta1, beta2,
+                             eps, step, grad_scale, _stream()), "sscg_adam_step")
 
 
 # ----------------------------------------------------------------------------- autograd functions
@@ -578,34 +690,73 @@ def bump_weight_epoch(epoch_cell=None):
     (epoch_cell if epoch_cell is not None else _WEIGHT_EPOCH)[0] += 1
 
 
-_WT_USERS = {}      # id -> weakref of the weights whose transposed copy a backward pass has asked for
+_WT_USERS = {}      # id -> (weakref of the weight, set of operand-copy kinds a pass has asked for: "t32", "t16", "w16")
+
+
+def _note_user(w, kind):
+    ent = _WT_USERS.get(id(w))
+    if ent is None:
+        key = id(w)
+        ent = _WT_USERS[key] = (weakref.ref(w, lambda _r, key=key: _WT_USERS.pop(key, None)), set())
+    ent[1].add(kind)
 
 
 def refresh_transposed_weights(weights=()):
-    """Bring the cached transposed copies of `weights` (and of every weight a backward pass has asked for) up to
-    date on the CURRENT stream.  The step calls this before it forks its forward passes over two streams: their
-    backward passes then only read the cache (a lazily rebuilt copy would be written on one stream and read on
-    the other)."""
+    """Bring the cached operand copies (transposed fp32 / transposed bf16 / plain bf16) of `weights` - and of every weight
+    a pass has asked for - up to date on the CURRENT stream.  The step calls this before it forks its forward passes over
+    two streams: their backward passes then only read the cache (a lazily rebuilt copy would be written on one stream and
+    read on the other)."""
+    bf16 = _MODE[0] == "bf16"
     for w in weights:
-        _cached_wt(w)
-    for r in list(_WT_USERS.values()):
+        _cached_wt(w, torch.bfloat16 if (bf16 and w.shape[0] % 64 == 0) else torch.float32)
+    for r, kinds in list(_WT_USERS.values()):
         w = r()
-        if w is not None:
-            _cached_wt(w)
+        if w is None:
+            continue
+        if "t32" in kinds:
+            _cached_wt(w, torch.float32)
+        if "t16" in kinds:
+            _cached_wt(w, torch.bfloat16)
+        if "w16" in kinds:
+            weight_bf16(w)
 
 
-def _cached_wt(w):
+def _wtag(w):
+    return (w._version, getattr(w, "_sscg_epoch", _WEIGHT_EPOCH)[0], w.data_ptr())
+
+
+def _cached_wt(w, dtype=torch.float32):
     """Transposed copy of a weight, cached ON the tensor object (dies with it; a recycled address can never
     alias).  Valid while neither torch (`_version`) nor our optimiser (`_WEIGHT_EPOCH`) has rewritten it."""
-    if id(w) not in _WT_USERS:
-        key = id(w)
-        _WT_USERS[key] = weakref.ref(w, lambda _r, key=key: _WT_USERS.pop(key, None))
-    tag = (w._version, getattr(w, "_sscg_epoch", _WEIGHT_EPOCH)[0], w.data_ptr())
-    ent = getattr(w, "_sscg_wt", None)
+    b16 = dtype == torch.bfloat16
+    _note_user(w, "t16" if b16 else "t32")
+    attr = "_sscg_wt16" if b16 else "_sscg_wt"
+    tag = _wtag(w)
+    ent = getattr(w, attr, None)
     if ent is None or ent[0] != tag:
-        ent = (tag, weight_transposed(w))
+        ent = (tag, weight_transposed(w, dtype))
         try:
-            w._sscg_wt = ent
+            setattr(w, attr, ent)
+        except AttributeError:
+            pass
+    return ent[1]
+
+
+def weight_bf16(w):
+    """bf16 operand copy of a conv weight, same [K][R][S][C] layout.  A parameter owned by optim.FusedAdam reads the
+    optimiser's bf16 shadow arena (rewritten by the Adam kernel itself: no per-step cast); any other weight (the frozen
+    nets) gets a cached cast."""
+    _note_user(w, "w16")
+    opt = getattr(w, "_sscg_opt", None)
+    opt = opt() if opt is not None else None
+    if opt is not None:
+        return opt.shadow_view(w)
+    tag = _wtag(w)
+    ent = getattr(w, "_sscg_w16", None)
+    if ent is None or ent[0] != tag:
+        ent = (tag, cast(w, torch.bfloat16))
+        try:
+            w._sscg_w16 = ent
         except AttributeError:
             pass
     return ent[1]
@@ -620,21 +771,41 @@ def _acc_target(param):
 
 
 class Conv2dFn(torch.autograd.Function):
-    """nn.Conv2d (+ folded nn.ReflectionPad2d, + fused activation when no norm layer follows)."""
+    """nn.Conv2d (+ folded nn.ReflectionPad2d, + fused activation when no norm layer follows).
+
+    `norm` = None, or the description of the normalisation layer that follows - (per_sample, eps, running_mean,
+    running_var, momentum): the conv's epilogue then also produces that layer's batch statistics (arch/ops.py:40-57 "Conv +
+    InstanceNorm / BatchNorm" blocks) and the function returns (y, mean, rstd); mean is None when the fusion does not apply
+    to the geometry (the caller falls back to a statistics pass over y)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, pad_mode, act, slope):
+    def forward(ctx, x, w, bias, stride, pad, dil, pad_mode, act, slope, out_f32, norm):
         x = to_nhwc(x)
-        y = conv2d_fwd(x, w, bias, stride, pad, dil, pad_mode, act, slope)
+        mean = rstd = None
+        if norm is not None:
+            per_sample, eps, rmean, rvar, momentum = norm
+            n, _, h, wd = x.shape
+            p, q = conv_out_size(h, w.shape[2], stride, pad, dil), conv_out_size(wd, w.shape[3], stride, pad, dil)
+            g, l, c = _glc_shape((n, w.shape[0], p, q), per_sample)
+            y, cs = conv2d_fwd(x, w, bias, stride, pad, dil, pad_mode, act, slope, out_f32, stats=(g, l))
+            if cs is not None:
+                mean, rstd = norm_stats_from_conv(cs, (g, l, c), eps, rmean, rvar, momentum)
+        else:
+            y = conv2d_fwd(x, w, bias, stride, pad, dil, pad_mode, act, slope, out_f32)
         ctx.cfg = (stride, pad, dil, pad_mode, act, slope)
         ctx.has_bias = bias is not None
         ctx.wref = w
         ctx.bref = bias
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
-        return y
+        if norm is None:
+            return y
+        if mean is None:
+            return y, None, None
+        ctx.mark_non_differentiable(mean, rstd)
+        return y, mean, rstd
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x, w, y = ctx.saved_tensors
         stride, pad, dil, pad_mode, act, slope = ctx.cfg
         dy = to_nhwc(dy)
@@ -644,7 +815,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if pad_mode == PAD_REFLECT:
                 raise _lib.SscgError("input gradient through a reflection-padded conv: use ReflectPadFn + pad=0 conv")
-            dx = conv2d_dgrad(dy, _cached_wt(ctx.wref), x.shape, w.shape, stride, pad, dil)
+            dx = conv2d_dgrad_param(dy, ctx.wref, x.shape, w.shape, stride, pad, dil, out_dtype=x.dtype)
         want_w = ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         wacc = _acc_target(ctx.wref) if want_w else None
@@ -664,7 +835,7 @@ class Conv2dFn(torch.autograd.Function):
             dw = conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode)
         if want_b and bacc is None:
             db = colsum(n * p * q, k, dy)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
@@ -683,8 +854,9 @@ class ConvTranspose2dFn(torch.autograd.Function):
         # mirrored conv: input [n, cout, oh, ow] -> output [n, cin, h, wd]
         if conv_out_size(oh, r, stride, pad, 1) != h or conv_out_size(ow, s, stride, pad, 1) != wd:
             raise _lib.SscgError("unsupported ConvTranspose2d geometry")
-        wt = _cached_wt(w)  # [Cout][R][S][Cin]
-        y = conv2d_dgrad(x, wt, (n, cout, oh, ow), (cin, cout, r, s), stride, pad, 1, bias, act, slope)
+        # the transposed operand copy [Cout][R][S][Cin] comes from the per-parameter cache inside conv2d_dgrad
+        y = conv2d_dgrad_param(x, w, (n, cout, oh, ow), (cin, cout, r, s), stride, pad, 1, bias, act, slope,
+                               out_dtype=_out_dtype(False))
         ctx.cfg = (stride, pad, act, slope)
         ctx.has_bias = bias is not None
         ctx.wref, ctx.bref = w, bias
@@ -701,7 +873,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # gradient wrt x = forward of the mirrored conv applied to dy
-            dx = conv2d_fwd(dy, w, None, stride, pad, 1)
+            dx = conv2d_fwd(dy, w, None, stride, pad, 1, out_f32=(x.dtype == torch.float32))
         want_w = ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         wacc = _acc_target(ctx.wref) if want_w else None
@@ -728,12 +900,15 @@ class NormActFn(torch.autograd.Function):
     """InstanceNorm2d / BatchNorm2d (+ residual add) + activation, one statistics pass + one apply pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, per_sample, training, momentum, eps, act, slope):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, per_sample, training, momentum, eps, act, slope,
+                pre_mean=None, pre_rstd=None):
         x = to_nhwc(x)
         if residual is not None:
             residual = to_nhwc(residual)
         use_batch_stats = training or running_mean is None
-        if use_batch_stats:
+        if use_batch_stats and pre_mean is not None:
+            mean, rstd = pre_mean, pre_rstd      # produced by the conv's epilogue (running statistics already advanced there)
+        elif use_batch_stats:
             upd = training and running_mean is not None and per_sample is not True
             mean, rstd = norm_stats(x, per_sample, eps, running_mean if upd else None, running_var if upd else None, momentum)
         else:
@@ -777,7 +952,7 @@ class NormActFn(torch.autograd.Function):
             run_on_side_stream(dy.device, (dgamma, dbeta), arena_grads, lane=getattr(ctx.gref, "_sscg_lane", 0))
         if not ctx.needs_input_grad[0]:
             dx = None
-        return dx, ret_g, ret_b, dres, None, None, None, None, None, None, None, None
+        return dx, ret_g, ret_b, dres, None, None, None, None, None, None, None, None, None, None
 
 
 class ActFn(torch.autograd.Function):
@@ -927,6 +1102,7 @@ class CrossEntropyFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, labels):
+        _need_hip(logits, f32_only=True)
         logits = to_nhwc(logits)
         labels = labels.contiguous()
         n, c, h, w = logits.shape
@@ -955,7 +1131,7 @@ class MSEConstFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, target):
-        _need_hip(x)
+        _need_hip(x, f32_only=True)
         if not (x.is_contiguous() or x.is_contiguous(memory_format=CL)):
             x = x.contiguous()
         loss = _scalar(x.device)
@@ -980,6 +1156,8 @@ class L1Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b):
+        _need_hip(a, f32_only=True)
+        _need_hip(b, f32_only=True)
         a, b = to_nhwc(a), to_nhwc(b)
         loss = _scalar(a.device)
         ws = _loss_ws(a.device)
@@ -1022,24 +1200,34 @@ class WeightedSumFn(torch.autograd.Function):
 
 
 # functional spellings
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0):
-    return Conv2dFn.apply(x, w, bias, stride, pad, dil, pad_mode, act, slope)
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0, out_f32=True):
+    """out_f32 matters in bf16 mode only: True keeps the result fp32 (network heads), False makes it a bf16 activation."""
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil, pad_mode, act, slope, out_f32, None)
+
+
+def conv2d_norm_stats(x, w, bias, stride, pad, dil, pad_mode, norm):
+    """Convolution whose epilogue also produces the statistics of the normalisation layer `norm` = (per_sample, eps,
+    running_mean, running_var, momentum) that follows it.  Returns (y, mean, rstd); mean/rstd None = not fused."""
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil, pad_mode, ACT_NONE, 0.0, False, norm)
 
 
 def conv_transpose2d(x, w, bias=None, stride=1, pad=0, out_pad=0, act=ACT_NONE, slope=0.0):
     return ConvTranspose2dFn.apply(x, w, bias, stride, pad, out_pad, act, slope)
 
 
-def instance_norm_act(x, act=ACT_NONE, slope=0.0, residual=None, eps=1e-5):
-    return NormActFn.apply(x, None, None, residual, None, None, True, True, 0.0, eps, act, slope)
+def instance_norm_act(x, act=ACT_NONE, slope=0.0, residual=None, eps=1e-5, stats=None):
+    m, r = stats if stats is not None else (None, None)
+    return NormActFn.apply(x, None, None, residual, None, None, True, True, 0.0, eps, act, slope, m, r)
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
-                   residual=None, groups=1):
+                   residual=None, groups=1, stats=None):
     """groups > 1: x holds `groups` batches stacked along N; each is normalised with its own statistics and the running
-    statistics advance once per group, in order - what `groups` successive calls would compute, in one launch."""
+    statistics advance once per group, in order - what `groups` successive calls would compute, in one launch.
+    stats = (mean, rstd) already produced by the preceding conv's epilogue (training mode)."""
     per = False if groups == 1 else int(groups)
-    return NormActFn.apply(x, gamma, beta, residual, running_mean, running_var, per, training, momentum, eps, act, slope)
+    m, r = stats if stats is not None else (None, None)
+    return NormActFn.apply(x, gamma, beta, residual, running_mean, running_var, per, training, momentum, eps, act, slope, m, r)
 
 
 def upsample_bilinear(x, size):

@@ -10,6 +10,8 @@ matching arenas for the gradient and both moments.  Consequences:
     materialises or adds per-parameter gradient tensors.
 `state_dict()` keeps torch.optim.Adam's format (per-parameter `step`, `exp_avg`, `exp_avg_sq`) for the
 parameters that have received a gradient, so checkpoints interchange with the reference."""
+import weakref
+
 import torch
 
 from . import functional as F
@@ -41,6 +43,8 @@ class FusedAdam(torch.optim.Optimizer):
         for t in (self.grad, self.exp_avg, self.exp_avg_sq):
             F.fill_(t, 0.0)
         self.trainable = ps
+        self.arena16 = None    # bf16 shadow of `arena` (bf16 mode): the conv operand copies, rewritten by the Adam kernel itself
+        self._shadow_ver = {}
         self._epoch = [0]      # bumped by step(): the cached transposed copies of these weights are stale
         self.slices = {}
         off = 0
@@ -53,6 +57,7 @@ class FusedAdam(torch.optim.Optimizer):
             p._sscg_grad = g
             p._sscg_touched = False
             p._sscg_epoch = self._epoch
+            p._sscg_opt = weakref.ref(self)
             p._sscg_lane = len(self.slices)      # side-stream lane of this parameter's gradient kernels (all of them: they accumulate)
             p.grad = g
             off += self._padded(n)
@@ -66,6 +71,26 @@ class FusedAdam(torch.optim.Optimizer):
         """View of flat[off : off+numel] with p's logical shape and (dense) strides."""
         return torch.as_strided(flat, p.shape, p.stride(), off)
 
+    # ---- bf16 shadow arena (BASELINE configs 3/5): conv weights as bf16 operands, fp32 master copy in `arena`
+    def refresh_shadow(self):
+        """(Re)build the whole shadow from the fp32 arena: first use, after a broadcast, after a checkpoint load."""
+        if self.arena16 is None:
+            self.arena16 = torch.empty(self.arena.numel(), dtype=torch.bfloat16, device=self.arena.device)
+        F.check(F.lib.sscg_cast(self.arena.data_ptr(), F.F32, self.arena16.data_ptr(), F.BF16, self.arena.numel(), F._stream()),
+                "sscg_cast")
+        self._shadow_ver = {p: p._version for p in self.trainable}
+
+    def shadow_view(self, p):
+        """bf16 view of parameter p inside the shadow arena (same logical shape / strides as p)."""
+        if self.arena16 is None:
+            self.refresh_shadow()
+        elif self._shadow_ver.get(p) != p._version:     # torch wrote p (load_state_dict, init): re-cast that slice
+            off, n = self.slices[p]
+            F.check(F.lib.sscg_cast(self.arena[off:off + n].data_ptr(), F.F32, self.arena16[off:off + n].data_ptr(), F.BF16, n,
+                                    F._stream()), "sscg_cast")
+            self._shadow_ver[p] = p._version
+        return self._view(self.arena16, p, self.slices[p][0])
+
     def zero_grad(self, set_to_none=False):
         F.fill_(self.grad, 0.0)
 
@@ -75,7 +100,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._steps += 1
         F.SideStream.join(self.arena.device)     # weight gradients are accumulated on the side stream
         F.adam_step(self.arena, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                    self._steps, 1.0 / self.world_size)
+                    self._steps, 1.0 / self.world_size, shadow_bf16=self.arena16)
         F.bump_weight_epoch(self._epoch)
 
     def mark_touched(self):

@@ -37,6 +37,8 @@ class DataParallel:
         for opt in (g_opt, d_opt):
             opt.world_size = self.world_size
             broadcast_flat(opt.arena)
+            if opt.arena16 is not None:
+                opt.refresh_shadow()
         for net in nets:
             for t in list(net.parameters()) + list(net.buffers()):
                 if getattr(t, "_sscg_grad", None) is None:   # arena-resident parameters were broadcast above

@@ -28,9 +28,16 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_conv_desc_layout_matches_header():
     import ctypes
     lib = load_sub("_lib")
-    assert ctypes.sizeof(lib.ConvDesc) == 15 * 4
+    assert ctypes.sizeof(lib.ConvDesc) == 19 * 4
     names = [f[0] for f in lib.ConvDesc._fields_]
-    assert names == ["N", "H", "W", "C", "K", "R", "S", "P", "Q", "stride", "pad", "dil", "pad_mode", "act", "slope"]
+    assert names == ["N", "H", "W", "C", "K", "R", "S", "P", "Q", "stride", "pad", "dil", "pad_mode", "act", "slope",
+                     "x_dtype", "w_dtype", "y_dtype", "precision"]
+    # the header declares the same members in the same order
+    src = open(os.path.join(ROOT, "include", "sscg.h")).read()
+    body = src[src.index("typedef struct sscg_conv_desc {"):src.index("} sscg_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    members = [m.strip() for decl in re.findall(r"(?:int32_t|float)\s+([^;]+);", body) for m in decl.split(",")]
+    assert members == names
 
 
 def test_product_refuses_cpu_tensors():
@@ -74,10 +81,21 @@ def test_argument_errors_are_returned_not_raised():
     assert lib.sscg_conv2d_fwd(C.byref(dl), one, one, None, one, None, 0, None) == WORKSPACE
     assert lib.sscg_conv2d_wgrad(C.byref(dl), one, one, one, 0.0, None, 0, None) == WORKSPACE
     # normalisation / class ops / optimiser / input pipeline
-    assert lib.sscg_norm_stats(None, 1, 10, 4, 1e-5, None, None, None, None, 0.1, None, 0, None) == BAD_ARG
-    assert lib.sscg_norm_apply(one, one, one, one, None, None, one, 1, 10, 4, 0, 0.0, None) == BAD_ARG  # gamma without beta
+    assert lib.sscg_norm_stats(None, 0, 1, 10, 4, 1e-5, None, None, None, None, 0.1, None, 0, None) == BAD_ARG
+    assert lib.sscg_norm_stats(one, 7, 1, 10, 4, 1e-5, one, one, None, None, 0.1, one, 1 << 20, None) == BAD_ARG   # unknown dtype code
+    assert lib.sscg_norm_apply(one, one, one, one, None, None, one, 0, 1, 10, 4, 0, 0.0, None) == BAD_ARG  # gamma without beta
     assert lib.sscg_softmax_fwd(None, None, 10, 4, None) == BAD_ARG
     assert lib.sscg_confusion_hist(one, one, 10, 65, one, None) == BAD_ARG                            # C > 64
     assert lib.sscg_label_lut(one, one, 10, None, None) == BAD_ARG
-    assert lib.sscg_set_conv_precision(7) == BAD_ARG and lib.sscg_get_conv_precision() == 0
-    assert lib.sscg_set_conv_precision(1) == 0 and lib.sscg_get_conv_precision() == 1 and lib.sscg_set_conv_precision(0) == 0
+    # dtype combinations the kernels do not cover are refused, not guessed: bf16 input with an fp32 weight operand
+    mix = L.ConvDesc(N=2, H=16, W=16, C=64, K=64, R=3, S=3, P=16, Q=16, stride=1, pad=1, dil=1, pad_mode=0, act=0, slope=0.0,
+                     x_dtype=L.BF16, w_dtype=L.F32, y_dtype=L.BF16, precision=0)
+    assert lib.sscg_conv2d_fwd(C.byref(mix), one, one, None, one, None, 0, None) == UNSUPPORTED
+    bad = L.ConvDesc(N=2, H=16, W=16, C=64, K=64, R=3, S=3, P=16, Q=16, stride=1, pad=1, dil=1, pad_mode=0, act=0, slope=0.0,
+                     precision=3)
+    assert lib.sscg_conv2d_fwd(C.byref(bad), one, one, None, one, None, 0, None) == BAD_ARG
+    # the fused-statistics query answers 0 where the fusion does not apply (3-channel head) and > 0 where it does
+    head = L.ConvDesc(N=2, H=16, W=16, C=64, K=3, R=3, S=3, P=16, Q=16, stride=1, pad=1, dil=1, pad_mode=0, act=0, slope=0.0)
+    assert lib.sscg_conv2d_fwd_stats_bytes(C.byref(head), 2, 256) == 0
+    assert lib.sscg_conv2d_fwd_stats_bytes(C.byref(dl), 1, 8 * 33 * 33) > 0
+    assert lib.sscg_conv2d_fwd_stats_bytes(C.byref(dl), 1, 77) == 0                                   # G * L != N * P * Q

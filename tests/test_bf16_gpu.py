@@ -1,0 +1,379 @@
+"""The bf16 path of BASELINE configs 3/5 (`--dtype bf16`): bf16 activations and conv-weight operands in HBM, bf16 LDS
+tiles, v_mfma_f32_32x32x16_bf16 with fp32 accumulation; fp32 master weights, statistics, losses, weight gradients.
+
+Kernel parity is EXACT in the following sense: a bf16 MFMA multiplies bf16 operands exactly and accumulates in fp32, so
+the fp32 result must equal an fp64 convolution of the SAME bf16-rounded operands up to fp32 accumulation order (1e-5
+class); where the kernel writes a bf16 tensor the comparison adds one bf16 rounding of the result (2^-9 relative).
+Network / step level: bf16 rounding of every activation is real arithmetic noise; the tolerances are stated per test."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from conftest import load_sub
+from oracle import fixtures as FX
+from oracle import step as ostep
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+BF = torch.bfloat16
+EPS16 = 2.0 ** -8          # one bf16 rounding: relative error <= 2^-9 of the value, compared against the tensor's max
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def r16(t):
+    """fp64 copy of the bf16 rounding of t (what a bf16 tensor holds)."""
+    return t.float().to(BF).double()
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def dev16(t, dev):
+    return t.float().to(dev).to(BF).contiguous(memory_format=CL)
+
+
+def dev32(t, dev):
+    return t.float().to(dev).contiguous(memory_format=CL)
+
+
+@pytest.fixture()
+def bf16_mode():
+    F = load_sub("functional")
+    F.set_conv_precision("bf16")
+    yield F
+    F.set_conv_precision("f32")
+
+
+# (N, C, H, W, K, R, stride, pad, dil)   every C and K a multiple of 64: bf16 tiles on both sides
+CONV16 = [
+    (2, 256, 33, 33, 256, 3, 1, 2, 2),      # DeepLab layer3 conv2 (64x64 tiles, tail split-K)
+    (2, 64, 65, 65, 64, 3, 1, 1, 1),        # layer1 conv2
+    (2, 256, 33, 33, 1024, 1, 1, 0, 1),     # conv3 1x1 (short reduction)
+    (2, 1024, 17, 17, 256, 1, 1, 0, 1),
+    (2, 256, 33, 33, 512, 1, 2, 0, 1),      # stride-2 1x1 downsample: three of the four dgrad parity classes meet no tap
+    (2, 64, 64, 64, 128, 3, 2, 1, 1),       # ResnetGenerator down-conv: dgrad by parity class
+    (2, 128, 32, 32, 256, 4, 2, 1, 1),      # PatchGAN 4x4 stride 2
+    (4, 512, 33, 33, 512, 3, 1, 4, 4),      # layer4 conv2, dilation 4
+    (16, 256, 33, 65, 256, 3, 1, 2, 2),     # config-3 geometry (Cityscapes 256x512, batch 16): 128x128 tiles
+    (2, 64, 128, 256, 64, 3, 1, 1, 1),      # 128x64 tiles (64 output channels on many rows)
+]
+
+
+@pytest.mark.parametrize("case", CONV16, ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_s%d_p%d_d%d" % c)
+def test_conv_bf16_tensors(case, dev, bf16_mode):
+    """forward / data gradient / weight gradient with bf16 activations and bf16 weight operands."""
+    F = bf16_mode
+    n, c, h, w, k, r, s, p, d = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, r, r, generator=g) * (1.0 / (c * r * r) ** 0.5)
+    b = torch.randn(k, generator=g) * 0.1
+    xr, wr = r16(x).requires_grad_(True), r16(wt).requires_grad_(True)
+    yr = TF.conv2d(xr, wr, b.double(), s, p, d)
+    gy = torch.randn(yr.shape, generator=g)
+    gyr = r16(gy)
+    yr.backward(gyr)
+    xg, wg = dev16(x, dev), dev16(wt, dev)
+    y = F.conv2d_fwd(xg, wg, b.to(dev), s, p, d, out_f32=True)        # fp32 result: accumulation order only
+    assert y.dtype == torch.float32 and rel(y, yr) < 2e-5
+    y16 = F.conv2d_fwd(xg, wg, b.to(dev), s, p, d, out_f32=False)
+    assert y16.dtype == BF and rel(y16, yr) < EPS16
+    gyg = dev16(gy, dev)
+    wtt = F.weight_transposed(wg, BF)
+    dx = F.conv2d_dgrad(gyg, wtt, x.shape, wt.shape, s, p, d, out_dtype=torch.float32)
+    assert rel(dx, xr.grad) < 2e-5
+    dx16 = F.conv2d_dgrad(gyg, wtt, x.shape, wt.shape, s, p, d, out_dtype=BF)
+    assert dx16.dtype == BF and rel(dx16, xr.grad) < EPS16
+    dw = F.conv2d_wgrad(xg, gyg, wt.shape, s, p, d)
+    assert dw.dtype == torch.float32 and rel(dw, wr.grad) < 2e-5
+    acc = torch.ones_like(dw)
+    F.conv2d_wgrad(xg, gyg, wt.shape, s, p, d, out=acc, accumulate=True)
+    assert rel(acc - 1.0, wr.grad) < 2e-4
+
+
+# layers at a network's fp32 boundary: (N, C, H, W, K, R, stride, pad, dil, x_is_f32)
+EDGE = [
+    (2, 3, 64, 64, 64, 7, 2, 3, 1, True),       # DeepLab stem: fp32 image in, bf16 out; dgrad into the image
+    (2, 21, 64, 64, 64, 7, 2, 3, 1, True),      # Gis stem (one-hot / softmax input, 21 channels: scalar loader)
+    (2, 20, 32, 64, 64, 7, 2, 3, 1, True),      # Cityscapes: 20 channels (vectorised, non-fast loader)
+    (2, 3, 64, 64, 64, 1, 1, 0, 1, True),       # PixelDiscriminator conv1
+    (2, 2048, 9, 9, 21, 3, 1, 6, 6, False),     # DeepLab classifier head: bf16 in, fp32 logits out (narrow tile, split-K)
+    (2, 2048, 9, 17, 20, 3, 1, 12, 12, False),
+    (2, 128, 64, 64, 1, 1, 1, 0, 1, False),     # PixelDiscriminator head 128 -> 1
+    (2, 64, 70, 70, 3, 7, 1, 0, 1, False),      # ResnetGenerator head 64 -> 3
+]
+
+
+@pytest.mark.parametrize("case", EDGE, ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_s%d_p%d_d%d_%s" % (c[:9] + ("stem" if c[9] else "head",)))
+def test_conv_bf16_mode_at_the_fp32_boundary(case, dev, bf16_mode):
+    """Stems read fp32 tensors (fp32 kernel, bf16 contraction, bf16 out); heads write fp32 from bf16 activations; their
+    data / weight gradients mix the two element types."""
+    F = bf16_mode
+    n, c, h, w, k, r, s, p, d, stem = case
+    g = torch.Generator().manual_seed(sum(case[:9]))
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, r, r, generator=g) * (1.0 / (c * r * r) ** 0.5)
+    xr, wr = r16(x).requires_grad_(True), r16(wt).requires_grad_(True)
+    yr = TF.conv2d(xr, wr, None, s, p, d)
+    gy = torch.randn(yr.shape, generator=g)
+    gyr = r16(gy)
+    yr.backward(gyr)
+    wg32 = dev32(wt, dev)
+    if stem:
+        xg = dev32(x, dev)                                   # fp32 input (values NOT pre-rounded: the contraction rounds them)
+        y = F.conv2d_fwd(xg, wg32, None, s, p, d, out_f32=False)
+        assert y.dtype == BF and rel(y, yr) < EPS16
+        gyg = dev16(gy, dev)
+        dx = F.conv2d_dgrad(gyg, F.weight_transposed(wg32, BF), x.shape, wt.shape, s, p, d, out_dtype=torch.float32)
+        assert rel(dx, xr.grad) < 2e-5
+        dw = F.conv2d_wgrad(xg, gyg, wt.shape, s, p, d)
+        assert rel(dw, wr.grad) < 5e-5
+    else:
+        xg = dev16(x, dev)
+        y = F.conv2d_fwd(xg, dev16(wt, dev), None, s, p, d, out_f32=True)
+        assert y.dtype == torch.float32 and rel(y, yr) < 2e-5
+        gyg = dev32(gyr, dev)                                # fp32 gradient of an fp32 head output
+        dx = F.conv2d_dgrad(gyg, F.weight_transposed(wg32, torch.float32), x.shape, wt.shape, s, p, d, out_dtype=BF)
+        assert dx.dtype == BF and rel(dx, xr.grad) < EPS16
+        dw = F.conv2d_wgrad(xg, gyg, wt.shape, s, p, d)
+        assert rel(dw, wr.grad) < 5e-5
+
+
+def test_conv_transpose_bf16(dev, bf16_mode):
+    F = bf16_mode
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 256, 16, 16, generator=g)
+    w = torch.randn(256, 128, 3, 3, generator=g) * 0.03
+    xr, wr = r16(x).requires_grad_(True), r16(w).requires_grad_(True)
+    yr = TF.conv_transpose2d(xr, wr, None, 2, 1, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(r16(gy))
+    xg = dev16(x, dev).requires_grad_(True)
+    wg = torch.nn.Parameter(dev32(w, dev))
+    y = F.conv_transpose2d(xg, wg, None, 2, 1, 1)
+    assert y.dtype == BF and rel(y, yr) < EPS16
+    y.backward(dev16(gy, dev))
+    assert xg.grad.dtype == BF and rel(xg.grad, xr.grad) < EPS16
+    assert rel(F.to_nchw(wg.grad), wr.grad) < 5e-5
+
+
+@pytest.mark.parametrize("per_sample", [True, False, 2])
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(4, 64, 17, 19), (2, 256, 9, 9), (2, 2048, 5, 5), (2, 132, 8, 8)])
+def test_norm_act_bf16(per_sample, act, shape, dev, bf16_mode):
+    """InstanceNorm / BatchNorm (+ grouped) + activation + residual on bf16 tensors: statistics in fp64 from the bf16 values,
+    output / gradients rounded once to bf16."""
+    F = bf16_mode
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(shape, generator=g) * 2.0 + 0.5
+    res = torch.randn(shape, generator=g)
+    gy = torch.randn(shape, generator=g)
+    xr, rr = r16(x).requires_grad_(True), r16(res).requires_grad_(True)
+    n = shape[0]
+    if per_sample is True:
+        dims, xv = (2, 3), xr
+    elif per_sample is False:
+        dims, xv = (0, 2, 3), xr
+    else:
+        dims, xv = (1, 3, 4), xr.view(per_sample, n // per_sample, *shape[1:])
+    mu = xv.mean(dims, keepdim=True)
+    var = ((xv - mu) ** 2).mean(dims, keepdim=True)
+    yr = ((xv - mu) / torch.sqrt(var + 1e-5)).view(shape) + rr
+    yr = torch.relu(yr) if act == 1 else (TF.leaky_relu(yr, 0.2) if act == 2 else yr)
+    yr.backward(r16(gy))
+    xg, rg = dev16(x, dev).requires_grad_(True), dev16(res, dev).requires_grad_(True)
+    y = F.NormActFn.apply(xg, None, None, rg, None, None, per_sample, True, 0.0, 1e-5, act, 0.2)
+    assert y.dtype == BF and rel(y, yr) < EPS16
+    y.backward(dev16(gy, dev))
+    assert xg.grad.dtype == BF and rel(xg.grad, xr.grad) < 2 * EPS16
+    assert rel(rg.grad, rr.grad) < EPS16
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [
+    # (N, C, H, W, K, R, stride, pad, dil, groups) groups: "in" = per-sample, else BatchNorm groups
+    (2, 256, 64, 64, 256, 3, 1, 1, 1, "in"),       # ResnetGenerator block conv (L = 4096 rows per image)
+    (3, 64, 31, 31, 128, 4, 1, 1, 1, "in"),        # PatchGAN-like: L = 900, tiles straddle image boundaries
+    (8, 256, 33, 33, 256, 3, 1, 2, 2, 1),          # DeepLab layer3 conv2 + BatchNorm: 8712 rows, tail split-K rows
+    (16, 256, 33, 33, 256, 3, 1, 2, 2, 2),         # the stacked Gsi pass: two BatchNorm groups of 8712 rows
+    (4, 64, 65, 65, 256, 1, 1, 0, 1, 2),           # 1x1, group boundary inside a tile
+    (2, 3, 64, 64, 64, 7, 2, 3, 1, 1),             # stem (fp32 input in both modes)
+], ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_s%d_p%d_d%d_g%s" % c)
+def test_norm_statistics_fused_into_the_conv_epilogue(case, mode, dev):
+    """K3/K4: mean / rstd (+ running statistics) of the normalisation layer that follows come out of the conv's epilogue
+    (sscg_conv2d_fwd_stats + sscg_norm_stats_from_conv) and equal the statistics of the conv output."""
+    F = load_sub("functional")
+    n, c, h, w, k, r, s, p, d, groups = case
+    F.set_conv_precision(mode)
+    try:
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(n, c, h, w, generator=g) + 0.3
+        wt = torch.randn(k, c, r, r, generator=g) * (1.0 / (c * r * r) ** 0.5)
+        b = torch.randn(k, generator=g)
+        stem = c % 64 != 0
+        if mode == "bf16" and not stem:
+            xg, xr, wr = dev16(x, dev), r16(x), r16(wt)
+        elif mode == "bf16":
+            xg, xr, wr = dev32(x, dev), r16(x), r16(wt)     # fp32 tensor, bf16 contraction
+        else:
+            xg, xr, wr = dev32(x, dev), x.double(), wt.double()
+        yr = TF.conv2d(xr, wr, b.double(), s, p, d)
+        P, Q = yr.shape[2], yr.shape[3]
+        per = True if groups == "in" else (False if groups == 1 else groups)
+        G = n if groups == "in" else groups
+        yv = yr.view(G, n // G, k, P, Q) if groups != "in" else yr.view(n, 1, k, P, Q)
+        mu = yv.mean((1, 3, 4))
+        var = ((yv - mu.view(G, 1, k, 1, 1)) ** 2).mean((1, 3, 4))
+        rm = torch.zeros(k, device=dev) if groups != "in" else None
+        rv = torch.ones(k, device=dev) if groups != "in" else None
+        wparam = dev32(wt, dev)
+        y, mean, rstd = F.conv2d_norm_stats(xg, wparam, b.to(dev), s, p, d, F.PAD_ZEROS, (per, 1e-5, rm, rv, 0.1))
+        assert mean is not None, "the fusion must apply to this geometry"
+        tol = 2e-5
+        scale = float(mu.abs().max() + var.sqrt().max())       # the magnitude of the summed values, not of their mean
+        assert float((mean.double().cpu() - mu).abs().max()) < tol * scale
+        assert rel(rstd, 1.0 / torch.sqrt(var + 1e-5)) < tol
+        if groups != "in":
+            L = (n // G) * P * Q
+            erm, erv = torch.zeros(k, dtype=torch.float64), torch.ones(k, dtype=torch.float64)
+            for gi in range(G):
+                erm = 0.9 * erm + 0.1 * mu[gi]
+                erv = 0.9 * erv + 0.1 * var[gi] * L / (L - 1)
+            assert rel(rm, erm) < 1e-5 and rel(rv, erv) < 1e-5
+        # the unfused path computes the same thing from y
+        m2, r2 = F.norm_stats(y, per, 1e-5)
+        assert float((m2.double().cpu() - mu).abs().max()) < (EPS16 if y.dtype == BF else 2e-5) * scale
+    finally:
+        F.set_conv_precision("f32")
+
+
+def test_pointwise_bf16(dev, bf16_mode):
+    F = bf16_mode
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 64, 33, 65, generator=g)
+    xr = r16(x).requires_grad_(True)
+    yr = TF.max_pool2d(xr, 3, 2, 1, ceil_mode=True)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(r16(gy))
+    xg = dev16(x, dev).requires_grad_(True)
+    y = F.MaxPoolFn.apply(xg)
+    assert y.dtype == BF and rel(y, yr) == 0.0               # a max of bf16 values is one of them
+    y.backward(dev16(gy, dev))
+    assert rel(xg.grad, xr.grad) < EPS16
+    a, b = dev16(x, dev), dev16(x.flip(0) * 0.5, dev)
+    assert rel(F.add(a, b), r16(x) + r16(x.flip(0) * 0.5)) < EPS16
+    d1 = F.dropout(a, 0.5, 99)
+    keep = d1 != 0
+    assert abs(float(keep.float().mean()) - 0.5) < 0.01
+    assert torch.equal(d1[keep].float(), (a[keep].float() * 2.0).to(BF).float())
+    assert rel(F.act_fwd(a, 2, 0.2), TF.leaky_relu(r16(x), 0.2)) < EPS16
+    pr = TF.pad(r16(x), (3, 3, 3, 3), mode="reflect")
+    assert rel(F.reflect_pad(a, 3), pr) == 0.0
+    c32 = F.cast(a, torch.float32)
+    assert c32.dtype == torch.float32 and rel(c32, r16(x)) == 0.0
+
+
+def test_fused_adam_keeps_a_bf16_shadow(dev, bf16_mode):
+    """The Adam kernel rewrites a bf16 copy of the arena in the same pass: the conv operand copies never need a cast."""
+    F = bf16_mode
+    optim = load_sub("optim")
+    ops = load_sub("arch.ops")
+    conv = ops.Conv2d(64, 64, 3, 1, 1, bias=False).to(dev)
+    opt = optim.FusedAdam(conv.parameters(), lr=1e-2)
+    w16 = F.weight_bf16(conv.weight)
+    assert w16.dtype == BF and torch.equal(w16.float(), conv.weight.detach().to(BF).float())
+    before = w16.clone()
+    x = dev16(torch.randn(2, 64, 16, 16), dev)
+    y = conv(x)
+    assert y.dtype == BF
+    y.backward(dev16(torch.randn(2, 64, 16, 16), dev))
+    opt.step()
+    torch.cuda.synchronize()
+    w16b = F.weight_bf16(conv.weight)
+    assert w16b.data_ptr() == w16.data_ptr()                   # the same shadow memory, rewritten by the optimiser
+    assert torch.equal(w16b.float(), conv.weight.detach().to(BF).float()) and not torch.equal(w16b, before)
+    with torch.no_grad():
+        conv.weight.copy_(torch.zeros_like(conv.weight))       # torch writes the parameter (load_state_dict): slice re-cast
+    assert float(F.weight_bf16(conv.weight).float().abs().max()) == 0.0
+
+
+NETS16 = [("deeplab_3_21", "deeplab", (3, 21), (2, 3, 64, 64), 4e-2), ("deeplab_21_3", "deeplab", (21, 3), (2, 21, 64, 64), 4e-2),
+          ("resnet9_21_3", "resnet_9blocks", (21, 3), (2, 21, 32, 32), 3e-2), ("pixel_3", "pixel", (3,), (2, 3, 32, 32), 2e-2),
+          ("nlayers_3", "n_layers", (3,), (2, 3, 64, 64), 3e-2)]
+
+
+@pytest.mark.parametrize("net", NETS16, ids=lambda n: n[0])
+def test_networks_in_bf16_vs_fp64_golden(net, dev, bf16_mode):
+    """Whole networks with bf16 activations against the reference's fp64 goldens (tests/golden/g2_nets.npz).  Stated bf16
+    tolerance: rel-L2 of the output <= 2-4 % (101 layers of bf16 rounding in DeepLab; InstanceNorm nets are tighter)."""
+    import json
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "g2_nets.npz"))
+    arch = load_sub("arch")
+    name, kind, args, xshape, tol = net
+    if kind in ("deeplab", "resnet_9blocks"):
+        m = quiet(arch.define_Gen, args[0], args[1], 64, kind, norm="instance", use_dropout=False, gpu_ids=[dev.index or 0])
+    else:
+        m = quiet(arch.define_Dis, args[0], 64, kind, 3, norm="instance", gpu_ids=[dev.index or 0])
+    m.load_state_dict(FX.net_weights(name, kind, args), strict=True)
+    m.train()
+    x = FX.net_input(name, xshape).to(dev).requires_grad_(True)
+    y = m(x)
+    assert y.dtype == torch.float32                              # network heads stay fp32
+    y64 = torch.as_tensor(gold[name + "/y/f64"])
+    l2 = float((y.detach().double().cpu() - y64).norm() / y64.norm())
+    print("%s bf16 forward rel-L2 vs fp64 golden: %.3e" % (name, l2))
+    assert l2 < tol
+    gy = FX.net_grad_out(name, y.shape).to(dev)
+    F = bf16_mode
+    y.backward(F.to_nhwc(gy))
+    assert x.grad.dtype == torch.float32 and bool(torch.isfinite(x.grad).all())
+    dx64 = torch.as_tensor(gold[name + "/dx/f64"])
+    l2dx = float((x.grad.double().cpu() - dx64).norm() / dx64.norm())
+    print("%s bf16 input-gradient rel-L2 vs fp64 golden: %.3e" % (name, l2dx))
+    assert l2dx < (0.5 if kind == "deeplab" else 5 * tol)        # DeepLab dx: ReLU-mask flips (fp32 itself is 4-5 % off, App. D)
+
+
+def test_cityscapes_first_step_bf16_vs_fp64_oracle(dev, bf16_mode):
+    """BASELINE config 3's dataset geometry (Cityscapes, 20 classes, 1:2 crop) in bf16: first G+D step against the fp64
+    CPU oracle on the same keyed weights / inputs.  Stated bf16 tolerance: 3e-2 relative on the losses one DeepLab pass deep,
+    1e-1 on the three that chain two passes (the reference's own fp32 run is up to 1e-2 off fp64 there)."""
+    F = bf16_mode
+    md = load_sub("model")
+    C, H, Wd = 20, 64, 128
+    args = FX.make_args(dataset="cityscapes", crop_height=H, crop_width=Wd, batch_size=2, gpu_ids=[dev.index or 0],
+                        checkpoint_dir="/tmp/sscg_test_ckpt_bf16", as_written=True)
+    m = quiet(md.semisuper_cycleGAN, args)
+    tag = "ds_cityscapes"
+    for k, sd in FX.semisup_state_dicts(C, torch.float32, tag).items():
+        getattr(m, k).load_state_dict(sd, strict=True)
+    l_img, l_gt, unl_img = FX.step_batch(tag, 0, C, H, Wd, 2)
+    np.random.seed(0)
+    out = m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev))
+    got = {k: float(v) for k, v in out.items()}
+    np.random.seed(0)
+    o64 = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float64, tag), crop=(H, Wd))
+    r64 = o64.step(l_img.double(), l_gt, unl_img.double())
+    worst = 0.0
+    for k in ostep.LOSS_KEYS:
+        e = abs(got[k] - r64[k]) / abs(r64[k])
+        worst = max(worst, e)
+        print("%-20s bf16 %.6f oracle64 %.6f  rel %.2e" % (k, got[k], r64[k], e))
+        chained = k in ("img_cycle_loss", "gt_cycle_loss", "cycle_img_dis_loss")
+        assert e < (1e-1 if chained else 3e-2), k
+    # a second step runs on the updated bf16 shadow weights and stays finite
+    l_img, l_gt, unl_img = FX.step_batch(tag, 1, C, H, Wd, 2)
+    out2 = m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev))
+    assert all(bool(torch.isfinite(v)) for v in out2.values())
+    assert got["lab_loss_CE"] != float(out2["lab_loss_CE"])

@@ -493,8 +493,8 @@ def test_conv_bf16_contraction_mode(shape, F, dev):
     yr.backward(gyr)
     exact = TF.conv2d(x.double(), w.double(), None, s, p, d)
     try:
-        F.set_conv_precision("bf16")
-        assert F.get_conv_precision() == "bf16"
+        F.set_conv_precision("bf16c")
+        assert F.get_conv_precision() == "bf16c"
         xg, wg, gyg = gpu(x, dev), gpu(w, dev), gpu(gy, dev)
         y = F.conv2d_fwd(xg, wg, None, s, p, d)
         dx = F.conv2d_dgrad(gyg, F.weight_transposed(wg), xg.shape, wg.shape, s, p, d)

@@ -283,7 +283,7 @@ def test_bf16_contraction_step_stays_within_bf16_noise_of_the_reference(gold, de
     F = load_sub("functional")
     np.random.seed(0)
     try:
-        F.set_conv_precision("bf16")
+        F.set_conv_precision("bf16c")
         m, (C, H, Wd, B, steps) = _make_model("s64", dev)
         l_img, l_gt, unl_img = FX.step_batch("s64", 0, C, H, Wd, B)
         got = {k: float(v) for k, v in m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev)).items()}
