@@ -24,7 +24,15 @@ NETS = [
 STEP_CONFIGS = {  # tag -> (classes, dataset, H, W, batch, steps)
     "s64": (21, "voc2012", 64, 64, 2, 3),
     "s128": (21, "voc2012", 128, 128, 2, 1),
+    "s256": (21, "voc2012", 256, 256, 2, 1),     # the bench geometry at the reference's default batch
 }
+
+# teacher-forced DeepLab stages: every stage is fed the reference's own (fp32-rounded) stage input
+STAGE_NET = ("deeplab_3_21", "deeplab", (3, 21), (2, 3, 32, 32))
+STAGES = ("stem", "layer1", "layer2", "layer3", "layer4", "layer5")
+
+# per-epoch evaluation (model.py:555-574): Gsi.eval() -> interp -> softmax -> argmax -> runningScore
+EVAL_CONFIG = dict(tag="ev", C=21, dataset="voc2012", H=64, W=64, batches=2, B=2)
 
 
 def spec_for(kind, args):

@@ -143,6 +143,61 @@ def nlayer_dis_spec(in_c, ndf=64, n_layers=3, norm="instance"):
     return s
 
 
+# --------------------------------------------------------------------------- bf16 storage emulation (tests of the bf16 path)
+class _RoundBoth(torch.autograd.Function):
+    """An activation stored as bfloat16: the value is rounded on the way forward, its gradient on the way back."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """bf16 operand copy of an fp32 tensor (weights, network inputs): rounded forward, gradient untouched."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """fp32 network output whose gradient enters a bf16 contraction: identity forward, gradient rounded."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class Bf16Emulation:
+    """Rounding points of the MI355X build's bf16 mode: `a` = activation written to HBM as bf16
+    (conv outputs, normalise+activation outputs), `w` = conv weight operand, `i` = fp32 network input read by a bf16
+    contraction, `o` = fp32 head output.  The arithmetic between the rounding points stays in the dtype of the tensors (fp64
+    in the tests), so what is emulated is exactly the information bf16 storage discards."""
+    a = staticmethod(_RoundBoth.apply)
+    w = staticmethod(_RoundFwd.apply)
+    i = staticmethod(_RoundFwd.apply)
+    o = staticmethod(_RoundBwd.apply)
+
+
+class _NoRounding:
+    a = w = i = o = staticmethod(lambda t: t)
+
+
+_NOQ = _NoRounding()
+
+
 # --------------------------------------------------------------------------- building blocks
 def _bn_apply(sd, key, x, train):
     """nn.BatchNorm2d: batch statistics + running-stat EMA in train mode (running tensors updated in place)."""
@@ -159,68 +214,72 @@ def _norm(sd, key, x, norm, train):
     return _bn_apply(sd, key, x, train)
 
 
-def bottleneck(sd, p, x, stride, dil, train):
-    """Bottleneck.forward (arch/generators.py:345-365)."""
-    out = TF.conv2d(x, sd[p + ".conv1.weight"], None, stride)
-    out = torch.relu(_bn_apply(sd, p + ".bn1", out, train))
-    out = TF.conv2d(out, sd[p + ".conv2.weight"], None, 1, dil, dil)
-    out = torch.relu(_bn_apply(sd, p + ".bn2", out, train))
-    out = TF.conv2d(out, sd[p + ".conv3.weight"])
+def bottleneck(sd, p, x, stride, dil, train, q=_NOQ):
+    """Bottleneck.forward (arch/generators.py:345-365).  `q`: rounding points of a bf16 run (Bf16Emulation), default none."""
+    out = q.a(TF.conv2d(x, q.w(sd[p + ".conv1.weight"]), None, stride))
+    out = q.a(torch.relu(_bn_apply(sd, p + ".bn1", out, train)))
+    out = q.a(TF.conv2d(out, q.w(sd[p + ".conv2.weight"]), None, 1, dil, dil))
+    out = q.a(torch.relu(_bn_apply(sd, p + ".bn2", out, train)))
+    out = q.a(TF.conv2d(out, q.w(sd[p + ".conv3.weight"])))
     out = _bn_apply(sd, p + ".bn3", out, train)
     if (p + ".downsample.0.weight") in sd:
-        res = TF.conv2d(x, sd[p + ".downsample.0.weight"], None, stride)
-        res = _bn_apply(sd, p + ".downsample.1", res, train)
+        res = q.a(TF.conv2d(x, q.w(sd[p + ".downsample.0.weight"]), None, stride))
+        res = q.a(_bn_apply(sd, p + ".downsample.1", res, train))
     else:
         res = x
-    return torch.relu(out + res)
+    return q.a(torch.relu(out + res))
 
 
-def deeplab(sd, x, train=True, taps=None):
+def _deeplab_stem(sd, x, train, q):
+    y = q.a(TF.conv2d(q.i(x), q.w(sd["conv1.weight"]), None, 2, 3))
+    y = q.a(torch.relu(_bn_apply(sd, "bn1", y, train)))
+    return TF.max_pool2d(y, 3, 2, 1, ceil_mode=True)
+
+
+def _deeplab_head(sd, y, q):
+    out = q.o(TF.conv2d(y, q.w(sd["layer5.conv2d_list.0.weight"]), sd["layer5.conv2d_list.0.bias"], 1, 6, 6))
+    return out + q.o(TF.conv2d(y, q.w(sd["layer5.conv2d_list.1.weight"]), sd["layer5.conv2d_list.1.bias"], 1, 12, 12))
+
+
+def deeplab(sd, x, train=True, taps=None, q=_NOQ):
     """ResNet.forward (arch/generators.py:430-441) incl. the two-of-four classifier quirk (:378-382).
     `taps` (optional dict) receives the stage outputs for teacher-forced per-stage checks."""
-    y = TF.conv2d(x, sd["conv1.weight"], None, 2, 3)
-    y = torch.relu(_bn_apply(sd, "bn1", y, train))
-    y = TF.max_pool2d(y, 3, 2, 1, ceil_mode=True)
+    y = _deeplab_stem(sd, x, train, q)
     if taps is not None:
         taps["stem"] = y
     for li, (planes, blocks, stride, dil) in enumerate(DEEPLAB_LAYERS, start=1):
         for b in range(blocks):
-            y = bottleneck(sd, "layer%d.%d" % (li, b), y, stride if b == 0 else 1, dil, train)
+            y = bottleneck(sd, "layer%d.%d" % (li, b), y, stride if b == 0 else 1, dil, train, q)
         if taps is not None:
             taps["layer%d" % li] = y
-    out = TF.conv2d(y, sd["layer5.conv2d_list.0.weight"], sd["layer5.conv2d_list.0.bias"], 1, 6, 6)
-    out = out + TF.conv2d(y, sd["layer5.conv2d_list.1.weight"], sd["layer5.conv2d_list.1.bias"], 1, 12, 12)
-    return out
+    return _deeplab_head(sd, y, q)
 
 
-def deeplab_stage(sd, name, x, train=True):
+def deeplab_stage(sd, name, x, train=True, q=_NOQ):
     """One stage of `deeplab` on a given stage input (teacher forcing)."""
     if name == "stem":
-        y = TF.conv2d(x, sd["conv1.weight"], None, 2, 3)
-        y = torch.relu(_bn_apply(sd, "bn1", y, train))
-        return TF.max_pool2d(y, 3, 2, 1, ceil_mode=True)
+        return _deeplab_stem(sd, x, train, q)
     if name == "layer5":
-        out = TF.conv2d(x, sd["layer5.conv2d_list.0.weight"], sd["layer5.conv2d_list.0.bias"], 1, 6, 6)
-        return out + TF.conv2d(x, sd["layer5.conv2d_list.1.weight"], sd["layer5.conv2d_list.1.bias"], 1, 12, 12)
+        return _deeplab_head(sd, x, q)
     li = int(name[-1])
     planes, blocks, stride, dil = DEEPLAB_LAYERS[li - 1]
     y = x
     for b in range(blocks):
-        y = bottleneck(sd, "layer%d.%d" % (li, b), y, stride if b == 0 else 1, dil, train)
+        y = bottleneck(sd, "layer%d.%d" % (li, b), y, stride if b == 0 else 1, dil, train, q)
     return y
 
 
-def resnet_generator(sd, x, n_blocks=9, tanh=True, norm="instance", use_dropout=True, train=True, dropout_masks=None):
+def resnet_generator(sd, x, n_blocks=9, tanh=True, norm="instance", use_dropout=True, train=True, dropout_masks=None, q=_NOQ):
     """ResnetGenerator.forward (arch/generators.py:73-95) with ResidualBlock (arch/ops.py:59-74).
 
     Dropout(0.5) is active whenever use_dropout (the frozen generators are never put in eval mode,
     SURVEY App. A).  `dropout_masks` is a list of keep-masks (already scaled by 2) - one per block;
     None with use_dropout=True draws from torch's RNG like the reference."""
     def cnr(idx, y, stride, pad):
-        y = TF.conv2d(y, sd["res_model.%d.0.weight" % idx], sd.get("res_model.%d.0.bias" % idx), stride, pad)
-        return torch.relu(_norm(sd, "res_model.%d.1" % idx, y, norm, train))
+        y = q.a(TF.conv2d(y, q.w(sd["res_model.%d.0.weight" % idx]), sd.get("res_model.%d.0.bias" % idx), stride, pad))
+        return q.a(torch.relu(_norm(sd, "res_model.%d.1" % idx, y, norm, train)))
 
-    y = TF.pad(x, (3, 3, 3, 3), mode="reflect")
+    y = TF.pad(q.i(x), (3, 3, 3, 3), mode="reflect")
     y = cnr(1, y, 1, 0)
     y = cnr(2, y, 2, 1)
     y = cnr(3, y, 2, 1)
@@ -229,44 +288,44 @@ def resnet_generator(sd, x, n_blocks=9, tanh=True, norm="instance", use_dropout=
         i = 4 + b
         pre = "res_model.%d.res_block." % i
         h = TF.pad(y, (1, 1, 1, 1), mode="reflect")
-        h = TF.conv2d(h, sd[pre + "1.0.weight"], sd.get(pre + "1.0.bias"))
-        h = torch.relu(_norm(sd, pre + "1.1", h, norm, train))
+        h = q.a(TF.conv2d(h, q.w(sd[pre + "1.0.weight"]), sd.get(pre + "1.0.bias")))
+        h = q.a(torch.relu(_norm(sd, pre + "1.1", h, norm, train)))
         if use_dropout:
             if dropout_masks is not None:
                 h = h * dropout_masks[b]
             else:
                 h = TF.dropout(h, 0.5, True)
         h = TF.pad(h, (1, 1, 1, 1), mode="reflect")
-        h = TF.conv2d(h, sd[pre + "%d.weight" % second], sd.get(pre + "%d.bias" % second))
+        h = q.a(TF.conv2d(h, q.w(sd[pre + "%d.weight" % second]), sd.get(pre + "%d.bias" % second)))
         h = _norm(sd, pre + "%d" % (second + 1), h, norm, train)
-        y = y + h
+        y = q.a(y + h)
     t = 4 + n_blocks
     for idx in (t, t + 1):
-        y = TF.conv_transpose2d(y, sd["res_model.%d.0.weight" % idx], sd.get("res_model.%d.0.bias" % idx), 2, 1, 1)
-        y = torch.relu(_norm(sd, "res_model.%d.1" % idx, y, norm, train))
+        y = q.a(TF.conv_transpose2d(y, q.w(sd["res_model.%d.0.weight" % idx]), sd.get("res_model.%d.0.bias" % idx), 2, 1, 1))
+        y = q.a(torch.relu(_norm(sd, "res_model.%d.1" % idx, y, norm, train)))
     y = TF.pad(y, (3, 3, 3, 3), mode="reflect")
-    y = TF.conv2d(y, sd["res_model.%d.weight" % (t + 3)], sd["res_model.%d.bias" % (t + 3)])
+    y = q.o(TF.conv2d(y, q.w(sd["res_model.%d.weight" % (t + 3)]), sd["res_model.%d.bias" % (t + 3)]))
     return torch.tanh(y) if tanh else y
 
 
-def pixel_discriminator(sd, x, norm="instance", train=True):
+def pixel_discriminator(sd, x, norm="instance", train=True, q=_NOQ):
     """PixelDiscriminator.forward (arch/discriminators.py:66-80)."""
-    y = TF.leaky_relu(TF.conv2d(x, sd["dis_model.0.weight"], sd["dis_model.0.bias"]), 0.2)
-    y = TF.conv2d(y, sd["dis_model.2.weight"], sd.get("dis_model.2.bias"))
-    y = TF.leaky_relu(_norm(sd, "dis_model.3", y, norm, train), 0.2)
-    return TF.conv2d(y, sd["dis_model.5.weight"], sd.get("dis_model.5.bias"))
+    y = q.a(TF.leaky_relu(TF.conv2d(q.i(x), q.w(sd["dis_model.0.weight"]), sd["dis_model.0.bias"]), 0.2))
+    y = q.a(TF.conv2d(y, q.w(sd["dis_model.2.weight"]), sd.get("dis_model.2.bias")))
+    y = q.a(TF.leaky_relu(_norm(sd, "dis_model.3", y, norm, train), 0.2))
+    return q.o(TF.conv2d(y, q.w(sd["dis_model.5.weight"]), sd.get("dis_model.5.bias")))
 
 
-def nlayer_discriminator(sd, x, n_layers=3, norm="instance", train=True):
+def nlayer_discriminator(sd, x, n_layers=3, norm="instance", train=True, q=_NOQ):
     """NLayerDiscriminator.forward (arch/discriminators.py:42-63)."""
-    y = TF.leaky_relu(TF.conv2d(x, sd["dis_model.0.weight"], sd["dis_model.0.bias"], 2, 1), 0.2)
+    y = q.a(TF.leaky_relu(TF.conv2d(q.i(x), q.w(sd["dis_model.0.weight"]), sd["dis_model.0.bias"], 2, 1), 0.2))
     idx = 2
     for n in range(1, n_layers + 1):
         stride = 2 if n < n_layers else 1
-        y = TF.conv2d(y, sd["dis_model.%d.0.weight" % idx], sd.get("dis_model.%d.0.bias" % idx), stride, 1)
-        y = TF.leaky_relu(_norm(sd, "dis_model.%d.1" % idx, y, norm, train), 0.2)
+        y = q.a(TF.conv2d(y, q.w(sd["dis_model.%d.0.weight" % idx]), sd.get("dis_model.%d.0.bias" % idx), stride, 1))
+        y = q.a(TF.leaky_relu(_norm(sd, "dis_model.%d.1" % idx, y, norm, train), 0.2))
         idx += 1
-    return TF.conv2d(y, sd["dis_model.%d.weight" % idx], sd["dis_model.%d.bias" % idx], 1, 1)
+    return q.o(TF.conv2d(y, q.w(sd["dis_model.%d.weight" % idx]), sd["dis_model.%d.bias" % idx], 1, 1))
 
 
 # block-level restatements of arch/ops.py:40-57 (used by the block goldens)

@@ -77,8 +77,9 @@ class SemiSupOracle:
     """State + one step of the semi-supervised CycleGAN (model.py:203-311 ctor, :370-552 loop body)."""
 
     def __init__(self, n_classes, state_dicts, lr=2e-4, lab_CE_weight=1.0, lab_MSE_weight=1.0, adversarial_weight=1.0,
-                 discriminator_weight=1.0, lamda_gt=0.1, norm="instance", use_dropout=False, crop=(64, 64)):
+                 discriminator_weight=1.0, lamda_gt=0.1, norm="instance", use_dropout=False, crop=(64, 64), as_written=False):
         self.C = n_classes
+        self.as_written = as_written   # also run the reference's forwards whose outputs nothing reads (timing baseline only)
         self.sd = state_dicts  # dict: Gis, Gsi, Di, Ds, old_Gis, old_Gsi, old_Di -> flat state dicts (modified in place)
         self.w = dict(ce=lab_CE_weight, l1=lab_MSE_weight, adv=adversarial_weight, dis=discriminator_weight, gt=lamda_gt)
         self.norm = norm
@@ -123,7 +124,11 @@ class SemiSupOracle:
         with torch.no_grad():
             resnet_fake_gt = torch.softmax(self._old_g("old_Gsi", unl_img, False), 1)            # :418,421
             resnet_recon_img = self._old_g("old_Gis", resnet_fake_gt, True)                      # :422
-            # :419-420,423 (old_Gsi(l_img) -> old_Gis) feed nothing and hold no state: elided
+            # :419-420,423 (old_Gsi(l_img) -> old_Gis) feed nothing and hold no state: elided unless the CPU baseline asks
+            # for the step exactly as written (same work as the GPU headline); the results are dropped either way
+            if self.as_written:
+                resnet_lab_gt = torch.softmax(self._old_g("old_Gsi", l_img, False), 1)               # :419-420
+                self._old_g("old_Gis", resnet_lab_gt, True)                                          # :423
         fake_img_dis = self._dis("Di", fake_img)                                                 # :431
         resnet_fake_img_dis = self._dis("old_Di", recon_img)                                     # :432
         fake_gt_dis = self._dis("Ds", argmax_one_hot(fake_gt, C))                                # :435-438

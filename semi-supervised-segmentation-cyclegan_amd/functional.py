@@ -283,7 +283,7 @@ class ConvProfile:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, flops, key, e0, e1 in self.records:
+        for kind, flops, key, e0, e1 in self.records:      # kind = (fwd|dgrad|wgrad, kernel family f32|bf16)
             s = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0, "shapes": {}})
             ms = e0.elapsed_time(e1)
             s["launches"] += 1
@@ -306,7 +306,14 @@ def _timed(kind, d, fn):
     e1.record()
     flops = 2.0 * d.N * d.P * d.Q * d.K * d.R * d.S * d.C
     key = "%dx%dx%d c%d k%d r%d s%d p%d d%d" % (d.N, d.H, d.W, d.C, d.K, d.R, d.stride, d.pad, d.dil)
-    prof.records.append((kind, flops, key, e0, e1))
+    # which kernel family the library dispatches to (include/sscg.h, "Supported dtype combinations")
+    if kind == "fwd":
+        b16 = d.x_dtype == BF16 and d.w_dtype == BF16
+    elif kind == "dgrad":
+        b16 = d.y_dtype == BF16 and d.w_dtype == BF16
+    else:
+        b16 = d.x_dtype == BF16 and d.y_dtype == BF16 and d.K >= 32 and d.R * d.S * d.C >= 32
+    prof.records.append(((kind, "bf16" if b16 else "f32"), flops, key, e0, e1))
     return r
 
 

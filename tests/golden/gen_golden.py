@@ -27,8 +27,8 @@ sys.path.insert(0, REF)
 warnings.filterwarnings("ignore")
 
 from oracle import nets, step as ostep, weights as W  # noqa: E402
-from oracle.fixtures import (NETS, SEED, STEP_CONFIGS, make_args, oracle_forward, semisup_state_dicts, spec_for,  # noqa: E402
-                             synth_sample)
+from oracle.fixtures import (EVAL_CONFIG, NETS, SEED, STAGE_NET, STAGES, STEP_CONFIGS, make_args, oracle_forward,  # noqa: E402
+                             semisup_state_dicts, spec_for, synth_sample)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 THREADS = 8
@@ -249,6 +249,61 @@ def g2(meta):
     meta["g2"] = info
 
 
+def g2_stages(meta):
+    """Teacher-forced DeepLab stages: the reference net in fp64 is evaluated stage by stage, every stage on
+    the fp32 ROUNDING of the previous stage's output - the exact tensor a test can hand to the stage under test - so a stage's
+    golden output depends on nothing but that stage.  Stored: stage input (fp32) and stage output (fp64 rounded to fp32)."""
+    name, kind, args, xshape = STAGE_NET
+    ref = build_ref(kind, args).double()
+    ref.load_state_dict(W.fill_state_dict(spec_for(kind, args), SEED, torch.float64, prefix=name + "/"), strict=True)
+    ref.train()
+    d = {}
+    x = W.uniform(SEED, name + "/stage_x", xshape, -1.0, 1.0, dtype=torch.float32)
+    fns = {"stem": lambda t: ref.maxpool(ref.relu(ref.bn1(ref.conv1(t)))), "layer1": ref.layer1, "layer2": ref.layer2,
+           "layer3": ref.layer3, "layer4": ref.layer4, "layer5": ref.layer5}
+    osd = {k: v.clone() for k, v in ref.state_dict().items()}
+    with torch.no_grad():
+        for st in STAGES:
+            y = fns[st](x.double())
+            yo = nets.deeplab_stage({k: v.clone() for k, v in osd.items()}, st, x.double())
+            assert rel(yo, y) < 1e-9, (st, rel(yo, y))
+            d["%s/x" % st] = npf(x)
+            d["%s/y" % st] = npf(y.float())
+            x = y.float()
+    np.savez_compressed(os.path.join(OUT, "g2s_stages.npz"), **d)
+    meta["g2s"] = {"net": name, "input": list(xshape), "stages": {st: list(d[st + "/y"].shape) for st in STAGES}}
+
+
+def g5_eval(meta):
+    """The per-epoch evaluation of model.py:555-574 on the reference's own modules: Gsi.eval(), nn.Upsample(bilinear,
+    align_corners), Softmax2d, max(1)[1], utils.runningScore.  Stored: the predicted label maps (uint8) and the scores."""
+    import utils as rutils
+    c = EVAL_CONFIG
+    C, H, Wd = c["C"], c["H"], c["W"]
+    ref = build_ref("deeplab", (3, C))
+    ref.load_state_dict(semisup_state_dicts(C, torch.float32, c["tag"])["Gsi"], strict=True)
+    ref.eval()
+    interp = torch.nn.Upsample((H, Wd), mode="bilinear", align_corners=True)
+    softmax = torch.nn.Softmax2d()
+    rs = rutils.runningScore(C, c["dataset"])
+    preds, margins = [], []
+    with torch.no_grad():
+        for b in range(c["batches"]):
+            smp = [synth_sample(c["tag"] + "/val", b * c["B"] + i, C, H, Wd) for i in range(c["B"])]
+            val_img, val_gt = torch.stack([a for a, _ in smp]), torch.stack([g for _, g in smp])
+            outputs = softmax(interp(ref(val_img)))                      # model.py:561-563
+            pred = outputs.data.max(1)[1].cpu().numpy()                  # :566
+            gt = val_gt.squeeze().data.cpu().numpy()                     # :567
+            rs.update(gt, pred)                                          # :569
+            preds.append(pred.astype(np.uint8))
+            top2 = outputs.topk(2, 1)[0]
+            margins.append(npf(top2[:, 0] - top2[:, 1]))
+    score, class_iou = rs.get_scores()
+    np.savez_compressed(os.path.join(OUT, "g5_eval.npz"), pred=np.stack(preds), margin=np.stack(margins).astype(np.float32))
+    meta["g5_eval"] = {"config": c, "miou": float(score["Mean IoU : \t"]), "acc": float(score["Overall Acc: \t"]),
+                       "class_iou": {str(k): (None if np.isnan(v) else float(v)) for k, v in class_iou.items()}}
+
+
 # ------------------------------------------------------------------ G3/G4 training steps through the real model.py
 def run_reference_semisup(md, C, dataset, H, Wd, B, steps, tag):
     class Synth(torch.utils.data.Dataset):
@@ -394,6 +449,9 @@ def main():
     print("g1 done")
     g2(meta)
     print("g2 done")
+    g2_stages(meta)
+    g5_eval(meta)
+    print("g2 stages + g5 eval done")
     os.chdir("/tmp/gg")
     import model as md
     g3(meta, md)

@@ -119,3 +119,59 @@ def test_supervised_steps_fp64():
     loss = o.step(torch.stack([a for a, _ in smp]), torch.stack([g for _, g in smp]))
     assert abs(loss - META["g4"]["oracle_f64"][0]) / loss < 1e-9
     assert abs(loss - META["g4"]["reference_f32"][0]) / loss < 1e-4   # fp32 reference vs fp64 restatement, first step
+
+
+def test_deeplab_stages_teacher_forced_fp64():
+    """The stage goldens (g2s_stages.npz: the reference net in fp64, every stage on the fp32 rounding of the previous stage's
+    output) are reproduced by the restatement's `deeplab_stage`."""
+    g = np.load(os.path.join(GOLD, "g2s_stages.npz"))
+    name, kind, args, xshape = FX.STAGE_NET
+    sd = FX.net_weights(name, kind, args, torch.float64)
+    for st in FX.STAGES:
+        x = torch.from_numpy(g[st + "/x"]).double()
+        y = nets.deeplab_stage({k: v.clone() for k, v in sd.items()}, st, x)
+        assert rel(y, g[st + "/y"]) < 1e-6, st          # the golden is stored as fp32
+        assert list(y.shape) == META["g2s"]["stages"][st]
+
+
+def test_evaluation_golden_fp32():
+    """model.py:555-574 on the reference's modules (g5_eval.npz) vs the restatement: same label maps except where the
+    reference's own top-2 softmax margin is at fp32 rounding level, same mIoU."""
+    cfg = META["g5_eval"]["config"]
+    gold = np.load(os.path.join(GOLD, "g5_eval.npz"))
+    C, H, Wd = cfg["C"], cfg["H"], cfg["W"]
+    sd = FX.semisup_state_dicts(C, torch.float32, cfg["tag"])["Gsi"]
+    conf = np.zeros((C, C))
+    with torch.no_grad():
+        for b in range(cfg["batches"]):
+            smp = [FX.synth_sample(cfg["tag"] + "/val", b * cfg["B"] + i, C, H, Wd) for i in range(cfg["B"])]
+            img, gt = torch.stack([a for a, _ in smp]), torch.stack([g for _, g in smp])
+            out = torch.softmax(TF.interpolate(nets.deeplab(sd, img, train=False), size=(H, Wd), mode="bilinear", align_corners=True), 1)
+            pred = out.max(1)[1].numpy()
+            mism = pred != gold["pred"][b]
+            assert mism.mean() < 1e-3 and (not mism.any() or gold["margin"][b][mism].max() < 1e-4)
+            conf += ostep.confusion(gt.squeeze(1).numpy(), pred, C)
+    assert abs(ostep.running_score(conf, cfg["dataset"])[2] - META["g5_eval"]["miou"]) < 1e-4
+
+
+def test_bf16_emulation_rounds_where_the_build_stores_bf16():
+    """oracle.nets.Bf16Emulation (the checker of the bf16 path): activations are rounded forward AND their gradients backward,
+    weight operands forward only, head outputs backward only; without it the networks are untouched (bitwise)."""
+    q = nets.Bf16Emulation
+    x = torch.tensor([1.00390625, -3.1415926], dtype=torch.float64, requires_grad=True)     # 1 + 2^-8: not a bf16 value
+    y = q.a(x)
+    assert torch.equal(y.detach(), x.detach().to(torch.bfloat16).double()) and not torch.equal(y.detach(), x.detach())
+    y.backward(torch.tensor([1.00390625, 2.0], dtype=torch.float64))
+    assert torch.equal(x.grad, torch.tensor([1.00390625, 2.0]).to(torch.bfloat16).double())
+    x.grad = None
+    q.w(x).backward(torch.tensor([1.00390625, 2.0], dtype=torch.float64))
+    assert torch.equal(x.grad, torch.tensor([1.00390625, 2.0], dtype=torch.float64))
+    x.grad = None
+    z = q.o(x)
+    assert torch.equal(z.detach(), x.detach())
+    z.backward(torch.tensor([1.00390625, 2.0], dtype=torch.float64))
+    assert torch.equal(x.grad, torch.tensor([1.00390625, 2.0]).to(torch.bfloat16).double())
+    sd = FX.net_weights("pixel_3", "pixel", (3,), torch.float64)
+    xin = FX.net_input("pixel_3", (2, 3, 32, 32), torch.float64)
+    y0, y1 = nets.pixel_discriminator(sd, xin), nets.pixel_discriminator(sd, xin, q=q)
+    assert 1e-5 < rel(y1, y0) < 5e-2

@@ -195,9 +195,10 @@ def test_first_step_other_datasets_vs_live_oracle(cfg, dev):
         e = abs(got[k] - r64[k]) / abs(r64[k])
         print("%-20s hip %.6f oracle32 %.6f oracle64 %.6f  e64 %.1e noise %.1e" % (k, got[k], ref[k], r64[k], e, noise))
         chained = k in ("img_cycle_loss", "gt_cycle_loss", "cycle_img_dis_loss")
-        # chained = two DeepLab passes with discrete argmax/ReLU-mask flips in between: our error and the reference's own
-        # fp32 error are two draws from that noise, and a ratio above 4 between two such draws is common (tests/test_nets_gpu.py)
-        assert e < (max(8 * noise, 1e-3) if chained else 1e-3), k
+        # chained = two DeepLab passes with discrete argmax/ReLU-mask flips in between: SURVEY App. D.2, k = 4 times the
+        # oracle's own fp32-vs-fp64 distance, measured to the nearer of its two runs
+        e32 = abs(got[k] - ref[k]) / abs(ref[k])
+        assert (min(e, e32) < max(4 * noise, 1e-3)) if chained else (e < 1e-3), k
 
 
 def test_opt_in_nets_and_loss_variants(dev):
