@@ -18,6 +18,7 @@
 // registers (16-bit interleaves) and writes [channel][pixel] rows, after which the contraction loop is the forward's.
 #include "common.h"
 #include "sscg_internal.h"
+#include "reduce_common.h"
 
 namespace {
 
@@ -52,6 +53,7 @@ struct K16Params {
     // per-tile column statistics of the fp32 accumulators (fused norm statistics): [tiles_m][2][Ng][2] doubles or null
     double* __restrict__ stats;
     int stat_L;                      // rows per normalisation group (a tile spans at most two groups: stat_L >= BM)
+    double* __restrict__ xstats;     // host side: records of the split rows ([blocks][Ng][2]), written by the split reduction
 };
 
 __device__ __forceinline__ void store_out(void* dst, size_t idx, float v, int out_bf16) {
@@ -422,6 +424,8 @@ int launch16(const K16Params& p0, hipStream_t st) {
         const size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
         const size_t esz = p.out_bf16 ? 2 : 4;
         void* yt = reinterpret_cast<char*>(p.dst) + (size_t)p.m_tail0 * p.Ng * esz;
+        if (p.xstats)
+            return launch_split_reduce_stats(p.part, p.bias, yt, p.out_bf16, p.M - p.m_tail0, p.Ng, p.splits, p.act, p.slope, p.xstats, st);
         hipLaunchKernelGGL(k16_reduce_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, p.part, p.bias, yt, p.out_bf16, n, p.Ng,
                            p.splits, p.act, p.slope);
         SSCG_LAUNCH_CHECK();
@@ -484,7 +488,7 @@ size_t sscg_conv16_dgrad_workspace(const sscg_conv_desc* d) {
 }
 
 int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
-                    void* ws, size_t ws_bytes, hipStream_t st) {
+                    double* xstats, void* ws, size_t ws_bytes, hipStream_t st) {
     K16Params p = {};
     p.src = reinterpret_cast<const bf16*>(x); p.wgt = reinterpret_cast<const bf16*>(w); p.bias = bias; p.dst = y;
     p.out_bf16 = d->y_dtype == SSCG_BF16;
@@ -492,7 +496,7 @@ int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const
     p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope;
-    p.stats = stats; p.stat_L = (int)stat_L;
+    p.stats = stats; p.stat_L = (int)stat_L; p.xstats = xstats;
     dense_taps(p);
     K16Split sp = plan16(p.M, p.Ng, p.Ktot, stats ? stat_L : 0);
     if (sp.splits > 1 && (!ws || ws_bytes < split16_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;

@@ -25,6 +25,7 @@
 // boundaries (wave-uniform branch every Cs/BK tiles) and the per-tile loader work is a pointer bump.
 #include "common.h"
 #include "sscg_internal.h"
+#include "reduce_common.h"
 
 namespace {
 
@@ -69,6 +70,7 @@ struct KcParams {
     // fused normalisation statistics (see conv_bf16.hip): records [tile_m * WM + wave_row][2 groups][Ng][2] doubles, or null
     double* __restrict__ stats;
     int stat_L;
+    double* __restrict__ xstats;     // host side: records of the split rows, written by the split reduction ([blocks][Ng][2])
 };
 
 __device__ __forceinline__ void store_out(void* dst, size_t idx, float v, int out_bf16) {
@@ -676,6 +678,8 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     if (p.splits > 1) {
         size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
         void* yt = reinterpret_cast<char*>(p.dst) + (size_t)p.m_tail0 * p.Ng * (p.out_bf16 ? 2 : 4);
+        if (p.xstats)    // the split rows' column statistics come out of their reduction pass
+            return launch_split_reduce_stats(p.part, p.bias, yt, p.out_bf16, p.M - p.m_tail0, p.Ng, p.splits, p.act, p.slope, p.xstats, st);
         if (p.Ng % 4 == 0 && (((size_t)yt | (size_t)p.part) & 15) == 0)
             hipLaunchKernelGGL(kc_reduce_kernel<4>, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st, p.part, p.bias, yt, p.out_bf16, n,
                                p.Ng, p.splits, p.act, p.slope);
@@ -796,7 +800,7 @@ static bool fwd_stats_plan(const sscg_conv_desc* d, int G, long L, StatPlan* sp)
         sp->valid_tiles = splits > 1 ? ks.full_tiles / tiles_n : sp->tiles_m;
         sp->m_tail0 = splits > 1 ? ks.m_tail0 : M;
     }
-    sp->xrec = sp->m_tail0 < M ? sscg_colstats_records(M - sp->m_tail0, d->K, d->y_dtype) : 0;
+    sp->xrec = sp->m_tail0 < M ? split_stats_records(M - sp->m_tail0) : 0;
     sp->xgroup = sp->m_tail0 < M ? (int)(sp->m_tail0 / L) : -1;
     sp->main_bytes = (size_t)sp->tiles_m * sp->wm * 2 * d->K * 2 * sizeof(double);
     sp->bytes = sp->main_bytes + (size_t)sp->xrec * d->K * 2 * sizeof(double);
@@ -816,11 +820,11 @@ extern "C" size_t sscg_conv2d_fwd_stats_workspace(const sscg_conv_desc* d) {
 }
 
 static int conv_fwd_impl(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
-                         void* ws, size_t ws_bytes, void* stream) {
+                         double* xstats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return SSCG_ERR_BAD_ARG;
-    if (sscg_conv16_fwd_applies(d)) return sscg_conv16_fwd(d, x, w, bias, y, stats, stat_L, ws, ws_bytes, (hipStream_t)stream);
+    if (sscg_conv16_fwd_applies(d)) return sscg_conv16_fwd(d, x, w, bias, y, stats, stat_L, xstats, ws, ws_bytes, (hipStream_t)stream);
     if (d->x_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return SSCG_ERR_UNSUPPORTED;
     KcParams p = {};
     p.src = reinterpret_cast<const float*>(x); p.wgt = reinterpret_cast<const float*>(w); p.bias = bias; p.dst = y;
@@ -829,7 +833,7 @@ static int conv_fwd_impl(const sscg_conv_desc* d, const void* x, const void* w, 
     p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope; p.tiles_n = 0; p.tiles = 0;
-    p.stats = stats; p.stat_L = (int)stat_L;
+    p.stats = stats; p.stat_L = (int)stat_L; p.xstats = xstats;
     kc_dense_taps(p);
     KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs, stats ? stat_L : 0);
     if (sp.splits > 1 && (!ws || ws_bytes < kc_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
@@ -840,7 +844,7 @@ static int conv_fwd_impl(const sscg_conv_desc* d, const void* x, const void* w, 
 
 extern "C" int sscg_conv2d_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias,
                                void* y, void* ws, size_t ws_bytes, void* stream) {
-    return conv_fwd_impl(d, x, w, bias, y, nullptr, 0, ws, ws_bytes, stream);
+    return conv_fwd_impl(d, x, w, bias, y, nullptr, 0, nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" int sscg_conv2d_fwd_stats(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int G,
@@ -850,15 +854,9 @@ extern "C" int sscg_conv2d_fwd_stats(const sscg_conv_desc* d, const void* x, con
     StatPlan sp;
     if (!fwd_stats_plan(d, G, (long)L, &sp)) return SSCG_ERR_UNSUPPORTED;
     if (!stats || stats_bytes < sp.bytes) return SSCG_ERR_WORKSPACE;
-    rc = conv_fwd_impl(d, x, w, bias, y, reinterpret_cast<double*>(stats), (long)L, ws, ws_bytes, stream);
-    if (rc) return rc;
-    if (sp.xrec > 0) {   // rows that went through split-K: summed from the finished output (a few % of the tensor)
-        const size_t esz = d->y_dtype == SSCG_BF16 ? 2 : 4;
-        const long M = (long)d->N * d->P * d->Q;
-        rc = sscg_colstats_launch(reinterpret_cast<const char*>(y) + (size_t)sp.m_tail0 * d->K * esz, d->y_dtype, M - sp.m_tail0, d->K,
-                                  reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + sp.main_bytes), (hipStream_t)stream);
-    }
-    return rc;
+    // rows that went through split-K: their statistics are produced by the split reduction itself (records after the main ones)
+    double* xr = sp.xrec > 0 ? reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + sp.main_bytes) : nullptr;
+    return conv_fwd_impl(d, x, w, bias, y, reinterpret_cast<double*>(stats), (long)L, xr, ws, ws_bytes, stream);
 }
 
 extern "C" int sscg_norm_stats_from_conv(const sscg_conv_desc* d, const void* stats, int G, int64_t L, float eps, float* mean,

@@ -417,8 +417,7 @@ inline int ew_grid(size_t total) {
 // ---- second stage of the statistics a convolution epilogue left behind (conv_igemm.hip / conv_bf16.hip):
 // records [rec][2 slots][C][2] doubles, rec = tile_m * RPT + wave_row; slot 0 = rows of the tile's first group
 // (group of row tile_m * BMT), slot 1 = rows of the next group; plus `xrec` records [xrec][C][2] of the rows that went
-// through split-K (all in group `xgroup`).  A block owns 64 channels; its 8 waves stride the records and are combined
-// through LDS in a fixed order (deterministic).
+// through split-K (all in group `xgroup`).  Record lanes are combined through LDS in a fixed order (deterministic).
 struct ConvStatParams {
     const double* __restrict__ rec;
     const double* __restrict__ xrecs;
@@ -434,38 +433,40 @@ struct ConvStatParams {
     float eps, momentum;
 };
 
-__global__ __launch_bounds__(512) void finalize_conv_stats_kernel(ConvStatParams p) {
-    __shared__ double sm[8][64][2];
-    const int cl = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+// block = 256 threads = 16 channels x 16 record lanes (a 16-channel row segment of a record is 256 contiguous bytes);
+// grid (C / 16, G or 1): enough blocks to keep the latency of this serial link (conv -> statistics -> normalise) short.
+__global__ __launch_bounds__(256) void finalize_conv_stats_kernel(ConvStatParams p) {
+    __shared__ double sm[16][16][2];
+    const int cl = threadIdx.x & 15;
+    const int w = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     const bool cok = c < p.C;
     const int g0 = p.rmean ? 0 : blockIdx.y;
     const int g1 = p.rmean ? p.G : blockIdx.y + 1;
     for (int g = g0; g < g1; ++g) {
         const long lo = (long)g * p.L, hi = lo + p.L;
-        int t_first = (int)((lo + p.BMT - 1) / p.BMT);
+        const int t_first = (int)((lo + p.BMT - 1) / p.BMT);
         int t_last = (int)((hi + p.BMT - 1) / p.BMT) - 1;
         if (t_last > p.valid_tiles - 1) t_last = p.valid_tiles - 1;
         double s = 0.0, q = 0.0;
         if (cok) {
             const int n0 = (t_last - t_first + 1) * p.RPT;          // slot-0 records of the tiles that start inside the group
-            for (int k = w; k < n0; k += 8) {
+            for (int k = w; k < n0; k += 16) {
                 const size_t r = (size_t)t_first * p.RPT + k;
-                const double* e = p.rec + ((r * 2 + 0) * p.C + c) * 2;
-                s += e[0]; q += e[1];
+                const double2 e = *reinterpret_cast<const double2*>(p.rec + ((r * 2 + 0) * p.C + c) * 2);
+                s += e.x; q += e.y;
             }
-            if (g > 0 && t_first - 1 < p.valid_tiles && t_first >= 1) {  // slot 1 of the tile that straddles the lower boundary
-                for (int k = w; k < p.RPT; k += 8) {
+            if (g > 0 && t_first >= 1 && t_first - 1 < p.valid_tiles) {  // slot 1 of the tile that straddles the lower boundary
+                for (int k = w; k < p.RPT; k += 16) {
                     const size_t r = (size_t)(t_first - 1) * p.RPT + k;
-                    const double* e = p.rec + ((r * 2 + 1) * p.C + c) * 2;
-                    s += e[0]; q += e[1];
+                    const double2 e = *reinterpret_cast<const double2*>(p.rec + ((r * 2 + 1) * p.C + c) * 2);
+                    s += e.x; q += e.y;
                 }
             }
             if (p.xrec > 0 && p.xgroup == g) {
-                for (int k = w; k < p.xrec; k += 8) {
-                    const double* e = p.xrecs + ((size_t)k * p.C + c) * 2;
-                    s += e[0]; q += e[1];
+                for (int k = w; k < p.xrec; k += 16) {
+                    const double2 e = *reinterpret_cast<const double2*>(p.xrecs + ((size_t)k * p.C + c) * 2);
+                    s += e.x; q += e.y;
                 }
             }
         }
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(512) void finalize_conv_stats_kernel(ConvStatParams
         if (w == 0 && cok) {
             double a = 0.0, b = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { a += sm[k][cl][0]; b += sm[k][cl][1]; }
+            for (int k = 0; k < 16; ++k) { a += sm[k][cl][0]; b += sm[k][cl][1]; }
             const int i = g * p.C + c;
             const double m = a / (double)p.L;
             double var = b / (double)p.L - m * m;
@@ -530,15 +531,6 @@ extern "C" int sscg_norm_stats(const void* x, int dtype, int G, int64_t L, int C
     return SSCG_OK;
 }
 
-// Column (sum, sum of squares) partials of `rows` rows in the record layout finalize_conv_stats_kernel's `xrecs` expects.
-int sscg_colstats_records(long rows, int C, int dtype) { return plan_reduce(1, rows, C, dtype).chunks; }
-
-int sscg_colstats_launch(const void* x, int dtype, long rows, int C, double* part, hipStream_t st) {
-    RedParams p = {};
-    p.x = x; p.part = part; p.L = rows; p.C = C;
-    return launch_reduce<RM_STATS>(p, 1, dtype, st);
-}
-
 int sscg_finalize_conv_stats(const double* stats, int valid_tiles, int rows_per_tile, int records_per_tile, const double* xrecs,
                              int xrec, int xgroup, int G, long L, int C, float eps, float* mean, float* rstd, float* running_mean,
                              float* running_var, float momentum, hipStream_t st) {
@@ -546,7 +538,7 @@ int sscg_finalize_conv_stats(const double* stats, int valid_tiles, int rows_per_
     p.rec = stats; p.xrecs = xrecs; p.mean = mean; p.rstd = rstd; p.rmean = running_mean; p.rvar = running_var;
     p.valid_tiles = valid_tiles; p.BMT = rows_per_tile; p.RPT = records_per_tile; p.xrec = xrec; p.xgroup = xgroup;
     p.G = G; p.C = C; p.L = L; p.eps = eps; p.momentum = momentum;
-    hipLaunchKernelGGL(finalize_conv_stats_kernel, dim3(cdiv(C, 64), running_mean ? 1 : G), dim3(512), 0, st, p);
+    hipLaunchKernelGGL(finalize_conv_stats_kernel, dim3(cdiv(C, 16), running_mean ? 1 : G), dim3(256), 0, st, p);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

@@ -11,7 +11,7 @@ bool sscg_conv16_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* w
 size_t sscg_conv16_fwd_workspace(const sscg_conv_desc* d, long stat_L);
 size_t sscg_conv16_dgrad_workspace(const sscg_conv_desc* d);
 int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
-                    void* ws, size_t ws_bytes, hipStream_t st);
+                    double* xstats, void* ws, size_t ws_bytes, hipStream_t st);
 int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
                       void* ws, size_t ws_bytes, hipStream_t st);
 bool sscg_wgrad16_applies(const sscg_conv_desc* d);
@@ -20,9 +20,7 @@ int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* 
 // conv_wgrad.hip: dw = beta * dw + sum_s ws[s] (fixed order)
 int sscg_wgrad_reduce(const float* ws, float* dw, size_t n, int splits, float beta, hipStream_t st);
 // norm.hip: the statistics a conv epilogue left behind -> mean / rstd (+ running statistics); the rows that went through
-// split-K are summed by sscg_colstats_launch into `xrec` extra records
-int sscg_colstats_records(long rows, int C, int dtype);
-int sscg_colstats_launch(const void* x, int dtype, long rows, int C, double* part, hipStream_t st);
+// split-K arrive as `xrec` extra records written by the split reduction (reduce_common.h)
 int sscg_finalize_conv_stats(const double* stats, int valid_tiles, int rows_per_tile, int records_per_tile, const double* xrecs,
                              int xrec, int xgroup, int G, long L, int C, float eps, float* mean, float* rstd, float* running_mean,
                              float* running_var, float momentum, hipStream_t st);

@@ -6,6 +6,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import ROOT, load_sub
@@ -117,3 +118,51 @@ def test_synthetic_loader_contract():
     assert len(names) == 2
     again = list(d.SyntheticLoader(2, 21, 40, 48, 3, seed=1))[0]
     assert torch.equal(again[0], img) and torch.equal(again[1], gt)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/arch"), reason="needs the reference checkout (build container only)")
+def test_checkpoints_interchange_with_the_reference_modules(tmp_path):
+    """a checkpoint written by the REFERENCE (its own modules' state_dict through its utils.save_checkpoint
+    format, model.py:646-655) loads into this build's networks with strict=True, and a checkpoint written by this build loads
+    into the reference's modules - for the DeepLab generators and the pixel / PatchGAN discriminators.  Runs where
+    /root/reference exists (the build container); no tensor arithmetic, so no GPU is needed."""
+    import importlib
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch, warnings
+warnings.filterwarnings("ignore")
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+import arch
+torch.manual_seed(7)
+nets = {"Gis": arch.define_Gen(21, 3, 64, "deeplab", "instance", True, []), "Gsi": arch.define_Gen(3, 21, 64, "deeplab", "instance", True, []),
+        "Di": arch.define_Dis(3, 64, "pixel", 3, "instance", []), "Ds": arch.define_Dis(21, 64, "n_layers", 3, "instance", []),
+        "old": arch.define_Gen(21, 3, 64, "resnet_9blocks", "instance", True, [])}
+if sys.argv[1] == "save":
+    torch.save({"epoch": 3, "best_iou": 0.5, **{k: v.state_dict() for k, v in nets.items()}}, sys.argv[2])
+else:
+    ck = torch.load(sys.argv[2], map_location="cpu")
+    for k, v in nets.items():
+        v.load_state_dict(ck[k], strict=True)
+    print("reference loaded", sorted(ck))
+'''
+    ref_ck, our_ck = str(tmp_path / "ref.ckpt"), str(tmp_path / "ours.ckpt")
+    subprocess.run([sys.executable, "-c", code, "save", ref_ck], check=True, capture_output=True)
+    arch = load_sub("arch")
+    utils = load_sub("utils")
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        ours = {"Gis": arch.define_Gen(21, 3, 64, "deeplab", "instance", True, []), "Gsi": arch.define_Gen(3, 21, 64, "deeplab", "instance", True, []),
+                "Di": arch.define_Dis(3, 64, "pixel", 3, "instance", []), "Ds": arch.define_Dis(21, 64, "n_layers", 3, "instance", []),
+                "old": arch.define_Gen(21, 3, 64, "resnet_9blocks", "instance", True, [])}
+        ck = utils.load_checkpoint(ref_ck)
+    assert ck["epoch"] == 3
+    for k, net in ours.items():
+        net.load_state_dict(ck[k], strict=True)                      # the reference's keys and shapes, nothing missing or extra
+        for name, t in net.state_dict().items():
+            assert torch.equal(t.cpu().contiguous(), ck[k][name].contiguous()), (k, name)
+    utils.save_checkpoint({"epoch": 4, "best_iou": 0.6, **{k: v.state_dict() for k, v in ours.items()}}, our_ck)
+    out = subprocess.run([sys.executable, "-c", code, "load", our_ck], check=True, capture_output=True, text=True).stdout
+    assert "reference loaded" in out

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Step-by-step health check of a bench configuration: losses and non-finite counts of the gradient / weight arenas per step.
+usage: python tools/diag_step.py --config 3 --batch 16 --steps 6 [--dtype bf16]"""
+import argparse
+import contextlib
+import importlib
+import io
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+PKG = bench.PKG
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", type=int, default=3)
+ap.add_argument("--batch", type=int, default=None)
+ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--dtype", default=None)
+ap.add_argument("--no-overlap", action="store_true")
+a = ap.parse_args()
+cfg = bench.CONFIGS[a.config]
+dtype = a.dtype or cfg["dtype"]
+bsz = a.batch or cfg["B"]
+md = importlib.import_module(PKG + ".model")
+F = importlib.import_module(PKG + ".functional")
+data = importlib.import_module(PKG + ".data")
+import main as cli  # noqa: E402
+args = cli.get_args(["--model", "semisupervised_cycleGAN", "--dataset", cfg["dataset"], "--crop_height", str(cfg["H"]), "--crop_width", str(cfg["W"]),
+                     "--batch_size", str(bsz), "--checkpoint_dir", "/tmp/sscg_diag_ckpt", "--dtype", dtype])
+args.gpu_ids, args.as_written, args.overlap_d = [0], True, not a.no_overlap
+torch.cuda.set_device(0)
+torch.manual_seed(0)
+F.set_conv_precision(dtype)
+with contextlib.redirect_stdout(io.StringIO()):
+    m = md.semisuper_cycleGAN(args)
+dev = torch.device("cuda", 0)
+lab = list(data.SyntheticLoader(bsz, cfg["C"], cfg["H"], cfg["W"], a.steps, 1, device=dev))
+unl = list(data.SyntheticLoader(bsz, cfg["C"], cfg["H"], cfg["W"], a.steps, 2, device=dev))
+
+
+def bad(t):
+    return int((~torch.isfinite(t)).sum())
+
+
+for s in range(a.steps):
+    out = m.step(lab[s][0], lab[s][1], unl[s][0])
+    m.sync_losses()
+    torch.cuda.synchronize()
+    vals = {k: float(v) for k, v in out.items()}
+    print("step %d  " % s + "  ".join("%s=%.4g" % (k[:14], v) for k, v in vals.items()))
+    print("        non-finite: G.grad %d  D.grad %d  G.w %d  D.w %d  | max|G.grad| %.3g  max|G.w| %.3g  max|D.w| %.3g" % (
+        bad(m.g_optimizer.grad), bad(m.d_optimizer.grad), bad(m.g_optimizer.arena), bad(m.d_optimizer.arena),
+        float(m.g_optimizer.grad.abs().max()), float(m.g_optimizer.arena.abs().max()), float(m.d_optimizer.arena.abs().max())))
+    sys.stdout.flush()
+print("peak memory %.1f GB" % (torch.cuda.max_memory_allocated() / 2 ** 30))
