@@ -65,6 +65,7 @@ template <int MODE, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
+    constexpr bool STAGE_OUT = BN >= 64;      // the narrow head tile writes fp32 / few channels: direct stores
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int PA = BM / 32;           // 32 rows per loader pass (8 lanes x 16 B per row)
     constexpr int PB = BN / 32;
@@ -193,27 +194,33 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
     set_tap(f_tap < p.R * p.S ? f_tap : 0);
     f_k += f_chunk * BK;
 
-    auto load_tile = [&]() {
+    // The copy of one k-tile = PA + PB LDS-DMA pieces per wave (1 KB each: this wave's 8 rows of a 32-row pass).  A piece costs
+    // ~100 issue cycles (address select, M0, the request); issued in one burst ahead of the MFMAs they would cost the wave
+    // more issue time than the 16 MFMAs of the tile take, so they are dealt out between the four MFMA groups instead.
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds0 = (lds_char*)smem_raw;
+    const int lds_wave = __builtin_amdgcn_readfirstlane(wave_id * 1024);      // byte offset of this wave's rows inside a pass (SGPR)
+    constexpr int NPIECE = PA + PB;
+    auto tile_begin = [&]() {
         if (f_chunk == f_nchunk) {       // wave-uniform: next tap
             f_chunk = 0;
             ++f_tap;
             set_tap(f_tap < p.R * p.S ? f_tap : 0);
         }
-        const int coff = f_chunk * BK;
-        bf16* la = As + dma_buf * BM * BK + wave_id * 512;       // wave w stages rows 8w .. 8w+7 of every 32-row pass
-        bf16* lb = Bs + dma_buf * BN * BK + wave_id * 512;
-#pragma unroll
-        for (int ps = 0; ps < PA; ++ps) {
-            const bf16* g = ((f_okbits >> ps) & 1u) ? aptr[ps] + coff : zero;
+    };
+    auto piece = [&](int q) {
+        if (q < PA) {
+            const bf16* g = ((f_okbits >> q) & 1u) ? aptr[q] + f_chunk * BK : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(la + ps * 2048), 16, 0, 0);
-        }
-#pragma unroll
-        for (int ps = 0; ps < PB; ++ps) {
+                                             (__attribute__((address_space(3))) void*)(lds0 + dma_buf * (BM * BK * 2) + lds_wave + q * 4096), 16, 0, 0);
+        } else {
+            const int ps = q - PA;
             const bf16* g = bok[ps] ? brow[ps] + f_k : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(lb + ps * 2048), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds0 + 2 * BM * BK * 2 + dma_buf * (BN * BK * 2) + lds_wave + ps * 4096), 16, 0, 0);
         }
+    };
+    auto tile_end = [&]() {
         dma_buf ^= 1;
         ++f_chunk;
         f_k += BK;
@@ -236,7 +243,12 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = kt1 - kt0;
-    if (nk > 0) load_tile();
+    if (nk > 0) {
+        tile_begin();
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) piece(q);
+        tile_end();
+    }
     __syncthreads();
     const int sw = swz(li);                    // rows row_w + i*32 + li: (row >> 1) & 7 == (li >> 1) & 7
     for (int kt = 0; kt < nk; ++kt) {
@@ -253,14 +265,25 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[kk][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * BK + off);
         }
-        if (kt + 1 < nk) load_tile();          // the copies of tile kt+1 land under the MFMAs below
+        const bool more = kt + 1 < nk;
+        if (more) tile_begin();
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 4; ++kk) {
+            // pieces kk, kk + 4, ... of the next tile go out ahead of MFMA group kk and land under the groups that follow
+            if (more) {
+#pragma unroll
+                for (int q = kk; q < NPIECE; q += 4) piece(q);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);      // keep this interleave: pieces and MFMAs stay in their groups
+        }
+        if (more) tile_end();
+        // every MFMA of the tile is in front of the barrier's `s_waitcnt vmcnt(0)` (left alone, the scheduler sinks 15 of the 16
+        // behind the wait and the copies get no cover at all)
         __syncthreads();
     }
 
@@ -273,6 +296,77 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
     if (want_stats) {
         const int g0 = m0 / p.stat_L;
         gb = (g0 + 1) * p.stat_L;
+    }
+    // bf16 results leave through LDS: in the MFMA layout a lane owns single elements of 16 x TM x TN different rows - 64 two-byte
+    // stores per lane and tile, each wave-instruction touching 2 x 64 B.  Staged as an fp32 [BM][BN + 4] tile (the k-loop is
+    // over, its images are dead), every thread then writes 16 bytes = 8 consecutive channels: 8x fewer, full-width stores.
+    const bool staged = STAGE_OUT && !partial && p.out_bf16;
+    auto put_stats = [&](int n, bool nok, double s0, double q0, double s1, double q1) {
+        // the two lane halves hold different rows of the same column
+        s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+        if (lh == 0 && nok) {
+            // record (tile_m, wm): [ (tile_m * WM + wm) ][2 groups][Ng][2]
+            double* rec = p.stats + ((size_t)(tile_m * WM + wm) * 2) * p.Ng * 2;
+            rec[(size_t)n * 2] = s0; rec[(size_t)n * 2 + 1] = q0;
+            rec[((size_t)p.Ng + n) * 2] = s1; rec[((size_t)p.Ng + n) * 2 + 1] = q1;
+        }
+    };
+    if (staged) {
+        constexpr int OLD = BN + 4;
+        float* ot = reinterpret_cast<float*>(smem_raw);
+        float* ob = ot + (row_w + 4 * lh) * OLD + col_w + li;        // this lane's corner; every element is a constant offset away
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + col_w + j * 32 + li;
+            const bool nok = n < p.Ng;
+            const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+            double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
+                    const int m = m0 + row_w + 4 * lh + ro;
+                    const float pre = acc[i][j][e] + bv;
+                    if (want_stats && m < p.M) {
+                        const double d = (double)pre;
+                        if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
+                    }
+                    ob[ro * OLD + j * 32] = sscg_act(pre, p.act, p.slope);
+                }
+            }
+            if (want_stats) put_stats(n, nok, s0, q0, s1, q1);
+        }
+        __syncthreads();
+        constexpr int TPR = BN / 8;             // threads per output row (8 channels = 16 bytes each)
+        constexpr int RPP = 256 / TPR;          // rows per pass
+        const int c8 = (tid % TPR) * 8;
+        const int n = n0 + c8;
+        bf16* out = reinterpret_cast<bf16*>(p.dst);
+        const float* src = ot + (tid / TPR) * OLD + c8;
+#pragma unroll
+        for (int ps = 0; ps < BM / RPP; ++ps) {
+            const int m = m0 + tid / TPR + ps * RPP;
+            if (m >= p.M || n >= p.Ng) continue;
+            size_t row = (size_t)m;
+            if (p.o_step != 1) {
+                const int img = m / (p.OH * p.OW);
+                const int rem = m - img * (p.OH * p.OW);
+                const int oi = rem / p.OW;
+                const int oj = rem - oi * p.OW;
+                row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+            }
+            float v[8];
+            ld4<float>(src + ps * RPP * OLD, v);
+            ld4<float>(src + ps * RPP * OLD + 4, v + 4);
+            if (n + 8 <= p.Ng) {
+                st8<bf16>(out + row * p.Ng + n, v);
+            } else {
+                for (int e = 0; e < 8 && n + e < p.Ng; ++e) out[row * p.Ng + n + e] = (bf16)v[e];
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -307,17 +401,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
                 }
             }
         }
-        if (want_stats) {
-            // the two lane halves hold different rows of the same column
-            s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
-            s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-            if (lh == 0 && nok) {
-                // record (tile_m, wm): [ (tile_m * WM + wm) ][2 groups][Ng][2]
-                double* rec = p.stats + ((size_t)(tile_m * WM + wm) * 2) * p.Ng * 2;
-                rec[(size_t)n * 2] = s0; rec[(size_t)n * 2 + 1] = q0;
-                rec[((size_t)p.Ng + n) * 2] = s1; rec[((size_t)p.Ng + n) * 2 + 1] = q1;
-            }
-        }
+        if (want_stats) put_stats(n, nok, s0, q0, s1, q1);
     }
 }
 
@@ -410,7 +494,9 @@ int launch16(const K16Params& p0, hipStream_t st) {
     p.tiles_n = cdiv(p.Ng, BN);
     const int tiles_m = cdiv(p.M, BM);
     p.tiles = tiles_m * p.tiles_n;
-    const size_t smem = (size_t)(2 * BM * BK + 2 * BN * BK) * sizeof(bf16) + (size_t)(p.R * p.S > 0 ? p.R * p.S : 1) * 8;
+    size_t smem = (size_t)(2 * BM * BK + 2 * BN * BK) * sizeof(bf16) + (size_t)(p.R * p.S > 0 ? p.R * p.S : 1) * 8;
+    const size_t stage = BN >= 64 ? (size_t)BM * (BN + 4) * sizeof(float) : 0;      // output tile of the staged epilogue
+    if (stage > smem) smem = stage;
     auto kern = conv16_kernel<MODE, WM, WN, TM, TN>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -634,17 +720,20 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wg16Params p) {
     }
 
     U4 stage[8];
+    unsigned okbits = 0;     // validity of the eight staged rows; applied at LDS-store time, so that the loaded registers are not
+                             // touched (= not waited for) until the MFMAs of the current tile have been issued
     auto load_tile = [&](int pt) {
         if (!active) return;
         const int pix0 = pt + pb * 8;
+        okbits = 0;
         if (isA) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int pix = pix0 + j;
                 const bool ok = col_ok && pix < p_end;
+                okbits |= ok ? (1u << j) : 0u;
                 const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)(ok ? pix : 0) * p.Kc);
-                stage[j].v[0] = ok ? v.x : 0u; stage[j].v[1] = ok ? v.y : 0u;
-                stage[j].v[2] = ok ? v.z : 0u; stage[j].v[3] = ok ? v.w : 0u;
+                stage[j].v[0] = v.x; stage[j].v[1] = v.y; stage[j].v[2] = v.z; stage[j].v[3] = v.w;
             }
         } else {
             // decode the first pixel, then walk (ox, oy, img) incrementally
@@ -665,17 +754,29 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wg16Params p) {
                 sy = reflect ? ry : sy;
                 sx = reflect ? rx : sx;
                 ok = ok && ((unsigned)sy < (unsigned)p.H) && ((unsigned)sx < (unsigned)p.W);
+                okbits |= ok ? (1u << j) : 0u;
                 const size_t off = ok ? (size_t)((img * p.H + sy) * p.W + sx) * p.C : 0;
                 const uint4 v = *reinterpret_cast<const uint4*>(base + off);
-                stage[j].v[0] = ok ? v.x : 0u; stage[j].v[1] = ok ? v.y : 0u;
-                stage[j].v[2] = ok ? v.z : 0u; stage[j].v[3] = ok ? v.w : 0u;
+                stage[j].v[0] = v.x; stage[j].v[1] = v.y; stage[j].v[2] = v.z; stage[j].v[3] = v.w;
+                // next pixel, branch-free (a branch here splits the loads over basic blocks and the compiler then waits for each)
                 ++ox;
-                if (ox == p.Q) { ox = 0; ++oy; if (oy == p.P) { oy = 0; ++img; } }
+                const bool wx = ox == p.Q;
+                ox = wx ? 0 : ox;
+                oy += wx ? 1 : 0;
+                const bool wy = oy == p.P;
+                oy = wy ? 0 : oy;
+                img += wy ? 1 : 0;
             }
         }
     };
     auto store_tile = [&](int buf) {
         if (!active) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = (okbits >> j) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stage[j].v[e] = ok ? stage[j].v[e] : 0u;
+        }
         U4 out[8];
         transpose_8x8(stage, out);
         bf16* img = isA ? As + buf * BM * BKP : Bs + buf * BN * BKP;
@@ -730,6 +831,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wg16Params p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);      // MFMAs first, then the transpose + LDS stores of the next tile, then the barrier
         if (it + 1 < nsteps) store_tile(buf ^ 1);
         __syncthreads();
     }

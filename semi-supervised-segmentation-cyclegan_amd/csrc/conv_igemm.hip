@@ -463,6 +463,9 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
         }
         if (NBUF == 1) __syncthreads();      // single LDS image: every wave is done reading before it is overwritten
         if (kt + 1 < nk) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
+        // keep every MFMA of this k-tile in front of the barrier's `s_waitcnt vmcnt(0)`: the copies of the next tile land under
+        // them (left alone, the scheduler sinks part of the MFMA block behind the wait)
+        if constexpr (DMA) __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
 
@@ -800,7 +803,7 @@ static bool fwd_stats_plan(const sscg_conv_desc* d, int G, long L, StatPlan* sp)
         sp->valid_tiles = splits > 1 ? ks.full_tiles / tiles_n : sp->tiles_m;
         sp->m_tail0 = splits > 1 ? ks.m_tail0 : M;
     }
-    sp->xrec = sp->m_tail0 < M ? split_stats_records(M - sp->m_tail0) : 0;
+    sp->xrec = sp->m_tail0 < M ? split_stats_records(M - sp->m_tail0, d->K) : 0;
     sp->xgroup = sp->m_tail0 < M ? (int)(sp->m_tail0 / L) : -1;
     sp->main_bytes = (size_t)sp->tiles_m * sp->wm * 2 * d->K * 2 * sizeof(double);
     sp->bytes = sp->main_bytes + (size_t)sp->xrec * d->K * 2 * sizeof(double);

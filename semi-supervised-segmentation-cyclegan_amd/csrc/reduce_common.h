@@ -77,23 +77,34 @@ __global__ __launch_bounds__(256) void split_reduce_stats_kernel(const float* __
     }
 }
 
-constexpr int SPLIT_STATS_ROWS = 32;     // rows per statistics record of the split rows
+// Rows per block (= per statistics record) of the split reduction: one row per row-lane, at least 4.  The split rows are
+// a few hundred to a thousand; the reduction sits on the critical path of its layer (conv -> statistics -> normalise), so
+// it is spread over >= 100 workgroups rather than kept compact.
+static inline int split_stats_rpb(int Ng) {
+    const int cgs = Ng % 4 == 0 ? Ng / 4 : Ng;
+    const int lanes = 256 / (cgs < 256 ? cgs : 256);
+    return lanes > 4 ? lanes : 4;
+}
 
-static inline int split_stats_records(long rows) { return (int)((rows + SPLIT_STATS_ROWS - 1) / SPLIT_STATS_ROWS); }
+static inline int split_stats_records(long rows, int Ng) {
+    const int rpb = split_stats_rpb(Ng);
+    return (int)((rows + rpb - 1) / rpb);
+}
 
 static inline int launch_split_reduce_stats(const float* part, const float* bias, void* y, int out_bf16, long rows, int Ng, int splits,
                                             int act, float slope, double* recs, hipStream_t st) {
-    const bool v4 = Ng % 4 == 0 && (((size_t)y | (size_t)part) & 15) == 0;
+    const bool v4 = Ng % 4 == 0;      // (y and part are 16-byte aligned: allocator granularity, and m_tail0 * Ng * 4 bytes with Ng % 4 == 0)
     const int cgs = v4 ? Ng / 4 : Ng;
     const int cg_blk = cgs < 256 ? cgs : 256;
-    dim3 grid(split_stats_records(rows), (cgs + cg_blk - 1) / cg_blk);
+    const int rpb = split_stats_rpb(Ng);
+    dim3 grid(split_stats_records(rows, Ng), (cgs + cg_blk - 1) / cg_blk);
     const size_t smem = (size_t)256 * (v4 ? 4 : 1) * 2 * sizeof(double);
     if (v4)
         hipLaunchKernelGGL(split_reduce_stats_kernel<4>, grid, dim3(256), smem, st, part, bias, y, out_bf16, (int)rows, Ng, splits, act,
-                           slope, recs, SPLIT_STATS_ROWS);
+                           slope, recs, rpb);
     else
         hipLaunchKernelGGL(split_reduce_stats_kernel<1>, grid, dim3(256), smem, st, part, bias, y, out_bf16, (int)rows, Ng, splits, act,
-                           slope, recs, SPLIT_STATS_ROWS);
+                           slope, recs, rpb);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

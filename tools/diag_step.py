@@ -21,6 +21,7 @@ ap.add_argument("--batch", type=int, default=None)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--dtype", default=None)
 ap.add_argument("--no-overlap", action="store_true")
+ap.add_argument("--no-sync", action="store_true", help="no host synchronisation between steps (the bench's schedule)")
 a = ap.parse_args()
 cfg = bench.CONFIGS[a.config]
 dtype = a.dtype or cfg["dtype"]
@@ -48,6 +49,8 @@ def bad(t):
 
 for s in range(a.steps):
     out = m.step(lab[s][0], lab[s][1], unl[s][0])
+    if a.no_sync and s + 1 < a.steps:
+        continue
     m.sync_losses()
     torch.cuda.synchronize()
     vals = {k: float(v) for k, v in out.items()}
