@@ -418,11 +418,15 @@ __global__ __launch_bounds__(256) void k16_reduce_kernel(const float* __restrict
 }
 
 // ---- host-side plan
+}  // namespace
+extern int sscg_force_conv_cfg;      // conv_igemm.hip: sscg_debug_set_conv_cfg(100 + cfg) forces a bf16 tile class (tuning hook)
+namespace {
 enum { CFG_128x128 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_128x64 = 3 };
 const int C16_BM[4] = {128, 64, 128, 128};
 const int C16_BN[4] = {128, 64, 32, 64};
 
 int choose16(long M, int Ng) {
+    if (sscg_force_conv_cfg >= 100 && sscg_force_conv_cfg < 104 && Ng > 32) return sscg_force_conv_cfg - 100;   // tuning hook
     if (Ng <= 32) return CFG_128x32;
     const long t128 = (long)cdiv(M, 128) * cdiv(Ng, 128);
     if (Ng >= 128 && t128 >= 384) return CFG_128x128;
@@ -466,7 +470,10 @@ K16Split plan16_raw(long M, int Ng, int Ktot) {
         r.full_tiles = 0; r.m_tail0 = 0;
         return r;
     }
-    if (cfg != CFG_64x64 || nk < 8 || tiles > 2300) return r;
+    // 64x64 and 128x128 launches: only the TAIL beyond the last whole round of 256 workgroups is cut along K (8712 rows x 256
+    // channels = 548 tiles of 64x64; 34320 rows = 538 tiles of 128x128: 512 run whole, two per CU side by side, the other
+    // 26 would keep a tenth of the chip busy for a whole tile time)
+    if ((cfg != CFG_64x64 && cfg != CFG_128x128) || nk < 8 || tiles > 2300) return r;
     const int q = tiles / 256;
     const int full_m = (q * 256) / tiles_n;
     const int tail = tiles - full_m * tiles_n;
@@ -657,12 +664,13 @@ struct Wg16Params {
 // 8 pixels x 8 channels (eight 16-byte rows, channel pairs packed in words) -> 8 channels x 8 pixels (eight 16-byte rows)
 struct U4 { uint32_t v[4]; };
 __device__ __forceinline__ void transpose_8x8(const U4 r[8], U4 out[8]) {
+    // v_perm_b32 D, S0, S1, sel: byte i of D = byte sel[i] of the 8-byte value {S0 (bytes 4-7), S1 (bytes 0-3)}
 #pragma unroll
     for (int w = 0; w < 4; ++w) {          // word w of a row = channels 2w (low half), 2w+1 (high half)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {   // pixel pair (2jj, 2jj+1)
-            out[2 * w].v[jj] = (r[2 * jj].v[w] & 0xffffu) | (r[2 * jj + 1].v[w] << 16);
-            out[2 * w + 1].v[jj] = (r[2 * jj].v[w] >> 16) | (r[2 * jj + 1].v[w] & 0xffff0000u);
+            out[2 * w].v[jj] = __builtin_amdgcn_perm(r[2 * jj + 1].v[w], r[2 * jj].v[w], 0x05040100u);       // (odd.lo << 16) | even.lo
+            out[2 * w + 1].v[jj] = __builtin_amdgcn_perm(r[2 * jj + 1].v[w], r[2 * jj].v[w], 0x07060302u);   // (odd.hi << 16) | even.hi
         }
     }
 }
@@ -720,19 +728,19 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wg16Params p) {
     }
 
     U4 stage[8];
-    unsigned okbits = 0;     // validity of the eight staged rows; applied at LDS-store time, so that the loaded registers are not
-                             // touched (= not waited for) until the MFMAs of the current tile have been issued
+    // masked rows (past the pixel range, padding) read a page of zeros: the staged registers need no select afterwards and are
+    // not touched (= not waited for) until the MFMAs of the current tile have been issued
+    const bf16* const zero16 = reinterpret_cast<const bf16*>(sscg_zero_page16);
     auto load_tile = [&](int pt) {
         if (!active) return;
         const int pix0 = pt + pb * 8;
-        okbits = 0;
         if (isA) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int pix = pix0 + j;
                 const bool ok = col_ok && pix < p_end;
-                okbits |= ok ? (1u << j) : 0u;
-                const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)(ok ? pix : 0) * p.Kc);
+                const bf16* src = ok ? base + (size_t)pix * p.Kc : zero16;
+                const uint4 v = *reinterpret_cast<const uint4*>(src);
                 stage[j].v[0] = v.x; stage[j].v[1] = v.y; stage[j].v[2] = v.z; stage[j].v[3] = v.w;
             }
         } else {
@@ -753,10 +761,9 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wg16Params p) {
                 rx = rx >= p.W ? 2 * (p.W - 1) - rx : rx;
                 sy = reflect ? ry : sy;
                 sx = reflect ? rx : sx;
-                ok = ok && ((unsigned)sy < (unsigned)p.H) && ((unsigned)sx < (unsigned)p.W);
-                okbits |= ok ? (1u << j) : 0u;
-                const size_t off = ok ? (size_t)((img * p.H + sy) * p.W + sx) * p.C : 0;
-                const uint4 v = *reinterpret_cast<const uint4*>(base + off);
+                ok = ok & ((unsigned)sy < (unsigned)p.H) & ((unsigned)sx < (unsigned)p.W);
+                const bf16* src = ok ? base + (size_t)((img * p.H + sy) * p.W + sx) * p.C : zero16;
+                const uint4 v = *reinterpret_cast<const uint4*>(src);
                 stage[j].v[0] = v.x; stage[j].v[1] = v.y; stage[j].v[2] = v.z; stage[j].v[3] = v.w;
                 // next pixel, branch-free (a branch here splits the loads over basic blocks and the compiler then waits for each)
                 ++ox;
@@ -771,12 +778,6 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wg16Params p) {
     };
     auto store_tile = [&](int buf) {
         if (!active) return;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool ok = (okbits >> j) & 1u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) stage[j].v[e] = ok ? stage[j].v[e] : 0u;
-        }
         U4 out[8];
         transpose_8x8(stage, out);
         bf16* img = isA ? As + buf * BM * BKP : Bs + buf * BN * BKP;

@@ -580,11 +580,13 @@ __global__ __launch_bounds__(256) void kc_reduce_kernel(const float* __restrict_
 // channel count is a multiple of BK stage through LDS-DMA (cfg 6/7).
 static const int KC_BM[9] = {128, 128, 64, 64, 128, 128, 64, 128, 256};
 static const int KC_BN[9] = {128, 64, 128, 64, 32, 128, 64, 128, 32};
-int sscg_force_conv_cfg = -1;    // test/tuning hooks (sscg_debug_set_conv_cfg)
+}  // namespace
+int sscg_force_conv_cfg = -1;    // test/tuning hooks (sscg_debug_set_conv_cfg); also read by conv_bf16.hip (values >= 100)
+namespace {
 int sscg_force_conv_split = 0;
 
 static int kc_choose_cfg(int M, int Ng, int Ktot, int Cs) {
-    if (sscg_force_conv_cfg >= 0) return sscg_force_conv_cfg;
+    if (sscg_force_conv_cfg >= 0 && sscg_force_conv_cfg < 100) return sscg_force_conv_cfg;
     const bool fast = Cs % BK == 0;
     if (Ng <= 4 && fast) return 8;
     if (Ng <= 32) return 4;
@@ -740,7 +742,7 @@ static void kc_dense_taps(KcParams& p) {
 
 // stride-2 data gradients are decomposed into parity classes when the vectorised tap walk applies (K % BK == 0)
 static bool dgrad_by_parity(const sscg_conv_desc* d) {
-    return sscg_force_conv_cfg < 0 && d->stride == 2 && d->dil == 1 && d->pad_mode == 0 && d->K % BK == 0;
+    return (sscg_force_conv_cfg < 0 || sscg_force_conv_cfg >= 100) && d->stride == 2 && d->dil == 1 && d->pad_mode == 0 && d->K % BK == 0;
 }
 
 static bool dt_ok(int dt) { return dt == SSCG_F32 || dt == SSCG_BF16; }
@@ -780,7 +782,7 @@ struct StatPlan { int tiles_m, bm, wm, valid_tiles, xrec, xgroup; long m_tail0; 
 
 static bool fwd_stats_plan(const sscg_conv_desc* d, int G, long L, StatPlan* sp) {
     const long M = (long)d->N * d->P * d->Q;
-    if (G <= 0 || L <= 0 || (long)G * L != M || d->act != SSCG_ACT_NONE || d->K <= 32) return false;
+    if (G <= 0 || L <= 0 || (long)G * L != M || d->act != SSCG_ACT_NONE || d->K <= 32) return false;   // (thin 1x1 shapes keep the matrix-core path when statistics are asked for)
     int splits;
     if (sscg_conv16_fwd_applies(d)) {
         int full_tiles, m_tail0, tiles_n;
@@ -827,6 +829,7 @@ static int conv_fwd_impl(const sscg_conv_desc* d, const void* x, const void* w, 
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return SSCG_ERR_BAD_ARG;
+    if (!stats && sscg_thin1x1_fwd_applies(d)) return sscg_thin1x1_fwd(d, x, w, bias, y, (hipStream_t)stream);
     if (sscg_conv16_fwd_applies(d)) return sscg_conv16_fwd(d, x, w, bias, y, stats, stat_L, xstats, ws, ws_bytes, (hipStream_t)stream);
     if (d->x_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return SSCG_ERR_UNSUPPORTED;
     KcParams p = {};
@@ -886,6 +889,7 @@ extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const void* dy, const 
     if (rc) return rc;
     if (!dy || !wt || !dx) return SSCG_ERR_BAD_ARG;
     if (d->pad_mode != 0) return SSCG_ERR_UNSUPPORTED;
+    if (sscg_thin1x1_dgrad_applies(d, bias, act)) return sscg_thin1x1_dgrad(d, dy, wt, dx, (hipStream_t)stream);
     if (sscg_conv16_dgrad_applies(d)) return sscg_conv16_dgrad(d, dy, wt, bias, dx, act, slope, ws, ws_bytes, (hipStream_t)stream);
     if (d->y_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return SSCG_ERR_UNSUPPORTED;
     KcParams p = {};

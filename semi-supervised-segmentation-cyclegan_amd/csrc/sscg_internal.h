@@ -17,6 +17,11 @@ int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, c
 bool sscg_wgrad16_applies(const sscg_conv_desc* d);
 size_t sscg_wgrad16_workspace(const sscg_conv_desc* d);
 int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_thin.hip: HBM-streaming kernels for 1x1 convolutions with a handful of channels on one side (PixelDiscriminator ends)
+bool sscg_thin1x1_fwd_applies(const sscg_conv_desc* d);
+int sscg_thin1x1_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, hipStream_t st);
+bool sscg_thin1x1_dgrad_applies(const sscg_conv_desc* d, const float* bias, int act);
+int sscg_thin1x1_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, void* dx, hipStream_t st);
 // conv_wgrad.hip: dw = beta * dw + sum_s ws[s] (fixed order)
 int sscg_wgrad_reduce(const float* ws, float* dw, size_t n, int splits, float beta, hipStream_t st);
 // norm.hip: the statistics a conv epilogue left behind -> mean / rstd (+ running statistics); the rows that went through

@@ -137,6 +137,7 @@ class semisuper_cycleGAN(object):
         resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch)
         dev = l_img.device
         fork = F.SideStream.enabled and self.fork_forward
+        self._wait_operand_copies(torch.cuda.current_stream(dev))
         if fork:
             # Two lanes: Gis(onehot) -> Gsi(fake_img) on the fork stream, Gsi(unl) -> Gsi(l_img) -> Gis(fake_gt) here.
             # The reference's order of BN running-stat updates (Gis: :385 before :408; Gsi: :386, :387 before :410) is kept
@@ -225,13 +226,19 @@ class semisuper_cycleGAN(object):
             g_works = self.dp.sync_grads_async(self.g_optimizer)     # overlaps the D step; the update is applied below
         else:
             self.g_optimizer.step()                                                  # :474
-            # the transposed weight copies the next step's data gradients read: rebuilt beside the discriminator step
+            # the transposed weight copies the next step's data gradients read: rebuilt beside the discriminator step.  The
+            # list holds the discriminators' copies too (stale since the previous D update): every stream that reads a copy
+            # - the discriminator step below, the next step's lanes - first waits for this event.
             F.run_on_side_stream(l_img.device, (), F.refresh_transposed_weights)
+            if F.SideStream.enabled:
+                self._copies_ready = torch.cuda.Event()
+                self._copies_ready.record(F.SideStream.get(dev, 0))
 
         # ---- discriminators (model.py:477-542)
         if self.overlap_d:
             main_s, d_s = torch.cuda.current_stream(dev), F.d_stream(dev)
             d_s.wait_stream(main_s)
+            self._wait_operand_copies(d_s)
             for t in (recon_img, fake_img, fake_gt, unl_img, onehot_gt, resnet_recon_img):
                 t.record_stream(d_s)
             with torch.cuda.stream(d_s):
@@ -240,6 +247,7 @@ class semisuper_cycleGAN(object):
                 self.dp.wait(g_works)
                 self.g_optimizer.step()                                              # :474 (deferred past the all-reduce)
         else:
+            self._wait_operand_copies(torch.cuda.current_stream(dev))
             d_vals = self._d_step(a, recon_img, fake_img, fake_gt, unl_img, onehot_gt, resnet_recon_img)
             if self.dp is not None:
                 self.dp.wait(g_works)
@@ -248,6 +256,12 @@ class semisuper_cycleGAN(object):
         out = {k: v.detach() for k, v in zip(LOSS_KEYS, vals)}
         out.update({k: v.detach() for k, v in extras.items()})
         return out
+
+    def _wait_operand_copies(self, stream):
+        """Order `stream` behind the side lane that rebuilt the transposed / bf16 operand copies of the weights."""
+        ev = getattr(self, "_copies_ready", None)
+        if ev is not None:
+            stream.wait_event(ev)
 
     def sync_losses(self):
         """Make the current stream wait for the discriminator stream (overlap_d): call before reading a step's losses."""
