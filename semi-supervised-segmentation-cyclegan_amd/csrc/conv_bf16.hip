@@ -54,6 +54,7 @@ struct K16Params {
     double* __restrict__ stats;
     int stat_L;                      // rows per normalisation group (a tile spans at most two groups: stat_L >= BM)
     double* __restrict__ xstats;     // host side: records of the split rows ([blocks][Ng][2]), written by the split reduction
+    int dma_first;                   // tuning: 1 = all pieces of the next tile go out ahead of MFMA group 0
 };
 
 __device__ __forceinline__ void store_out(void* dst, size_t idx, float v, int out_bf16) {
@@ -271,8 +272,15 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
         for (int kk = 0; kk < 4; ++kk) {
             // pieces kk, kk + 4, ... of the next tile go out ahead of MFMA group kk and land under the groups that follow
             if (more) {
+                if (p.dma_first) {
+                    if (kk == 0) {
 #pragma unroll
-                for (int q = kk; q < NPIECE; q += 4) piece(q);
+                        for (int q = 0; q < NPIECE; ++q) piece(q);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = kk; q < NPIECE; q += 4) piece(q);
+                }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -420,15 +428,20 @@ __global__ __launch_bounds__(256) void k16_reduce_kernel(const float* __restrict
 // ---- host-side plan
 }  // namespace
 extern int sscg_force_conv_cfg;      // conv_igemm.hip: sscg_debug_set_conv_cfg(100 + cfg) forces a bf16 tile class (tuning hook)
+extern int sscg_tune_flags;          // bit 0: spread the LDS-DMA pieces of the next tile over the four MFMA groups (default: all ahead of group 0)
 namespace {
 enum { CFG_128x128 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_128x64 = 3 };
 const int C16_BM[4] = {128, 64, 128, 128};
 const int C16_BN[4] = {128, 64, 32, 64};
 
-int choose16(long M, int Ng) {
+// Measured on the step's shapes (tools/conv16_bench.py, profiles/r02_conv16_shapes.txt): 128x128 wins wherever the k-loop is long
+// (3x3 on 256/512 channels: 840 TF/s); a short k-loop (Ktot <= 1024: the 1x1 bottleneck ends, the PixelDiscriminator) is
+// dominated by its epilogue and runs 10-20 % faster on 128x64 tiles, which put twice as many stores in flight.
+int choose16(long M, int Ng, int Ktot) {
     if (sscg_force_conv_cfg >= 100 && sscg_force_conv_cfg < 104 && Ng > 32) return sscg_force_conv_cfg - 100;   // tuning hook
     if (Ng <= 32) return CFG_128x32;
     const long t128 = (long)cdiv(M, 128) * cdiv(Ng, 128);
+    if (Ktot <= 1024 && Ng <= 1024 && cdiv(M, 128) * cdiv(Ng, 64) >= 384) return CFG_128x64;
     if (Ng >= 128 && t128 >= 384) return CFG_128x128;
     if (Ng <= 64 && cdiv(M, 128) >= 384) return CFG_128x64;
     return CFG_64x64;
@@ -445,7 +458,7 @@ K16Split plan16_raw(long M, int Ng, int Ktot);
 K16Split plan16(long M, int Ng, int Ktot, long stat_L = 0) {
     K16Split r = plan16_raw(M, Ng, Ktot);
     if (stat_L > 0 && r.splits > 1 && (r.full_tiles == 0 || r.m_tail0 / stat_L != (M - 1) / stat_L)) {
-        const int cfg = choose16(M, Ng);
+        const int cfg = choose16(M, Ng, Ktot);
         r.splits = 1; r.ksplit = Ktot / BK;
         r.full_tiles = cdiv(M, C16_BM[cfg]) * cdiv(Ng, C16_BN[cfg]); r.m_tail0 = (int)M;
     }
@@ -454,7 +467,7 @@ K16Split plan16(long M, int Ng, int Ktot, long stat_L = 0) {
 
 K16Split plan16_raw(long M, int Ng, int Ktot) {
     const int nk = Ktot / BK;
-    const int cfg = choose16(M, Ng);
+    const int cfg = choose16(M, Ng, Ktot);
     const int bm = C16_BM[cfg], bn = C16_BN[cfg];
     const int tiles_m = cdiv(M, bm), tiles_n = cdiv(Ng, bn);
     const int tiles = tiles_m * tiles_n;
@@ -510,6 +523,7 @@ int launch16(const K16Params& p0, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
     }
     if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
+    p.dma_first = !(sscg_tune_flags & 1);
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
     SSCG_LAUNCH_CHECK();
@@ -528,7 +542,7 @@ int launch16(const K16Params& p0, hipStream_t st) {
 
 template <int MODE>
 int dispatch16(const K16Params& p, hipStream_t st) {
-    switch (choose16(p.M, p.Ng)) {
+    switch (choose16(p.M, p.Ng, p.Ktot)) {
         case CFG_128x128: return launch16<MODE, 2, 2, 2, 2>(p, st);
         case CFG_64x64: return launch16<MODE, 2, 2, 1, 1>(p, st);
         case CFG_128x32: return launch16<MODE, 4, 1, 1, 1>(p, st);
@@ -559,7 +573,7 @@ bool sscg_conv16_dgrad_applies(const sscg_conv_desc* d) {
 // geometry of the statistics records of a forward launch (records = [tiles_m * wm][2 groups][K][2] doubles)
 bool sscg_conv16_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* wm, int* tiles_n, int* splits, int* full_tiles, int* m_tail0) {
     const long M = (long)d->N * d->P * d->Q;
-    const int cfg = choose16(M, d->K);
+    const int cfg = choose16(M, d->K, d->R * d->S * d->C);
     if (cfg == CFG_128x32 || L < C16_BM[cfg]) return false;
     *bm = C16_BM[cfg];
     *wm = 2;

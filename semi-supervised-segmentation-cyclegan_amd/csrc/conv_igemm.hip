@@ -582,6 +582,7 @@ static const int KC_BM[9] = {128, 128, 64, 64, 128, 128, 64, 128, 256};
 static const int KC_BN[9] = {128, 64, 128, 64, 32, 128, 64, 128, 32};
 }  // namespace
 int sscg_force_conv_cfg = -1;    // test/tuning hooks (sscg_debug_set_conv_cfg); also read by conv_bf16.hip (values >= 100)
+int sscg_tune_flags = 0;         // bits 16..23 of sscg_debug_set_conv_cfg: kernel-variant switches for tools/conv16_bench.py
 namespace {
 int sscg_force_conv_split = 0;
 
@@ -727,9 +728,10 @@ int dispatch_mode(const KcParams& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int sscg_debug_set_conv_cfg(int cfg) {
-    if (cfg < 0) { sscg_force_conv_cfg = -1; sscg_force_conv_split = 0; return SSCG_OK; }
+    if (cfg < 0) { sscg_force_conv_cfg = -1; sscg_force_conv_split = 0; sscg_tune_flags = 0; return SSCG_OK; }
     sscg_force_conv_cfg = (cfg & 0xff) == 0xff ? -1 : (cfg & 0xff);
     sscg_force_conv_split = (cfg >> 8) & 0xff;
+    sscg_tune_flags = (cfg >> 16) & 0xff;
     return SSCG_OK;
 }
 

@@ -708,14 +708,19 @@ def _note_user(w, kind):
     ent[1].add(kind)
 
 
-def refresh_transposed_weights(weights=()):
-    """Bring the cached operand copies (transposed fp32 / transposed bf16 / plain bf16) of `weights` - and of every weight
-    a pass has asked for - up to date on the CURRENT stream.  The step calls this before it forks its forward passes over
-    two streams: their backward passes then only read the cache (a lazily rebuilt copy would be written on one stream and
-    read on the other)."""
+def refresh_transposed_weights(weights=(), all_users=True):
+    """Bring the cached operand copies (transposed fp32 / transposed bf16 / plain bf16) of `weights` - and, with
+    `all_users`, of every weight a pass has asked for - up to date on the CURRENT stream.  The step calls this before it
+    forks its forward passes over two streams: their backward passes then only read the cache (a lazily rebuilt copy would
+    be written on one stream and read on the other).
+
+    `all_users` is only safe on a stream that is ordered behind EVERY optimiser's last update and every reader of the
+    stale copies (a rebuild frees the old copy: the allocator may hand its block to the next allocation at once)."""
     bf16 = _MODE[0] == "bf16"
     for w in weights:
         _cached_wt(w, torch.bfloat16 if (bf16 and w.shape[0] % 64 == 0) else torch.float32)
+    if not all_users:
+        return
     for r, kinds in list(_WT_USERS.values()):
         w = r()
         if w is None:

@@ -142,7 +142,10 @@ class semisuper_cycleGAN(object):
             # Two lanes: Gis(onehot) -> Gsi(fake_img) on the fork stream, Gsi(unl) -> Gsi(l_img) -> Gis(fake_gt) here.
             # The reference's order of BN running-stat updates (Gis: :385 before :408; Gsi: :386, :387 before :410) is kept
             # with two events; autograd runs every backward op on its forward's stream, so the backward chains fork too.
-            F.refresh_transposed_weights(p for net in (self.Gis, self.Gsi) for p in net.parameters() if p.dim() == 4)
+            # (the generators' copies only: the discriminators' update of the previous step may still be in flight on
+            # the D stream - rebuilding THEIR copies here would read half-updated weights and free copies still being read)
+            F.refresh_transposed_weights((p for net in (self.Gis, self.Gsi) for p in net.parameters() if p.dim() == 4),
+                                         all_users=False)
             main, lane = torch.cuda.current_stream(dev), F.ForkStream.get(dev)
             lane.wait_stream(main)
             with torch.cuda.stream(lane):

@@ -22,6 +22,9 @@ ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--dtype", default=None)
 ap.add_argument("--no-overlap", action="store_true")
 ap.add_argument("--no-sync", action="store_true", help="no host synchronisation between steps (the bench's schedule)")
+ap.add_argument("--no-fork", action="store_true")
+ap.add_argument("--no-side", action="store_true", help="everything on one stream")
+ap.add_argument("--no-stack", action="store_true")
 a = ap.parse_args()
 cfg = bench.CONFIGS[a.config]
 dtype = a.dtype or cfg["dtype"]
@@ -33,9 +36,13 @@ import main as cli  # noqa: E402
 args = cli.get_args(["--model", "semisupervised_cycleGAN", "--dataset", cfg["dataset"], "--crop_height", str(cfg["H"]), "--crop_width", str(cfg["W"]),
                      "--batch_size", str(bsz), "--checkpoint_dir", "/tmp/sscg_diag_ckpt", "--dtype", dtype])
 args.gpu_ids, args.as_written, args.overlap_d = [0], True, not a.no_overlap
+args.fork_forward = not a.no_fork
+args.stack_gsi = not a.no_stack
 torch.cuda.set_device(0)
 torch.manual_seed(0)
 F.set_conv_precision(dtype)
+if a.no_side:
+    F.SideStream.enabled = False
 with contextlib.redirect_stdout(io.StringIO()):
     m = md.semisuper_cycleGAN(args)
 dev = torch.device("cuda", 0)
@@ -47,8 +54,16 @@ def bad(t):
     return int((~torch.isfinite(t)).sum())
 
 
+trace = []
 for s in range(a.steps):
     out = m.step(lab[s][0], lab[s][1], unl[s][0])
+    if a.no_sync:      # device-side health record, no host synchronisation: [9 losses, non-finite counts of G.grad, D.grad, G.w]
+        cur = torch.cuda.current_stream(dev)
+        if args.overlap_d:
+            cur.wait_stream(F.d_stream(dev))
+        rec = torch.stack([v.float() for v in out.values()] + [(~torch.isfinite(t)).sum().float() for t in
+                          (m.g_optimizer.grad, m.d_optimizer.grad, m.g_optimizer.arena)])
+        trace.append(rec)
     if a.no_sync and s + 1 < a.steps:
         continue
     m.sync_losses()
@@ -59,4 +74,19 @@ for s in range(a.steps):
         bad(m.g_optimizer.grad), bad(m.d_optimizer.grad), bad(m.g_optimizer.arena), bad(m.d_optimizer.arena),
         float(m.g_optimizer.grad.abs().max()), float(m.g_optimizer.arena.abs().max()), float(m.d_optimizer.arena.abs().max())))
     sys.stdout.flush()
+    if not all(v == v and abs(v) != float("inf") for v in vals.values()) or bad(m.g_optimizer.grad) or bad(m.d_optimizer.grad):
+        for name in ("Gis", "Gsi", "Di", "Ds"):
+            net = getattr(m, name)
+            gbad = [k for k, p in net.named_parameters() if getattr(p, "_sscg_grad", None) is not None and bad(p._sscg_grad)]
+            wbad = [k for k, p in net.named_parameters() if bad(p.data)]
+            bbad = [k for k, b in net.named_buffers() if b.dtype.is_floating_point and bad(b)]
+            print("   %s: %d params with non-finite grad %s | %d non-finite weights %s | %d non-finite buffers %s" % (
+                name, len(gbad), gbad[:4], len(wbad), wbad[:3], len(bbad), bbad[:4]))
+        break
+if trace:
+    torch.cuda.synchronize()
+    for i, r in enumerate(trace):
+        v = r.cpu().tolist()
+        print("trace step %d: losses finite %s  G.grad bad %d  D.grad bad %d  G.w bad %d  | %s" % (
+            i, all(x == x and abs(x) != float("inf") for x in v[:9]), v[9], v[10], v[11], " ".join("%.3g" % x for x in v[:9])))
 print("peak memory %.1f GB" % (torch.cuda.max_memory_allocated() / 2 ** 30))
