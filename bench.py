@@ -267,6 +267,12 @@ def pmc_traffic(fam):
     return {"traffic": None, "traffic_source": "no committed PMC profile covers %s" % want}
 
 
+def cpu_sample_text(cfg, torch_version, physical, logical, model):
+    return ("as-written G+D step (incl. model.py:419-420,423), %s %d-class %dx%d, batch 2: 1 warm-up + 3 timed steps, torch %s CPU fp32, "
+            "%d threads = all physical cores (%d logical) of %s"
+            % (cfg["dataset"], cfg["C"], cfg["H"], cfg["W"], torch_version, physical, logical, model))
+
+
 def cpu_baseline(cfg):
     """oracle/ = CPU restatement of the reference step (validated bit-exact against the reference's losses by
     tests/golden/gen_golden.py), timed on this box's host cores: the as-written step at the configuration's geometry with
@@ -309,9 +315,7 @@ def cpu_baseline(cfg):
     o.step(l_img, l_gt, unl_img)
     dte = time.perf_counter() - t0
     return {"value": round(bs / dt, 4), "unit": "img/s", "cores": physical, "kind": "port",
-            "sample": "as-written G+D step (incl. model.py:419-420,423), %s %d-class %dx%d, batch 2: 1 warm-up + 3 timed steps, torch %s CPU fp32, "
-                      "%d threads = all physical cores (%d logical) of %s"
-                      % (cfg["dataset"], C, H, W, torch.__version__, physical, physical, logical, model),
+            "sample": cpu_sample_text(cfg, torch.__version__, physical, logical, model),
             "seconds_per_step": round(dt, 2), "warmup_seconds": round(times[0], 2), "cpu_model": model,
             "elided_dead_work": {"value": round(bs / dte, 4), "seconds_per_step": round(dte, 2)}}
 

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "sscg_internal.h"
 #include "reduce_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -54,7 +55,6 @@ struct K16Params {
     double* __restrict__ stats;
     int stat_L;                      // rows per normalisation group (a tile spans at most two groups: stat_L >= BM)
     double* __restrict__ xstats;     // host side: records of the split rows ([blocks][Ng][2]), written by the split reduction
-    int dma_first;                   // tuning: 1 = all pieces of the next tile go out ahead of MFMA group 0
 };
 
 __device__ __forceinline__ void store_out(void* dst, size_t idx, float v, int out_bf16) {
@@ -62,20 +62,28 @@ __device__ __forceinline__ void store_out(void* dst, size_t idx, float v, int ou
     else reinterpret_cast<float*>(dst)[idx] = v;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
+// Fragment reads and the waits of the k-loop are written out by hand: with an LDS-DMA in flight hipcc orders every LDS read it
+// can see behind `s_waitcnt vmcnt(0)` (the copy "may alias" the read), which caps the copy pipeline at ONE k-tile ahead.  The
+// loop below keeps NSTAGE - 1 tiles in flight: the compiler sees no LDS access inside it, the ordering is explicit
+// (`s_waitcnt vmcnt(pieces still allowed in flight)` + `s_barrier` before a tile is read, a barrier before it is overwritten).
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }      // orders the consumer behind the wait above it
+
+template <int MODE, int WM, int WN, int TM, int TN, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void conv16_kernel(K16Params p) {
+    constexpr int NT = WM * WN * 64;          // 4 waves (256 threads) or 8 waves (512)
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr bool STAGE_OUT = BN >= 64;      // the narrow head tile writes fp32 / few channels: direct stores
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int PA = BM / 32;           // 32 rows per loader pass (8 lanes x 16 B per row)
-    constexpr int PB = BN / 32;
+    constexpr int RP = NT / 8;                // rows per loader pass (8 lanes x 16 B per row)
+    constexpr int PA = BM / RP;
+    constexpr int PB = BN / RP;
+    static_assert(BM % RP == 0 && BN % RP == 0, "whole loader passes");
+    constexpr int A_STAGE = BM * BK * 2;      // bytes of one A image
+    constexpr int B_STAGE = BN * BK * 2;
 
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    bf16* As = reinterpret_cast<bf16*>(smem_raw);                   // [2][BM][64]
-    bf16* Bs = As + 2 * BM * BK;                                    // [2][BN][64]
-    int* tapinfo = reinterpret_cast<int*>(Bs + 2 * BN * BK);        // [R*S]: (dy << 16) | dx
-    int* wtapinfo = tapinfo + (p.R * p.S > 0 ? p.R * p.S : 1);      // [R*S]: tap index inside the weight row
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [NSTAGE][BM][64] A images, then [NSTAGE][BN][64] B images
 
     const int tid = threadIdx.x;
     int split = 0, tile;
@@ -94,13 +102,6 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
-    for (int t = tid; t < p.R * p.S; t += 256) {
-        const int ky = t / p.S;
-        const int kx = t - ky * p.S;
-        tapinfo[t] = ((ky * p.dil) << 16) | (kx * p.dil);
-        wtapinfo[t] = (p.wt_ky0 + ky * p.wt_step) * p.wt_S + p.wt_kx0 + kx * p.wt_step;
-    }
-
     const int r0 = tid >> 3;                        // row inside a pass
     const int kq = (tid & 7) ^ swz(r0);             // 16-byte k slot this lane fetches: lands at LDS slot tid & 7 of row r0
     const int wave_id = tid >> 6;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
     bool aok[PA];
 #pragma unroll
     for (int ps = 0; ps < PA; ++ps) {
-        const int m = m0 + r0 + ps * 32;
+        const int m = m0 + r0 + ps * RP;
         aok[ps] = m < p.M;
         const int mm = aok[ps] ? m : 0;
         const int img = mm / (p.OH * p.OW);
@@ -130,11 +131,10 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
     bool bok[PB];
 #pragma unroll
     for (int ps = 0; ps < PB; ++ps) {
-        const int n = n0 + r0 + ps * 32;
+        const int n = n0 + r0 + ps * RP;
         bok[ps] = n < p.Ng;
         brow[ps] = p.wgt + (size_t)(bok[ps] ? n : 0) * p.wKtot + kq * 8;
     }
-    __syncthreads();              // tapinfo visible
 
     const bool reflect = p.pad_mode == 1;
     auto locate = [&](int ps, int tdy, int tdx, int& pix) -> bool {
@@ -171,18 +171,23 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
     const int kt0 = partial ? split * p.ksplit : 0;
     const int kt1 = partial ? min(nk_all, kt0 + p.ksplit) : nk_all;
     const int f_nchunk = p.Cs / BK;
-    int f_tap = kt0 / f_nchunk;
-    int f_chunk = kt0 - f_tap * f_nchunk;
+    // the copy front: (tap = (f_ky, f_kx), channel chunk) of the next k-tile to request - wave-uniform, walked incrementally
+    int f_chunk, f_ky, f_kx;
+    {
+        const int tap0 = kt0 / f_nchunk;
+        f_chunk = kt0 - tap0 * f_nchunk;
+        f_ky = tap0 / p.S;
+        f_kx = tap0 - f_ky * p.S;
+    }
     int f_k = 0;
     const bf16* aptr[PA];
     unsigned f_okbits = 0;
-    int dma_buf = 0;
+    int dma_stage = 0;
     const bf16* zero = reinterpret_cast<const bf16*>(sscg_zero_page16);
 
-    auto set_tap = [&](int tap) {
-        const int ti = tapinfo[tap];
-        const int tdy = ti >> 16, tdx = ti & 0xffff;
-        f_k = wtapinfo[tap] * p.Cs;
+    auto set_tap = [&]() {
+        const int tdy = f_ky * p.dil, tdx = f_kx * p.dil;
+        f_k = ((p.wt_ky0 + f_ky * p.wt_step) * p.wt_S + p.wt_kx0 + f_kx * p.wt_step) * p.Cs;
         f_okbits = 0;
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
@@ -192,39 +197,46 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
             aptr[ps] = arow[ps] + (size_t)pix * p.Cs + kq * 8;
         }
     };
-    set_tap(f_tap < p.R * p.S ? f_tap : 0);
+    set_tap();
     f_k += f_chunk * BK;
 
-    // The copy of one k-tile = PA + PB LDS-DMA pieces per wave (1 KB each: this wave's 8 rows of a 32-row pass).  A piece costs
-    // ~100 issue cycles (address select, M0, the request); issued in one burst ahead of the MFMAs they would cost the wave
-    // more issue time than the 16 MFMAs of the tile take, so they are dealt out between the four MFMA groups instead.
+    // The copy of one k-tile = PA + PB LDS-DMA pieces per wave (1 KB each: this wave's 8 rows of a loader pass).
     typedef __attribute__((address_space(3))) char lds_char;
     lds_char* const lds0 = (lds_char*)smem_raw;
     const int lds_wave = __builtin_amdgcn_readfirstlane(wave_id * 1024);      // byte offset of this wave's rows inside a pass (SGPR)
     constexpr int NPIECE = PA + PB;
+    static_assert((NSTAGE - 2) * NPIECE < 64, "vmcnt is a 6-bit counter");
     auto tile_begin = [&]() {
         if (f_chunk == f_nchunk) {       // wave-uniform: next tap
             f_chunk = 0;
-            ++f_tap;
-            set_tap(f_tap < p.R * p.S ? f_tap : 0);
+            ++f_kx;
+            if (f_kx == p.S) { f_kx = 0; ++f_ky; }
+            if (f_ky >= p.R) { f_ky = 0; f_kx = 0; }      // past the last tap (never requested)
+            set_tap();
         }
     };
     auto piece = [&](int q) {
         if (q < PA) {
             const bf16* g = ((f_okbits >> q) & 1u) ? aptr[q] + f_chunk * BK : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(lds0 + dma_buf * (BM * BK * 2) + lds_wave + q * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds0 + dma_stage * A_STAGE + lds_wave + q * (RP * 128)), 16, 0, 0);
         } else {
             const int ps = q - PA;
             const bf16* g = bok[ps] ? brow[ps] + f_k : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(lds0 + 2 * BM * BK * 2 + dma_buf * (BN * BK * 2) + lds_wave + ps * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + dma_stage * B_STAGE + lds_wave + ps * (RP * 128)), 16, 0, 0);
         }
     };
     auto tile_end = [&]() {
-        dma_buf ^= 1;
+        dma_stage = dma_stage + 1 == NSTAGE ? 0 : dma_stage + 1;
         ++f_chunk;
         f_k += BK;
+    };
+    auto request_tile = [&]() {
+        tile_begin();
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) piece(q);
+        tile_end();
     };
 
     const int lane = tid & 63;
@@ -244,55 +256,66 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = kt1 - kt0;
-    if (nk > 0) {
-        tile_begin();
+    // prologue: tiles 0 .. NSTAGE - 2 on their way, tile 0 landed
+    int issued = 0;
 #pragma unroll
-        for (int q = 0; q < NPIECE; ++q) piece(q);
-        tile_end();
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+        if (s < nk) { request_tile(); ++issued; }
     }
-    __syncthreads();
-    const int sw = swz(li);                    // rows row_w + i*32 + li: (row >> 1) & 7 == (li >> 1) & 7
+    if (nk >= NSTAGE - 1) wait_vm<(NSTAGE - 2) * NPIECE>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+
+    // fragment addresses: MFMA kk contracts k = 16 kk .. 16 kk + 15 of the tile; lane half h supplies the 8 elements of slot 2 kk + h
+    // (rows row_w + i*32 + li: (row >> 1) & 7 == (li >> 1) & 7)
+    const int sw = swz(li);
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) foff[kk] = ((kk * 2 + lh) ^ sw) * 16;
+    const lds_char* const a_base = lds0 + (row_w + li) * 128;
+    const lds_char* const b_base = lds0 + NSTAGE * A_STAGE + (col_w + li) * 128;
+    int rd_stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bf16* a = As + buf * BM * BK + (row_w + li) * BK;
-        const bf16* b = Bs + buf * BN * BK + (col_w + li) * BK;
-        // MFMA kk contracts k = 16 kk .. 16 kk + 15 of the tile: lane half h supplies the 8 elements of slot 2 kk + h
-        bf16x8 fa[4][TM], fb[4][TN];
+        const lds_char* a = a_base + rd_stage * A_STAGE;
+        const lds_char* b = b_base + rd_stage * B_STAGE;
+        bf16x8 fa[2][TM], fb[2][TN];
+        auto read_frags = [&](int kk, int slot) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[slot][i]) : "v"(a + foff[kk]), "n"(i * 32 * 128));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[slot][j]) : "v"(b + foff[kk]), "n"(j * 32 * 128));
+        };
+        read_frags(0, 0);
+        // the tile NSTAGE - 1 ahead goes into the stage that was read in the previous k-step (every wave is past that barrier)
+        const bool more = issued < nk;
+        if (more) { request_tile(); ++issued; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int off = ((kk * 2 + lh) ^ sw) * 8;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[kk][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * BK + off);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[kk][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * BK + off);
-        }
-        const bool more = kt + 1 < nk;
-        if (more) tile_begin();
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            // pieces kk, kk + 4, ... of the next tile go out ahead of MFMA group kk and land under the groups that follow
-            if (more) {
-                if (p.dma_first) {
-                    if (kk == 0) {
-#pragma unroll
-                        for (int q = 0; q < NPIECE; ++q) piece(q);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = kk; q < NPIECE; q += 4) piece(q);
-                }
+            const int cur = kk & 1;
+            if (kk < 3) {
+                read_frags(kk + 1, cur ^ 1);
+                wait_lgkm<TM + TN>();           // LDS returns in order: all but the reads just issued have landed
+            } else {
+                wait_lgkm<0>();
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) pin(fa[cur][i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) pin(fb[cur][j]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);      // keep this interleave: pieces and MFMAs stay in their groups
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);      // reads of group kk + 1 stay in front of the MFMAs of group kk
         }
-        if (more) tile_end();
-        // every MFMA of the tile is in front of the barrier's `s_waitcnt vmcnt(0)` (left alone, the scheduler sinks 15 of the 16
-        // behind the wait and the copies get no cover at all)
-        __syncthreads();
+        rd_stage = rd_stage + 1 == NSTAGE ? 0 : rd_stage + 1;
+        // tile kt + 1 must have landed; the NSTAGE - 2 tiles behind it may stay in flight (while tiles are still being requested:
+        // in the last steps fewer are outstanding and the count says nothing - wait for all)
+        if (more) wait_vm<(NSTAGE - 2) * NPIECE>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -348,7 +371,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(K16Params p) {
         }
         __syncthreads();
         constexpr int TPR = BN / 8;             // threads per output row (8 channels = 16 bytes each)
-        constexpr int RPP = 256 / TPR;          // rows per pass
+        constexpr int RPP = NT / TPR;           // rows per pass
         const int c8 = (tid % TPR) * 8;
         const int n = n0 + c8;
         bf16* out = reinterpret_cast<bf16*>(p.dst);
@@ -430,15 +453,18 @@ __global__ __launch_bounds__(256) void k16_reduce_kernel(const float* __restrict
 extern int sscg_force_conv_cfg;      // conv_igemm.hip: sscg_debug_set_conv_cfg(100 + cfg) forces a bf16 tile class (tuning hook)
 extern int sscg_tune_flags;          // bit 0: spread the LDS-DMA pieces of the next tile over the four MFMA groups (default: all ahead of group 0)
 namespace {
-enum { CFG_128x128 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_128x64 = 3 };
-const int C16_BM[4] = {128, 64, 128, 128};
-const int C16_BN[4] = {128, 64, 32, 64};
+// tile classes: block tile, waves, copy stages (k-tiles in LDS).  The deep classes hold 2-3 tiles in flight per workgroup.
+enum { CFG_128x128 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_128x64 = 3, CFG_128x128_S3 = 4, CFG_128x128_S4 = 5, CFG_256x128_S3 = 6,
+       CFG_64x64_S4 = 7, CFG_128x64_S3 = 8, NCFG16 = 9 };
+const int C16_BM[NCFG16] = {128, 64, 128, 128, 128, 128, 256, 64, 128};
+const int C16_BN[NCFG16] = {128, 64, 32, 64, 128, 128, 128, 64, 64};
+const int C16_WM[NCFG16] = {2, 2, 4, 2, 2, 2, 4, 2, 2};      // wave rows of a tile (= statistics records per tile row)
 
 // Measured on the step's shapes (tools/conv16_bench.py, profiles/r02_conv16_shapes.txt): 128x128 wins wherever the k-loop is long
 // (3x3 on 256/512 channels: 840 TF/s); a short k-loop (Ktot <= 1024: the 1x1 bottleneck ends, the PixelDiscriminator) is
 // dominated by its epilogue and runs 10-20 % faster on 128x64 tiles, which put twice as many stores in flight.
 int choose16(long M, int Ng, int Ktot) {
-    if (sscg_force_conv_cfg >= 100 && sscg_force_conv_cfg < 104 && Ng > 32) return sscg_force_conv_cfg - 100;   // tuning hook
+    if (sscg_force_conv_cfg >= 100 && sscg_force_conv_cfg < 100 + NCFG16 && Ng > 32) return sscg_force_conv_cfg - 100;   // tuning hook
     if (Ng <= 32) return CFG_128x32;
     const long t128 = (long)cdiv(M, 128) * cdiv(Ng, 128);
     if (Ktot <= 1024 && Ng <= 1024 && cdiv(M, 128) * cdiv(Ng, 64) >= 384) return CFG_128x64;
@@ -486,7 +512,7 @@ K16Split plan16_raw(long M, int Ng, int Ktot) {
     // 64x64 and 128x128 launches: only the TAIL beyond the last whole round of 256 workgroups is cut along K (8712 rows x 256
     // channels = 548 tiles of 64x64; 34320 rows = 538 tiles of 128x128: 512 run whole, two per CU side by side, the other
     // 26 would keep a tenth of the chip busy for a whole tile time)
-    if ((cfg != CFG_64x64 && cfg != CFG_128x128) || nk < 8 || tiles > 2300) return r;
+    if (cfg == CFG_128x32 || cfg == CFG_128x64 || cfg == CFG_128x64_S3 || nk < 8 || tiles > 2300) return r;
     const int q = tiles / 256;
     const int full_m = (q * 256) / tiles_n;
     const int tail = tiles - full_m * tiles_n;
@@ -506,26 +532,26 @@ size_t split16_bytes(const K16Split& sp, long M, int Ng) {
     return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, int NSTAGE>
 int launch16(const K16Params& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
+    constexpr int NT = WM * WN * 64;
     K16Params p = p0;
     p.tiles_n = cdiv(p.Ng, BN);
     const int tiles_m = cdiv(p.M, BM);
     p.tiles = tiles_m * p.tiles_n;
-    size_t smem = (size_t)(2 * BM * BK + 2 * BN * BK) * sizeof(bf16) + (size_t)(p.R * p.S > 0 ? p.R * p.S : 1) * 8;
+    size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(bf16);
     const size_t stage = BN >= 64 ? (size_t)BM * (BN + 4) * sizeof(float) : 0;      // output tile of the staged epilogue
     if (stage > smem) smem = stage;
-    auto kern = conv16_kernel<MODE, WM, WN, TM, TN>;
+    auto kern = conv16_kernel<MODE, WM, WN, TM, TN, NSTAGE>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
     if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
-    p.dma_first = !(sscg_tune_flags & 1);
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);
     SSCG_LAUNCH_CHECK();
     if (p.splits > 1) {
         const size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
@@ -543,10 +569,15 @@ int launch16(const K16Params& p0, hipStream_t st) {
 template <int MODE>
 int dispatch16(const K16Params& p, hipStream_t st) {
     switch (choose16(p.M, p.Ng, p.Ktot)) {
-        case CFG_128x128: return launch16<MODE, 2, 2, 2, 2>(p, st);
-        case CFG_64x64: return launch16<MODE, 2, 2, 1, 1>(p, st);
-        case CFG_128x32: return launch16<MODE, 4, 1, 1, 1>(p, st);
-        case CFG_128x64: return launch16<MODE, 2, 2, 2, 1>(p, st);
+        case CFG_128x128: return launch16<MODE, 2, 2, 2, 2, 2>(p, st);
+        case CFG_64x64: return launch16<MODE, 2, 2, 1, 1, 2>(p, st);
+        case CFG_128x32: return launch16<MODE, 4, 1, 1, 1, 2>(p, st);
+        case CFG_128x64: return launch16<MODE, 2, 2, 2, 1, 2>(p, st);
+        case CFG_128x128_S3: return launch16<MODE, 2, 2, 2, 2, 3>(p, st);
+        case CFG_128x128_S4: return launch16<MODE, 2, 2, 2, 2, 4>(p, st);
+        case CFG_256x128_S3: return launch16<MODE, 4, 2, 2, 2, 3>(p, st);
+        case CFG_64x64_S4: return launch16<MODE, 2, 2, 1, 1, 4>(p, st);
+        case CFG_128x64_S3: return launch16<MODE, 2, 2, 2, 1, 3>(p, st);
         default: return SSCG_ERR_BAD_ARG;
     }
 }
@@ -576,7 +607,7 @@ bool sscg_conv16_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* w
     const int cfg = choose16(M, d->K, d->R * d->S * d->C);
     if (cfg == CFG_128x32 || L < C16_BM[cfg]) return false;
     *bm = C16_BM[cfg];
-    *wm = 2;
+    *wm = C16_WM[cfg];
     *tiles_n = cdiv(d->K, C16_BN[cfg]);
     K16Split sp = plan16(M, d->K, d->R * d->S * d->C, L);
     *splits = sp.splits; *full_tiles = sp.full_tiles; *m_tail0 = sp.m_tail0;
@@ -873,6 +904,242 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wg16Params p) {
     }
 }
 
+// ---- weight gradient, LDS-DMA + transpose-read version -------------------------------------------------------------------------
+// The operands are [pixel][channel] in HBM: contiguous along the OUTPUT axes, strided along the reduction (pixels), while an
+// MFMA operand is 8 consecutive k (= pixels) of one output row.  wgrad16_kernel above transposes 8x8 pieces in registers and
+// pays 32 v_perm + 8 ds_write_b128 per thread and k-step (the ds_write path alone is ~400 of a k-step's 512 MFMA cycles).
+// gfx950's `ds_read_b64_tr_b16` transposes on the way OUT of LDS instead: a 16-lane group reads a [4 pixels][16 channels]
+// block (lane i supplies the address of 4 consecutive channels of pixel i >> 2) and lane i receives the 4 pixels of channel i.
+// So the [pixel][channel] rows go to LDS as they are, by LDS-DMA (no staging registers, no ds_write), NSTAGE - 1 k-tiles in
+// flight, and the fragments come from two transpose-reads per operand.
+//   LDS image of one operand and stage: [64 pixels][BT channels] bf16, rows of BT * 2 bytes; the 16-byte chunk q of pixel row r
+//   sits at chunk q ^ wsw(r): the four pixel rows a transpose-read touches land in four different quarters of the 256-byte
+//   bank line (plain rows of 256 B would hit the same 64 bytes four times).
+template <int BT> __device__ __forceinline__ int wsw(int pixel) { return BT == 128 ? ((pixel & 3) << 2) : (((pixel >> 1) & 1) << 2); }
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((address_space(3))) char wg_lds_char;
+
+template <int KK, int TM, int TN, int A_ROWB, int B_ROWB>
+__device__ __forceinline__ void wg_read_frags(bf16x4 (&fa)[TM][2], bf16x4 (&fb)[TN][2], const wg_lds_char* a, const wg_lds_char* b,
+                                              const int (&a_off)[TM], const int (&b_off)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[i][0]) : "v"(a + a_off[i]), "n"((16 * KK) * A_ROWB));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[i][1]) : "v"(a + a_off[i]), "n"((16 * KK + 4) * A_ROWB));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[j][0]) : "v"(b + b_off[j]), "n"((16 * KK) * B_ROWB));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[j][1]) : "v"(b + b_off[j]), "n"((16 * KK + 4) * B_ROWB));
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int NSTAGE>
+__global__ __launch_bounds__(256) void wgrad16t_kernel(Wg16Params p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    static_assert(WM * WN == 4 && (BM == 64 || BM == 128) && (BN == 64 || BN == 128), "4 waves; 64- or 128-channel operand tiles");
+    constexpr int A_ROWB = BM * 2, B_ROWB = BN * 2;            // bytes per pixel row
+    constexpr int A_STAGE = BKP * A_ROWB, B_STAGE = BKP * B_ROWB;
+    constexpr int A_PR = 1024 / A_ROWB, B_PR = 1024 / B_ROWB;   // pixel rows per 1 KB DMA piece (4 or 8)
+    constexpr int A_NP = A_STAGE / 1024 / 4, B_NP = B_STAGE / 1024 / 4;   // pieces per wave and k-tile (4 or 2)
+    constexpr int NPIECE = A_NP + B_NP;
+    static_assert((NSTAGE - 2) * NPIECE < 64, "vmcnt is a 6-bit counter");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [NSTAGE] A images, then [NSTAGE] B images
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds0 = (lds_char*)smem_raw;
+
+    const int tid = threadIdx.x;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / p.tiles;
+    const int tl = lin - split * p.tiles;
+    const int tile_n = tl % p.tiles_n;
+    const int tile_m = tl / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int p_begin = split * p.chunk;
+    const int p_end = min(p.npix, p_begin + p.chunk);
+    const bool reflect = p.pad_mode == 1;
+    const int wave_id = tid >> 6;
+    const int lane = tid & 63;
+    const bf16* const zero = reinterpret_cast<const bf16*>(sscg_zero_page16);
+
+    // ---- copy side.  A piece = 1 KB of LDS = A_PR (B_PR) whole pixel rows; lane l writes chunk l % (ROWB / 16) of row l / (ROWB / 16),
+    // i.e. it FETCHES source chunk (that chunk ^ wsw(row)).  Wave w owns pieces w * NP .. w * NP + NP - 1 of every k-tile.
+    const int a_row = lane / (A_ROWB / 16);                  // pixel row inside a piece (pieces start at multiples of 4 / 8 pixels)
+    const int a_q = (lane % (A_ROWB / 16)) ^ wsw<BM>(a_row);
+    const bool a_colok = m0 + a_q * 8 < p.Kc;
+    const bf16* const a_src = p.dy + (a_colok ? m0 + a_q * 8 : 0);
+    const int b_row = lane / (B_ROWB / 16);
+    const int b_q = (lane % (B_ROWB / 16)) ^ wsw<BN>(b_row);
+    const int b_n = n0 + b_q * 8;
+    const bool b_colok = b_n < p.Ng;
+    int tdy, tdx;
+    const bf16* b_src;
+    {
+        const int nn = b_colok ? b_n : 0;
+        const int tap = nn / p.C;
+        const int c = nn - tap * p.C;
+        const int ky = tap / p.S;
+        const int kx = tap - ky * p.S;
+        tdy = ky * p.dil - p.pad;
+        tdx = kx * p.dil - p.pad;
+        b_src = p.x + c;
+    }
+    const bool plain = p.Ng == p.C && p.stride == 1 && p.pad == 0;      // 1x1, stride 1: source pixel = output pixel
+    int dma_stage = 0;
+    int f_pix = p_begin;                                      // first pixel of the next k-tile to request
+    const int lds_wave_a = __builtin_amdgcn_readfirstlane(wave_id * A_NP * 1024);
+    const int lds_wave_b = __builtin_amdgcn_readfirstlane(wave_id * B_NP * 1024);
+    auto request_tile = [&]() {
+#pragma unroll
+        for (int s = 0; s < A_NP; ++s) {
+            const int pix = f_pix + (wave_id * A_NP + s) * A_PR + a_row;
+            const bf16* g = (a_colok && pix < p_end) ? a_src + (size_t)pix * p.Kc : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lds0 + dma_stage * A_STAGE + lds_wave_a + s * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < B_NP; ++s) {
+            const int pix = f_pix + (wave_id * B_NP + s) * B_PR + b_row;
+            bool ok = b_colok && pix < p_end;
+            const int pp = ok ? pix : 0;
+            size_t spix;
+            if (plain) {
+                spix = (size_t)pp;
+            } else {
+                const int img = fd_div(pp, p.div_pq);
+                const int rem = pp - img * (p.P * p.Q);
+                const int oy = fd_div(rem, p.div_q);
+                const int ox = rem - oy * p.Q;
+                int sy = oy * p.stride + tdy;
+                int sx = ox * p.stride + tdx;
+                if (reflect) {          // wave-uniform (ReflectionPad2d folded into the conv: the ResNet generators' stems / blocks)
+                    sy = sy < 0 ? -sy : sy;
+                    sx = sx < 0 ? -sx : sx;
+                    sy = sy >= p.H ? 2 * (p.H - 1) - sy : sy;
+                    sx = sx >= p.W ? 2 * (p.W - 1) - sx : sx;
+                }
+                ok = ok & ((unsigned)sy < (unsigned)p.H) & ((unsigned)sx < (unsigned)p.W);
+                spix = (size_t)((img * p.H + sy) * p.W + sx);
+            }
+            const bf16* g = ok ? b_src + spix * p.C : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + dma_stage * B_STAGE + lds_wave_b + s * 1024), 16, 0, 0);
+        }
+        dma_stage = dma_stage + 1 == NSTAGE ? 0 : dma_stage + 1;
+        f_pix += BKP;
+    };
+
+    // ---- MFMA side
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int i16 = lane & 15;                // lane inside its 16-lane transpose group
+    const int wm = wave_id / WN;
+    const int wn = wave_id % WN;
+    const int row_w = wm * TM * 32;
+    const int col_w = wn * TN * 32;
+    // transpose-read address of operand rows (channels) cb .. cb + 15 handled by this lane's group, pixels 8 lh + (0..3) [+ 4 t]:
+    // the lane supplies 4 consecutive channels (8 bytes) of pixel 8 lh + (i16 >> 2)
+    const int tr_pix = 8 * lh + (i16 >> 2);
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ch = row_w + i * 32 + (li & 16) + 4 * (i16 & 3);
+        a_off[i] = tr_pix * A_ROWB + (((ch >> 3) ^ wsw<BM>(tr_pix)) << 4) + ((ch >> 2) & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ch = col_w + j * 32 + (li & 16) + 4 * (i16 & 3);
+        b_off[j] = NSTAGE * A_STAGE + tr_pix * B_ROWB + (((ch >> 3) ^ wsw<BN>(tr_pix)) << 4) + ((ch >> 2) & 1) * 8;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nsteps = (p_end - p_begin + BKP - 1) / BKP;
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+        if (s < nsteps) { request_tile(); ++issued; }
+    }
+    if (nsteps >= NSTAGE - 1) wait_vm<(NSTAGE - 2) * NPIECE>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+
+    int rd_stage = 0;
+    for (int it = 0; it < nsteps; ++it) {
+        const lds_char* a = lds0 + rd_stage * A_STAGE;
+        const lds_char* b = lds0 + rd_stage * B_STAGE;
+        bf16x4 fa[2][TM][2], fb[2][TN][2];
+        // MFMA kk contracts pixels 16 kk .. 16 kk + 15: lane half lh feeds pixels 16 kk + 8 lh + (0..7) = two transpose-reads
+        auto mfma_group = [&](int cur) {
+            bf16x8 va[TM], vb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                va[i] = __builtin_shufflevector(fa[cur][i][0], fa[cur][i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                pin(va[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                vb[j] = __builtin_shufflevector(fb[cur][j][0], fb[cur][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                pin(vb[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i], vb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        wg_read_frags<0, TM, TN, A_ROWB, B_ROWB>(fa[0], fb[0], a, b, a_off, b_off);
+        const bool more = issued < nsteps;
+        if (more) { request_tile(); ++issued; }
+        __builtin_amdgcn_sched_barrier(0);
+        wg_read_frags<1, TM, TN, A_ROWB, B_ROWB>(fa[1], fb[1], a, b, a_off, b_off);
+        wait_lgkm<2 * (TM + TN)>();
+        mfma_group(0);
+        wg_read_frags<2, TM, TN, A_ROWB, B_ROWB>(fa[0], fb[0], a, b, a_off, b_off);
+        wait_lgkm<2 * (TM + TN)>();
+        mfma_group(1);
+        wg_read_frags<3, TM, TN, A_ROWB, B_ROWB>(fa[1], fb[1], a, b, a_off, b_off);
+        wait_lgkm<2 * (TM + TN)>();
+        mfma_group(0);
+        wait_lgkm<0>();
+        mfma_group(1);
+        rd_stage = rd_stage + 1 == NSTAGE ? 0 : rd_stage + 1;
+        if (more) wait_vm<(NSTAGE - 2) * NPIECE>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+    }
+
+    float* out = p.out + (size_t)split * p.Kc * p.Ng;
+    const bool direct = (p.splits == 1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + col_w + j * 32 + li;
+        if (n >= p.Ng) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.Kc) {
+                    const size_t o = (size_t)m * p.Ng + n;
+                    float v = acc[i][j][e];
+                    if (direct && p.beta != 0.f) v += p.beta * out[o];
+                    out[o] = v;
+                }
+            }
+        }
+    }
+}
+
 struct Wg16Plan { int cfg, bm, bn, splits, chunk; };
 
 // Split of the pixel range: enough workgroups for ~3 rounds of the 256 CUs, at least 4 k-steps each.
@@ -912,6 +1179,24 @@ int launch_wg16(Wg16Params p, int splits, hipStream_t st) {
     return SSCG_OK;
 }
 
+template <int WM, int WN, int TM, int TN, int NSTAGE>
+int launch_wg16t(Wg16Params p, int splits, hipStream_t st) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    p.tiles_n = cdiv(p.Ng, BN);
+    p.tiles = cdiv(p.Kc, BM) * p.tiles_n;
+    p.splits = splits;
+    const size_t smem = (size_t)NSTAGE * BKP * (BM + BN) * sizeof(bf16);
+    auto kern = wgrad16t_kernel<WM, WN, TM, TN, NSTAGE>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles * splits), dim3(256), smem, st, p);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
 }  // namespace
 
 bool sscg_wgrad16_applies(const sscg_conv_desc* d) {
@@ -938,7 +1223,19 @@ int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* 
     p.beta = pl.splits > 1 ? 0.f : beta;
     p.div_pq = make_fastdiv(d->P * d->Q);
     p.div_q = make_fastdiv(d->Q);
-    int rc = pl.cfg == 0 ? launch_wg16<2, 2, 2, 2>(p, pl.splits, st) : launch_wg16<2, 2, 1, 1>(p, pl.splits, st);
+    int rc;
+    const int variant = (sscg_tune_flags >> 1) & 7;      // tools/conv16_bench.py: 0 = default
+    if (sscg_tune_flags & 1) {                           // register-transposing kernel (kept for comparison)
+        rc = pl.cfg == 0 ? launch_wg16<2, 2, 2, 2>(p, pl.splits, st) : launch_wg16<2, 2, 1, 1>(p, pl.splits, st);
+    } else if (pl.cfg == 0) {
+        rc = variant == 1 ? launch_wg16t<2, 2, 2, 2, 2>(p, pl.splits, st)
+           : variant == 2 ? launch_wg16t<2, 2, 2, 2, 4>(p, pl.splits, st)
+                          : launch_wg16t<2, 2, 2, 2, 3>(p, pl.splits, st);
+    } else {
+        rc = variant == 1 ? launch_wg16t<2, 2, 1, 1, 2>(p, pl.splits, st)
+           : variant == 2 ? launch_wg16t<2, 2, 1, 1, 6>(p, pl.splits, st)
+                          : launch_wg16t<2, 2, 1, 1, 4>(p, pl.splits, st);
+    }
     if (rc) return rc;
     if (pl.splits > 1) return sscg_wgrad_reduce(reinterpret_cast<const float*>(ws), dw, (size_t)d->K * p.Ng, pl.splits, beta, st);
     return SSCG_OK;

@@ -166,3 +166,18 @@ else:
     utils.save_checkpoint({"epoch": 4, "best_iou": 0.6, **{k: v.state_dict() for k, v in ours.items()}}, our_ck)
     out = subprocess.run([sys.executable, "-c", code, "load", our_ck], check=True, capture_output=True, text=True).stdout
     assert "reference loaded" in out
+
+
+def test_bench_cpu_baseline_leg_runs_and_reports(monkeypatch):
+    """bench.py's cpu_baseline leg end to end on a tiny geometry (the driver's default bench run executes it at 256x256)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    threads = torch.get_num_threads()
+    try:
+        r = bench.cpu_baseline({"dataset": "voc2012", "C": 21, "H": 32, "W": 32})
+    finally:
+        torch.set_num_threads(threads)
+    assert r["kind"] == "port" and r["unit"] == "img/s" and r["value"] > 0 and r["cores"] >= 1
+    assert "32x32" in r["sample"] and "1 warm-up + 3 timed" in r["sample"] and r["cpu_model"] in r["sample"]
+    assert r["elided_dead_work"]["value"] > 0
+    json.dumps(r)

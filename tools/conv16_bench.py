@@ -21,7 +21,8 @@ SHAPES = [(32, 256, 64, 128, 256, 3, 1, 1, 1), (16, 256, 33, 65, 256, 3, 1, 2, 2
           (32, 64, 128, 256, 128, 3, 2, 1, 1), (32, 128, 64, 128, 256, 3, 2, 1, 1), (16, 64, 128, 256, 128, 4, 2, 1, 1),
           (16, 128, 64, 128, 256, 4, 2, 1, 1), (16, 256, 32, 64, 512, 4, 1, 1, 1)]
 # name, forced tile class (100 + cfg; 0xff = planner), tune flags (1 = LDS-DMA pieces spread over the MFMA groups)
-VARIANTS = [("plan", 0xff, 0), ("plan+spread", 0xff, 1), ("128x128", 100, 0), ("64x64", 101, 0), ("128x64", 103, 0)]
+VARIANTS = [("plan", 0xff, 0), ("128x128", 100, 0), ("128x128s3", 104, 0), ("128x128s4", 105, 0), ("256x128s3", 106, 0), ("64x64", 101, 0),
+            ("64x64s4", 107, 0), ("128x64", 103, 0), ("128x64s3", 108, 0)]
 
 
 def timeit(fn, n=20):
@@ -46,15 +47,37 @@ for (n, c, h, w, k, r, s, p, d) in SHAPES:
     wtt = F.weight_transposed(wt, torch.bfloat16)
     flops = 2.0 * n * y.shape[2] * y.shape[3] * k * c * r * r
     row = "%-36s" % ("%dx%dx%d c%d k%d r%d d%d" % (n, h, w, c, k, r, d))
+    for _ in range(10):      # clocks up before the first variant is timed
+        F.conv2d_fwd(x, wt, None, s, p, d, out_f32=False)
+    y_ref = y.float()
+    dx_ref = F.conv2d_dgrad(gy, wtt, x.shape, wt.shape, s, p, d, out_dtype=torch.bfloat16).float()
     for name, cfg, tune in VARIANTS:
         F.lib.sscg_debug_set_conv_cfg(cfg | (tune << 16))
         try:
+            ey = float((F.conv2d_fwd(x, wt, None, s, p, d, out_f32=False).float() - y_ref).abs().max())
+            ed = float((F.conv2d_dgrad(gy, wtt, x.shape, wt.shape, s, p, d, out_dtype=torch.bfloat16).float() - dx_ref).abs().max())
+            if ey > 0.0 or ed > 0.0:      # the tile class does not change the order of a row's k-sum: results are bitwise equal (tail splits aside)
+                row += " | %s DIFF %.3g %.3g" % (name, ey, ed)
             tf = timeit(lambda: F.conv2d_fwd(x, wt, None, s, p, d, out_f32=False))
             td = timeit(lambda: F.conv2d_dgrad(gy, wtt, x.shape, wt.shape, s, p, d, out_dtype=torch.bfloat16))
-            row += " | %-15s f %6.1f d %6.1f" % (name, flops / tf / 1e9, flops / td / 1e9)
+            row += " | %-9s f %6.1f d %6.1f" % (name, flops / tf / 1e9, flops / td / 1e9)
         finally:
             F.lib.sscg_debug_set_conv_cfg(-1)
-    tw = timeit(lambda: F.conv2d_wgrad(x, gy, wt.shape, s, p, d))
-    row += " | wgrad %6.1f" % (flops / tw / 1e9)
+    # weight gradient: register-transposing kernel (flag 1) vs LDS-DMA + transpose-read kernel with 3 (default) / 2 / 4 copy stages
+    dw_ref = None
+    for name, tune in (("wg-old", 1), ("wg-s3", 0), ("wg-s2", 2), ("wg-s4", 4)):
+        F.lib.sscg_debug_set_conv_cfg(0xff | (tune << 16))
+        try:
+            dw = F.conv2d_wgrad(x, gy, wt.shape, s, p, d)
+            if dw_ref is None:
+                dw_ref = dw
+            else:
+                err = float((dw - dw_ref).abs().max() / dw_ref.abs().max())
+                if err > 2e-4:
+                    row += " | %s DIFF %.3g" % (name, err)
+            tw = timeit(lambda: F.conv2d_wgrad(x, gy, wt.shape, s, p, d))
+            row += " | %s %6.1f" % (name, flops / tw / 1e9)
+        finally:
+            F.lib.sscg_debug_set_conv_cfg(-1)
     out.write(row + "\n")
     out.flush()
