@@ -71,7 +71,7 @@ template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_w
 __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }      // orders the consumer behind the wait above it
 
 template <int MODE, int WM, int WN, int TM, int TN, int NSTAGE>
-__global__ __launch_bounds__(WM * WN * 64) void conv16_kernel(K16Params p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 2) void conv16_kernel(K16Params p) {
     constexpr int NT = WM * WN * 64;          // 4 waves (256 threads) or 8 waves (512)
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -454,22 +454,23 @@ extern int sscg_force_conv_cfg;      // conv_igemm.hip: sscg_debug_set_conv_cfg(
 extern int sscg_tune_flags;          // bit 0: spread the LDS-DMA pieces of the next tile over the four MFMA groups (default: all ahead of group 0)
 namespace {
 // tile classes: block tile, waves, copy stages (k-tiles in LDS).  The deep classes hold 2-3 tiles in flight per workgroup.
-enum { CFG_128x128 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_128x64 = 3, CFG_128x128_S3 = 4, CFG_128x128_S4 = 5, CFG_256x128_S3 = 6,
-       CFG_64x64_S4 = 7, CFG_128x64_S3 = 8, NCFG16 = 9 };
-const int C16_BM[NCFG16] = {128, 64, 128, 128, 128, 128, 256, 64, 128};
-const int C16_BN[NCFG16] = {128, 64, 32, 64, 128, 128, 128, 64, 64};
-const int C16_WM[NCFG16] = {2, 2, 4, 2, 2, 2, 4, 2, 2};      // wave rows of a tile (= statistics records per tile row)
+enum { CFG_128x128 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_128x64 = 3, CFG_128x128_W8 = 4, CFG_256x128_W8 = 5, NCFG16 = 6 };
+const int C16_BM[NCFG16] = {128, 64, 128, 128, 128, 256};
+const int C16_BN[NCFG16] = {128, 64, 32, 64, 128, 128};
+const int C16_WM[NCFG16] = {2, 2, 4, 2, 2, 4};      // wave rows of a tile (= statistics records per tile row)
 
-// Measured on the step's shapes (tools/conv16_bench.py, profiles/r02_conv16_shapes.txt): 128x128 wins wherever the k-loop is long
-// (3x3 on 256/512 channels: 840 TF/s); a short k-loop (Ktot <= 1024: the 1x1 bottleneck ends, the PixelDiscriminator) is
-// dominated by its epilogue and runs 10-20 % faster on 128x64 tiles, which put twice as many stores in flight.
+// Measured on the step's shapes (tools/conv16_bench.py, profiles/r02_conv16_shapes.txt).  What decides the rate is the number of
+// waves per SIMD, not the depth of the copy pipeline or the tile's arithmetic intensity: 128x128 tiles as 4 waves of 64x64 (2
+// workgroups = 2 waves per SIMD) reach 600 TF/s on the 34320-row 256-channel 3x3, the same tile as 8 waves of 64x32 (4 per SIMD)
+// 710; three or four k-tiles in flight with ONE workgroup per CU: 470; 256x128 tiles: no gain.  Few output channels: 128x64 /
+// 64x64 tiles of 4 waves.
 int choose16(long M, int Ng, int Ktot) {
     if (sscg_force_conv_cfg >= 100 && sscg_force_conv_cfg < 100 + NCFG16 && Ng > 32) return sscg_force_conv_cfg - 100;   // tuning hook
+    (void)Ktot;
     if (Ng <= 32) return CFG_128x32;
-    const long t128 = (long)cdiv(M, 128) * cdiv(Ng, 128);
-    if (Ktot <= 1024 && Ng <= 1024 && cdiv(M, 128) * cdiv(Ng, 64) >= 384) return CFG_128x64;
-    if (Ng >= 128 && t128 >= 384) return CFG_128x128;
-    if (Ng <= 64 && cdiv(M, 128) >= 384) return CFG_128x64;
+    const long tm = cdiv(M, 128);
+    if (Ng <= 64) return tm >= 384 ? CFG_128x64 : CFG_64x64;
+    if (tm * cdiv(Ng, 128) >= 384) return CFG_128x128_W8;
     return CFG_64x64;
 }
 
@@ -512,7 +513,7 @@ K16Split plan16_raw(long M, int Ng, int Ktot) {
     // 64x64 and 128x128 launches: only the TAIL beyond the last whole round of 256 workgroups is cut along K (8712 rows x 256
     // channels = 548 tiles of 64x64; 34320 rows = 538 tiles of 128x128: 512 run whole, two per CU side by side, the other
     // 26 would keep a tenth of the chip busy for a whole tile time)
-    if (cfg == CFG_128x32 || cfg == CFG_128x64 || cfg == CFG_128x64_S3 || nk < 8 || tiles > 2300) return r;
+    if (cfg == CFG_128x32 || cfg == CFG_128x64 || nk < 8 || tiles > 2300) return r;
     const int q = tiles / 256;
     const int full_m = (q * 256) / tiles_n;
     const int tail = tiles - full_m * tiles_n;
@@ -573,11 +574,8 @@ int dispatch16(const K16Params& p, hipStream_t st) {
         case CFG_64x64: return launch16<MODE, 2, 2, 1, 1, 2>(p, st);
         case CFG_128x32: return launch16<MODE, 4, 1, 1, 1, 2>(p, st);
         case CFG_128x64: return launch16<MODE, 2, 2, 2, 1, 2>(p, st);
-        case CFG_128x128_S3: return launch16<MODE, 2, 2, 2, 2, 3>(p, st);
-        case CFG_128x128_S4: return launch16<MODE, 2, 2, 2, 2, 4>(p, st);
-        case CFG_256x128_S3: return launch16<MODE, 4, 2, 2, 2, 3>(p, st);
-        case CFG_64x64_S4: return launch16<MODE, 2, 2, 1, 1, 4>(p, st);
-        case CFG_128x64_S3: return launch16<MODE, 2, 2, 2, 1, 3>(p, st);
+        case CFG_128x128_W8: return launch16<MODE, 2, 4, 2, 1, 2>(p, st);      // 8 waves of 64x32: 4 waves per SIMD with 2 workgroups per CU
+        case CFG_256x128_W8: return launch16<MODE, 4, 2, 2, 2, 2>(p, st);      // 8 waves of 64x64: 96 KB of LDS, one workgroup per CU
         default: return SSCG_ERR_BAD_ARG;
     }
 }
@@ -936,14 +934,15 @@ __device__ __forceinline__ void wg_read_frags(bf16x4 (&fa)[TM][2], bf16x4 (&fb)[
 }
 
 template <int WM, int WN, int TM, int TN, int NSTAGE>
-__global__ __launch_bounds__(256) void wgrad16t_kernel(Wg16Params p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 2) void wgrad16t_kernel(Wg16Params p) {
+    constexpr int NW = WM * WN;               // 4 or 8 waves
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    static_assert(WM * WN == 4 && (BM == 64 || BM == 128) && (BN == 64 || BN == 128), "4 waves; 64- or 128-channel operand tiles");
+    static_assert((NW == 4 || NW == 8) && (BM == 64 || BM == 128) && (BN == 64 || BN == 128), "64- or 128-channel operand tiles");
     constexpr int A_ROWB = BM * 2, B_ROWB = BN * 2;            // bytes per pixel row
     constexpr int A_STAGE = BKP * A_ROWB, B_STAGE = BKP * B_ROWB;
     constexpr int A_PR = 1024 / A_ROWB, B_PR = 1024 / B_ROWB;   // pixel rows per 1 KB DMA piece (4 or 8)
-    constexpr int A_NP = A_STAGE / 1024 / 4, B_NP = B_STAGE / 1024 / 4;   // pieces per wave and k-tile (4 or 2)
+    constexpr int A_NP = A_STAGE / 1024 / NW, B_NP = B_STAGE / 1024 / NW;   // pieces per wave and k-tile (4, 2 or 1)
     constexpr int NPIECE = A_NP + B_NP;
     static_assert((NSTAGE - 2) * NPIECE < 64, "vmcnt is a 6-bit counter");
 
@@ -1151,7 +1150,9 @@ Wg16Plan plan_wg16(const sscg_conv_desc* d) {
     pl.cfg = (Kc >= 128 && Ng >= 128 && (long)cdiv(Kc, 128) * cdiv(Ng, 128) >= 8) ? 0 : 1;
     pl.bm = pl.bn = pl.cfg == 0 ? 128 : 64;
     const long tiles = (long)cdiv(Kc, pl.bm) * cdiv(Ng, pl.bn);
-    long s = cdiv(768, tiles);
+    // workgroups aimed at: tools/conv16_bench.py sweeps this through the tuning flags (bits 4..7 = target / 128)
+    const long target = ((sscg_tune_flags >> 4) & 15) ? 128L * ((sscg_tune_flags >> 4) & 15) : 768;
+    long s = cdiv(target, tiles);
     if (s > steps / 4) s = steps / 4;
     if (s > 1024) s = 1024;
     if (s < 1) s = 1;
@@ -1187,12 +1188,13 @@ int launch_wg16t(Wg16Params p, int splits, hipStream_t st) {
     p.tiles = cdiv(p.Kc, BM) * p.tiles_n;
     p.splits = splits;
     const size_t smem = (size_t)NSTAGE * BKP * (BM + BN) * sizeof(bf16);
+    constexpr int NT = WM * WN * 64;
     auto kern = wgrad16t_kernel<WM, WN, TM, TN, NSTAGE>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles * splits), dim3(256), smem, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles * splits), dim3(NT), smem, st, p);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -1228,13 +1230,10 @@ int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* 
     if (sscg_tune_flags & 1) {                           // register-transposing kernel (kept for comparison)
         rc = pl.cfg == 0 ? launch_wg16<2, 2, 2, 2>(p, pl.splits, st) : launch_wg16<2, 2, 1, 1>(p, pl.splits, st);
     } else if (pl.cfg == 0) {
-        rc = variant == 1 ? launch_wg16t<2, 2, 2, 2, 2>(p, pl.splits, st)
-           : variant == 2 ? launch_wg16t<2, 2, 2, 2, 4>(p, pl.splits, st)
-                          : launch_wg16t<2, 2, 2, 2, 3>(p, pl.splits, st);
+        // 128x128 tile as 8 waves of 64x32: 4 waves per SIMD with two workgroups per CU (550 -> 665 TF/s on the 256-ch 3x3)
+        rc = variant == 1 ? launch_wg16t<2, 2, 2, 2, 2>(p, pl.splits, st) : launch_wg16t<2, 4, 2, 1, 2>(p, pl.splits, st);
     } else {
-        rc = variant == 1 ? launch_wg16t<2, 2, 1, 1, 2>(p, pl.splits, st)
-           : variant == 2 ? launch_wg16t<2, 2, 1, 1, 6>(p, pl.splits, st)
-                          : launch_wg16t<2, 2, 1, 1, 4>(p, pl.splits, st);
+        rc = variant == 1 ? launch_wg16t<2, 2, 1, 1, 4>(p, pl.splits, st) : launch_wg16t<2, 2, 1, 1, 2>(p, pl.splits, st);
     }
     if (rc) return rc;
     if (pl.splits > 1) return sscg_wgrad_reduce(reinterpret_cast<const float*>(ws), dw, (size_t)d->K * p.Ng, pl.splits, beta, st);

@@ -433,10 +433,13 @@ struct ConvStatParams {
     float eps, momentum;
 };
 
-// block = 256 threads = 16 channels x 16 record lanes (a 16-channel row segment of a record is 256 contiguous bytes);
-// grid (C / 16, G or 1): enough blocks to keep the latency of this serial link (conv -> statistics -> normalise) short.
-__global__ __launch_bounds__(256) void finalize_conv_stats_kernel(ConvStatParams p) {
-    __shared__ double sm[16][16][2];
+// block = 1024 threads = 16 channels x 64 record lanes (a 16-channel row segment of a record is 256 contiguous bytes);
+// grid (C / 16, G or 1).  This kernel is a serial link (conv -> statistics -> normalise) in front of EVERY normalisation layer:
+// with 16 record lanes a thread walked ~34 dependent-latency loads (29 us per launch, 16 ms per Cityscapes step); 64 lanes and
+// four loads in flight per thread bring it to a handful of memory latencies.
+constexpr int FCS_LANES = 64;
+__global__ __launch_bounds__(1024) void finalize_conv_stats_kernel(ConvStatParams p) {
+    __shared__ double sm[FCS_LANES][16][2];
     const int cl = threadIdx.x & 15;
     const int w = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -451,31 +454,44 @@ __global__ __launch_bounds__(256) void finalize_conv_stats_kernel(ConvStatParams
         double s = 0.0, q = 0.0;
         if (cok) {
             const int n0 = (t_last - t_first + 1) * p.RPT;          // slot-0 records of the tiles that start inside the group
-            for (int k = w; k < n0; k += 16) {
-                const size_t r = (size_t)t_first * p.RPT + k;
-                const double2 e = *reinterpret_cast<const double2*>(p.rec + ((r * 2 + 0) * p.C + c) * 2);
+            const double* base = p.rec + (((size_t)t_first * p.RPT * 2 + 0) * p.C + c) * 2;
+            const size_t rstride = (size_t)2 * p.C * 2;             // doubles between consecutive records of one slot
+            int k = w;
+            for (; k + 3 * FCS_LANES < n0; k += 4 * FCS_LANES) {    // four independent loads in flight
+                const double2 e0 = *reinterpret_cast<const double2*>(base + (size_t)k * rstride);
+                const double2 e1 = *reinterpret_cast<const double2*>(base + (size_t)(k + FCS_LANES) * rstride);
+                const double2 e2 = *reinterpret_cast<const double2*>(base + (size_t)(k + 2 * FCS_LANES) * rstride);
+                const double2 e3 = *reinterpret_cast<const double2*>(base + (size_t)(k + 3 * FCS_LANES) * rstride);
+                s += (e0.x + e1.x) + (e2.x + e3.x);
+                q += (e0.y + e1.y) + (e2.y + e3.y);
+            }
+            for (; k < n0; k += FCS_LANES) {
+                const double2 e = *reinterpret_cast<const double2*>(base + (size_t)k * rstride);
                 s += e.x; q += e.y;
             }
             if (g > 0 && t_first >= 1 && t_first - 1 < p.valid_tiles) {  // slot 1 of the tile that straddles the lower boundary
-                for (int k = w; k < p.RPT; k += 16) {
-                    const size_t r = (size_t)(t_first - 1) * p.RPT + k;
+                for (int k1 = w; k1 < p.RPT; k1 += FCS_LANES) {
+                    const size_t r = (size_t)(t_first - 1) * p.RPT + k1;
                     const double2 e = *reinterpret_cast<const double2*>(p.rec + ((r * 2 + 1) * p.C + c) * 2);
                     s += e.x; q += e.y;
                 }
             }
             if (p.xrec > 0 && p.xgroup == g) {
-                for (int k = w; k < p.xrec; k += 16) {
-                    const double2 e = *reinterpret_cast<const double2*>(p.xrecs + ((size_t)k * p.C + c) * 2);
+                for (int k2 = w; k2 < p.xrec; k2 += FCS_LANES) {
+                    const double2 e = *reinterpret_cast<const double2*>(p.xrecs + ((size_t)k2 * p.C + c) * 2);
                     s += e.x; q += e.y;
                 }
             }
         }
         sm[w][cl][0] = s; sm[w][cl][1] = q;
         __syncthreads();
-        if (w == 0 && cok) {
-            double a = 0.0, b = 0.0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { a += sm[k][cl][0]; b += sm[k][cl][1]; }
+        for (int st = FCS_LANES / 2; st >= 1; st >>= 1) {           // fixed-shape tree: deterministic
+            if (w < st) { sm[w][cl][0] += sm[w + st][cl][0]; sm[w][cl][1] += sm[w + st][cl][1]; }
+            __syncthreads();
+        }
+        if (w == 0 && cok) {
+            const double a = sm[0][cl][0], b = sm[0][cl][1];
             const int i = g * p.C + c;
             const double m = a / (double)p.L;
             double var = b / (double)p.L - m * m;
@@ -538,7 +554,7 @@ int sscg_finalize_conv_stats(const double* stats, int valid_tiles, int rows_per_
     p.rec = stats; p.xrecs = xrecs; p.mean = mean; p.rstd = rstd; p.rmean = running_mean; p.rvar = running_var;
     p.valid_tiles = valid_tiles; p.BMT = rows_per_tile; p.RPT = records_per_tile; p.xrec = xrec; p.xgroup = xgroup;
     p.G = G; p.C = C; p.L = L; p.eps = eps; p.momentum = momentum;
-    hipLaunchKernelGGL(finalize_conv_stats_kernel, dim3(cdiv(C, 16), running_mean ? 1 : G), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(finalize_conv_stats_kernel, dim3(cdiv(C, 16), running_mean ? 1 : G), dim3(1024), 0, st, p);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

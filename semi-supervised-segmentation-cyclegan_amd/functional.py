@@ -809,6 +809,9 @@ class Conv2dFn(torch.autograd.Function):
         ctx.wref = w
         ctx.bref = bias
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        # (mean, rstd) are non-differentiable outputs: left alone, autograd hands backward() two zero-filled tensors for them -
+        # 850 fill launches per Cityscapes step
+        ctx.set_materialize_grads(False)
         if norm is None:
             return y
         if mean is None:
@@ -818,6 +821,8 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *_unused):
+        if dy is None:          # nothing downstream used y
+            return (None,) * 11
         x, w, y = ctx.saved_tensors
         stride, pad, dil, pad_mode, act, slope = ctx.cfg
         dy = to_nhwc(dy)

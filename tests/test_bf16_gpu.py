@@ -102,6 +102,71 @@ def test_conv_bf16_tensors(case, dev, bf16_mode):
     assert rel(acc - 1.0, wr.grad) < 2e-4
 
 
+TILE_CLASSES = [(100, "128x128/4 waves"), (101, "64x64"), (103, "128x64"), (104, "128x128/8 waves"), (105, "256x128/8 waves")]
+
+
+@pytest.mark.parametrize("cfg", TILE_CLASSES, ids=[c[1].replace(" ", "") for c in TILE_CLASSES])
+@pytest.mark.parametrize("case", [(8, 256, 33, 33, 256, 3, 1, 2, 2, 2), (4, 128, 40, 48, 192, 3, 1, 1, 1, 1), (2, 64, 31, 37, 320, 1, 1, 0, 1, 2)],
+                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_s%d_p%d_d%d_g%d" % c)
+def test_conv_bf16_every_tile_class(case, cfg, dev, bf16_mode):
+    """The planner picks one tile class per shape; here every class (forced through the tuning hook) runs the same
+    convolutions: forward (+ fused BatchNorm statistics over `g` groups), data gradient - against fp64 on the bf16-rounded operands."""
+    F = bf16_mode
+    n, c, h, w, k, r, s, p, d, groups = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, c, h, w, generator=g) + 0.2
+    wt = torch.randn(k, c, r, r, generator=g) * (1.0 / (c * r * r) ** 0.5)
+    b = torch.randn(k, generator=g) * 0.1
+    xr, wr = r16(x).requires_grad_(True), r16(wt)
+    yr = TF.conv2d(xr, wr, b.double(), s, p, d)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(r16(gy))
+    xg, wg, gyg = dev16(x, dev), dev16(wt, dev), dev16(gy, dev)
+    wtt = F.weight_transposed(wg, BF)
+    yv = yr.detach().view(groups, n // groups, k, yr.shape[2], yr.shape[3])
+    mu = yv.mean((1, 3, 4))
+    var = ((yv - mu.view(groups, 1, k, 1, 1)) ** 2).mean((1, 3, 4))
+    F.lib.sscg_debug_set_conv_cfg(cfg[0])
+    try:
+        y = F.conv2d_fwd(xg, wg, b.to(dev), s, p, d, out_f32=True)
+        assert rel(y, yr) < 2e-5
+        y16 = F.conv2d_fwd(xg, wg, b.to(dev), s, p, d, out_f32=False)
+        assert rel(y16, yr) < EPS16
+        dx = F.conv2d_dgrad(gyg, wtt, x.shape, wt.shape, s, p, d, out_dtype=torch.float32)
+        assert rel(dx, xr.grad) < 2e-5
+        per = False if groups == 1 else groups
+        _, mean, rstd = F.conv2d_norm_stats(xg, dev32(wt, dev), b.to(dev), s, p, d, F.PAD_ZEROS, (per, 1e-5, None, None, 0.1))
+        if mean is not None:          # a class whose tile is taller than a group does not fuse (the caller falls back)
+            scale = float(mu.abs().max() + var.sqrt().max())
+            assert float((mean.double().cpu() - mu).abs().max()) < 1e-4 * scale
+            assert rel(rstd, 1.0 / torch.sqrt(var + 1e-5)) < 1e-4
+    finally:
+        F.lib.sscg_debug_set_conv_cfg(-1)
+
+
+@pytest.mark.parametrize("flags", [(0, "transpose-read"), (1, "register-transposing"), (2, "transpose-read/8 waves")], ids=lambda f: f[1].replace(" ", ""))
+@pytest.mark.parametrize("case", [(8, 256, 33, 33, 256, 3, 1, 2, 2), (2, 64, 65, 65, 64, 3, 1, 1, 1), (2, 256, 33, 33, 1024, 1, 1, 0, 1),
+                                  (2, 128, 32, 32, 256, 4, 2, 1, 1), (3, 72, 19, 23, 136, 3, 1, 1, 1)],
+                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_s%d_p%d_d%d" % c)
+def test_wgrad_bf16_every_kernel(case, flags, dev, bf16_mode):
+    """Weight gradient kernels: LDS-DMA + ds_read_b64_tr_b16 (default; 4 or 8 waves) and the register-transposing one."""
+    F = bf16_mode
+    n, c, h, w, k, r, s, p, d = case
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, c, h, w, generator=g)
+    wr = torch.zeros(k, c, r, r, dtype=torch.float64, requires_grad=True)
+    yr = TF.conv2d(r16(x), wr, None, s, p, d)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(r16(gy))
+    xg, gyg = dev16(x, dev), dev16(gy, dev)
+    F.lib.sscg_debug_set_conv_cfg(0xff | (flags[0] << 16))
+    try:
+        dw = F.conv2d_wgrad(xg, gyg, (k, c, r, r), s, p, d)
+        assert rel(dw, wr.grad) < 2e-5
+    finally:
+        F.lib.sscg_debug_set_conv_cfg(-1)
+
+
 # layers at a network's fp32 boundary: (N, C, H, W, K, R, stride, pad, dil, x_is_f32)
 EDGE = [
     (2, 3, 64, 64, 64, 7, 2, 3, 1, True),       # DeepLab stem: fp32 image in, bf16 out; dgrad into the image

@@ -21,8 +21,7 @@ SHAPES = [(32, 256, 64, 128, 256, 3, 1, 1, 1), (16, 256, 33, 65, 256, 3, 1, 2, 2
           (32, 64, 128, 256, 128, 3, 2, 1, 1), (32, 128, 64, 128, 256, 3, 2, 1, 1), (16, 64, 128, 256, 128, 4, 2, 1, 1),
           (16, 128, 64, 128, 256, 4, 2, 1, 1), (16, 256, 32, 64, 512, 4, 1, 1, 1)]
 # name, forced tile class (100 + cfg; 0xff = planner), tune flags (1 = LDS-DMA pieces spread over the MFMA groups)
-VARIANTS = [("plan", 0xff, 0), ("128x128", 100, 0), ("128x128s3", 104, 0), ("128x128s4", 105, 0), ("256x128s3", 106, 0), ("64x64", 101, 0),
-            ("64x64s4", 107, 0), ("128x64", 103, 0), ("128x64s3", 108, 0)]
+VARIANTS = [("plan", 0xff, 0), ("128x128w8", 104, 0), ("64x64", 101, 0)]
 
 
 def timeit(fn, n=20):
@@ -63,9 +62,9 @@ for (n, c, h, w, k, r, s, p, d) in SHAPES:
             row += " | %-9s f %6.1f d %6.1f" % (name, flops / tf / 1e9, flops / td / 1e9)
         finally:
             F.lib.sscg_debug_set_conv_cfg(-1)
-    # weight gradient: register-transposing kernel (flag 1) vs LDS-DMA + transpose-read kernel with 3 (default) / 2 / 4 copy stages
+    # weight gradient: register-transposing kernel (flag 1) vs LDS-DMA + transpose-read kernel with 2 (default) / 3-4 copy stages
     dw_ref = None
-    for name, tune in (("wg-old", 1), ("wg-s3", 0), ("wg-s2", 2), ("wg-s4", 4)):
+    for name, tune in (("wg-old", 1), ("wg8-768", 0), ("wg4", 2), ("wg8-512", 4 << 4), ("wg8-1024", 8 << 4), ("wg8-1536", 12 << 4), ("wg8-384", 3 << 4)):
         F.lib.sscg_debug_set_conv_cfg(0xff | (tune << 16))
         try:
             dw = F.conv2d_wgrad(x, gy, wt.shape, s, p, d)

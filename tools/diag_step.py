@@ -25,6 +25,7 @@ ap.add_argument("--no-sync", action="store_true", help="no host synchronisation 
 ap.add_argument("--no-fork", action="store_true")
 ap.add_argument("--no-side", action="store_true", help="everything on one stream")
 ap.add_argument("--no-stack", action="store_true")
+ap.add_argument("--time-only", action="store_true", help="with --no-sync: no per-step health record (it orders the main stream behind the D stream)")
 a = ap.parse_args()
 cfg = bench.CONFIGS[a.config]
 dtype = a.dtype or cfg["dtype"]
@@ -54,10 +55,15 @@ def bad(t):
     return int((~torch.isfinite(t)).sum())
 
 
+import time  # noqa: E402
 trace = []
+t_start = None
 for s in range(a.steps):
+    if s == 2:
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
     out = m.step(lab[s][0], lab[s][1], unl[s][0])
-    if a.no_sync:      # device-side health record, no host synchronisation: [9 losses, non-finite counts of G.grad, D.grad, G.w]
+    if a.no_sync and not a.time_only:      # device-side health record, no host synchronisation: [9 losses, non-finite counts of G.grad, D.grad, G.w]
         cur = torch.cuda.current_stream(dev)
         if args.overlap_d:
             cur.wait_stream(F.d_stream(dev))
@@ -89,4 +95,7 @@ if trace:
         v = r.cpu().tolist()
         print("trace step %d: losses finite %s  G.grad bad %d  D.grad bad %d  G.w bad %d  | %s" % (
             i, all(x == x and abs(x) != float("inf") for x in v[:9]), v[9], v[10], v[11], " ".join("%.3g" % x for x in v[:9])))
+if t_start is not None and a.no_sync:
+    torch.cuda.synchronize()
+    print("%.2f ms/step over steps 2..%d" % ((time.perf_counter() - t_start) * 1e3 / (a.steps - 2), a.steps - 1))
 print("peak memory %.1f GB" % (torch.cuda.max_memory_allocated() / 2 ** 30))

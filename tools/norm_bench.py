@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Effective HBM bandwidth of the normalisation / pointwise kernels on the tensor shapes of BASELINE config 3 (tuning aid).
+usage: python tools/norm_bench.py [out.txt]      - GB/s = algorithmic bytes (tensors read + written once) / time"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+F = importlib.import_module("semi-supervised-segmentation-cyclegan_amd.functional")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+CL = torch.channels_last
+BF = torch.bfloat16
+# (N, C, H, W, per_sample): DeepLab BatchNorm maps (per_sample False / 2 groups) and ResnetGenerator InstanceNorm maps
+SHAPES = [(16, 256, 33, 65, False), (16, 1024, 33, 65, False), (32, 256, 33, 65, 2), (32, 1024, 33, 65, 2), (16, 512, 33, 65, False),
+          (16, 2048, 33, 65, False), (16, 64, 65, 129, False), (16, 256, 65, 129, False), (32, 256, 64, 128, True),
+          (32, 128, 128, 256, True), (32, 64, 256, 512, True), (16, 128, 256, 512, True)]
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+out = open(sys.argv[1], "w") if len(sys.argv) > 1 else sys.stdout
+for (n, c, h, w, per) in SHAPES:
+    x = torch.randn(n, c, h, w, device=dev).to(BF).contiguous(memory_format=CL)
+    res = torch.randn(n, c, h, w, device=dev).to(BF).contiguous(memory_format=CL)
+    dy = torch.randn(n, c, h, w, device=dev).to(BF).contiguous(memory_format=CL)
+    gamma = torch.ones(c, device=dev)
+    beta = torch.zeros(c, device=dev)
+    nb = x.numel() * 2
+    mean, rstd = F.norm_stats(x, per)
+    y = F.norm_apply(x, mean, rstd, gamma, beta, None, per, F.ACT_RELU)
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    t_stats = timeit(lambda: F.norm_stats(x, per))
+    t_apply = timeit(lambda: F.norm_apply(x, mean, rstd, gamma, beta, None, per, F.ACT_RELU))
+    t_apply_r = timeit(lambda: F.norm_apply(x, mean, rstd, gamma, beta, res, per, F.ACT_RELU))
+    t_bwd = timeit(lambda: F.norm_bwd(dy, x, y, mean, rstd, gamma, per, F.ACT_RELU, 0.0, True, False, dg, db))
+    t_bwd_r = timeit(lambda: F.norm_bwd(dy, x, y, mean, rstd, gamma, per, F.ACT_RELU, 0.0, True, True, dg, db))
+    t_add = timeit(lambda: F.add(x, res))
+    row = "%-28s %7.1f MB | stats %6.1f us %5.0f GB/s | apply %6.1f us %5.0f | apply+res %6.1f us %5.0f | bwd %6.1f us %5.0f | bwd+dres %6.1f us %5.0f | add %6.1f us %5.0f" % (
+        "%dx%dx%dx%d g=%s" % (n, c, h, w, per), nb / 1e6, t_stats * 1e3, nb / t_stats / 1e6, t_apply * 1e3, 2 * nb / t_apply / 1e6,
+        t_apply_r * 1e3, 3 * nb / t_apply_r / 1e6, t_bwd * 1e3, 7 * nb / t_bwd / 1e6, t_bwd_r * 1e3, 8 * nb / t_bwd_r / 1e6,
+        t_add * 1e3, 3 * nb / t_add / 1e6)
+    out.write(row + "\n")
+    out.flush()
