@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-elided", action="store_true")
+    ap.add_argument("--no-small", action="store_true", help="skip the 64x64 batch-2 host-bound figure")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--dtype", choices=["f32", "bf16", "bf16c"], default=None, help="default: the configuration's")
     ap.add_argument("--no-bf16", action="store_true", help="config 2: skip the secondary bf16 figure")
@@ -108,10 +109,13 @@ def main():
         out = None
         for i in range(first, first + count):
             out = run(i)
+        host[0] = (time.perf_counter() - t0) / count      # the host thread is free again: pure issue cost of a step
         torch.cuda.synchronize()
         if dp:
             dp.barrier()
         return par.max_over_ranks(time.perf_counter() - t0), out
+
+    host = [0.0]
 
     for i in range(a.warmup):
         run(i)
@@ -130,6 +134,7 @@ def main():
         "step_conv_tflops": round(world * bsz * cfg["tflop_per_pair"] * a.steps / dt, 2),
         "step_frac_of_mfma_peak": round(bsz * cfg["tflop_per_pair"] * a.steps / dt / peak, 4),
         "mfma_peak_tflops": peak,
+        "host_issue_ms_per_step": round(1e3 * host[0], 2),
     }
 
     # secondary figure (BASELINE.md section 2 / SURVEY 8(d)): the same step without the forwards whose outputs the
@@ -151,6 +156,29 @@ def main():
         out["bf16"] = {"value": round(world * bsz * a.steps / dtb, 4), "unit": "img/s", "ms_per_step": round(1e3 * dtb / a.steps, 3),
                        "losses_finite": all(bool(torch.isfinite(v)) for v in lb.values()),
                        "note": "not the headline (this configuration is fp32): " + DTYPE_TEXT["bf16"]}
+
+    # The reference's own default is batch 2 (main.py:14) on small crops: there the step is bound by the host's issue rate, not by
+    # the GPU.  One line beside the headline, single rank only (a second, small model: 64x64, batch 2, same dtype).
+    if world == 1 and not a.no_small:
+        sargs = cli.get_args(["--model", "semisupervised_cycleGAN", "--dataset", cfg["dataset"], "--crop_height", "64", "--crop_width", "64",
+                              "--batch_size", "2", "--checkpoint_dir", "/tmp/sscg_bench_ckpt_small", "--dtype", dtype])
+        sargs.gpu_ids, sargs.as_written, sargs.overlap_d = [local], True, args.overlap_d
+        with contextlib.redirect_stdout(io.StringIO()):
+            small = md.semisuper_cycleGAN(sargs)
+        sl = list(data.SyntheticLoader(2, C, 64, 64, 14, 3, device=dev))
+        su = list(data.SyntheticLoader(2, C, 64, 64, 14, 4, device=dev))
+        for i in range(4):
+            small.step(sl[i][0], sl[i][1], su[i][0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(4, 14):
+            small.step(sl[i][0], sl[i][1], su[i][0])
+        th = (time.perf_counter() - t0) / 10
+        torch.cuda.synchronize()
+        ts = (time.perf_counter() - t0) / 10
+        out["host_bound_case"] = {"workload": "the same step at 64x64, batch 2 (main.py:14 default batch)", "ms_per_step": round(1e3 * ts, 2),
+                                  "host_issue_ms_per_step": round(1e3 * th, 2), "value": round(2 / ts, 2), "unit": "img/s"}
+        del small, sl, su
 
     if not a.no_roofline:
         # per-kernel timing needs the kernels one at a time: the side stream (concurrent weight gradients /

@@ -328,6 +328,25 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         const int g0 = m0 / p.stat_L;
         gb = (g0 + 1) * p.stat_L;
     }
+    // tiles inside one group and inside the tensor (nearly all): four consecutive rows are summed in fp32, the 4-row sums in fp64
+    const bool slow_stats = want_stats && (m0 + BM > gb || m0 + BM > p.M);
+    const bool fast_stats = want_stats && !slow_stats;
+    auto fast_sums = [&](int j, float bv, double& s0, double& q0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float pre = acc[i][j][g4 * 4 + t] + bv;
+                    a += pre;
+                    b = fmaf(pre, pre, b);
+                }
+                s0 += (double)a; q0 += (double)b;
+            }
+        }
+    };
     // bf16 results leave through LDS: in the MFMA layout a lane owns single elements of 16 x TM x TN different rows - 64 two-byte
     // stores per lane and tile, each wave-instruction touching 2 x 64 B.  Staged as an fp32 [BM][BN + 4] tile (the k-loop is
     // over, its images are dead), every thread then writes 16 bytes = 8 consecutive channels: 8x fewer, full-width stores.
@@ -353,6 +372,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             const bool nok = n < p.Ng;
             const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
             double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+            if (fast_stats) fast_sums(j, bv, s0, q0);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -360,7 +380,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                     const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
                     const int m = m0 + row_w + 4 * lh + ro;
                     const float pre = acc[i][j][e] + bv;
-                    if (want_stats && m < p.M) {
+                    if (slow_stats && m < p.M) {
                         const double d = (double)pre;
                         if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
                     }
@@ -405,6 +425,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         const bool nok = n < p.Ng;
         const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
         double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+        if (fast_stats) fast_sums(j, bv, s0, q0);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                         p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc[i][j][e];
                     } else {
                         const float pre = acc[i][j][e] + bv;
-                        if (want_stats) {
+                        if (slow_stats) {
                             const double d = (double)pre;
                             if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
                         }
@@ -1141,7 +1162,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
 
 struct Wg16Plan { int cfg, bm, bn, splits, chunk; };
 
-// Split of the pixel range: enough workgroups for ~3 rounds of the 256 CUs, at least 4 k-steps each.
+// Split of the pixel range.  The 128x128 kernel (8 waves, 64 KB of LDS) runs two workgroups per CU: the split is the largest that
+// still fits ONE round of 512 workgroups (256-channel 3x3: 36 tiles x 14 = 504; one more split = 540 workgroups = a second, nearly
+// empty round: 690 -> 560 TF/s); the 64x64 kernel holds four per CU.  At least 4 k-steps per workgroup.
 Wg16Plan plan_wg16(const sscg_conv_desc* d) {
     Wg16Plan pl;
     const int Kc = d->K, Ng = d->R * d->S * d->C;
@@ -1150,9 +1173,8 @@ Wg16Plan plan_wg16(const sscg_conv_desc* d) {
     pl.cfg = (Kc >= 128 && Ng >= 128 && (long)cdiv(Kc, 128) * cdiv(Ng, 128) >= 8) ? 0 : 1;
     pl.bm = pl.bn = pl.cfg == 0 ? 128 : 64;
     const long tiles = (long)cdiv(Kc, pl.bm) * cdiv(Ng, pl.bn);
-    // workgroups aimed at: tools/conv16_bench.py sweeps this through the tuning flags (bits 4..7 = target / 128)
-    const long target = ((sscg_tune_flags >> 4) & 15) ? 128L * ((sscg_tune_flags >> 4) & 15) : 768;
-    long s = cdiv(target, tiles);
+    const long slots = ((sscg_tune_flags >> 4) & 15) ? 128L * ((sscg_tune_flags >> 4) & 15) : (pl.cfg == 0 ? 512 : 1024);   // bits 4..7: tools/conv16_bench.py
+    long s = slots / tiles;
     if (s > steps / 4) s = steps / 4;
     if (s > 1024) s = 1024;
     if (s < 1) s = 1;

@@ -58,11 +58,15 @@ def bad(t):
 import time  # noqa: E402
 trace = []
 t_start = None
+host_s = 0.0
 for s in range(a.steps):
     if s == 2:
         torch.cuda.synchronize()
         t_start = time.perf_counter()
+    t_h = time.perf_counter()
     out = m.step(lab[s][0], lab[s][1], unl[s][0])
+    if s >= 2:
+        host_s += time.perf_counter() - t_h
     if a.no_sync and not a.time_only:      # device-side health record, no host synchronisation: [9 losses, non-finite counts of G.grad, D.grad, G.w]
         cur = torch.cuda.current_stream(dev)
         if args.overlap_d:
@@ -97,5 +101,6 @@ if trace:
             i, all(x == x and abs(x) != float("inf") for x in v[:9]), v[9], v[10], v[11], " ".join("%.3g" % x for x in v[:9])))
 if t_start is not None and a.no_sync:
     torch.cuda.synchronize()
-    print("%.2f ms/step over steps 2..%d" % ((time.perf_counter() - t_start) * 1e3 / (a.steps - 2), a.steps - 1))
+    print("%.2f ms/step over steps 2..%d; host time inside step(): %.2f ms/step" % (
+        (time.perf_counter() - t_start) * 1e3 / (a.steps - 2), a.steps - 1, host_s * 1e3 / (a.steps - 2)))
 print("peak memory %.1f GB" % (torch.cuda.max_memory_allocated() / 2 ** 30))
