@@ -19,6 +19,7 @@ NETS = [
     ("pixel_3", "pixel", (3,), (2, 3, 32, 32)),
     ("pixel_21", "pixel", (21,), (2, 21, 32, 32)),
     ("nlayers_3", "n_layers", (3,), (2, 3, 64, 64)),
+    ("unet128_3_2", "unet_128", (3, 2), (1, 3, 256, 256)),      # 7 downs: 256 -> 2x2 at the bottleneck (InstanceNorm needs > 1 pixel)
 ]
 
 STEP_CONFIGS = {  # tag -> (classes, dataset, H, W, batch, steps)
@@ -42,6 +43,8 @@ def spec_for(kind, args):
         return nets.resnet_gen_spec_full(args[0], args[1], 64, 9, "instance", use_dropout=False)
     if kind == "pixel":
         return nets.pixel_dis_spec(args[0])
+    if kind == "unet_128":
+        return nets.unet_spec(args[0], args[1], 7, 64, "instance")
     return nets.nlayer_dis_spec(args[0])
 
 
@@ -54,6 +57,8 @@ def oracle_forward(kind, sd, x, taps=None):
         return nets.resnet_generator(sd, x, 9, False, "instance", False)
     if kind == "pixel":
         return nets.pixel_discriminator(sd, x)
+    if kind == "unet_128":
+        return nets.unet_generator(sd, x, 7, "instance")
     return nets.nlayer_discriminator(sd, x)
 
 

@@ -109,6 +109,45 @@ def resnet_gen_spec_full(in_c, out_c, ngf=64, n_blocks=9, norm="instance", use_d
     return s
 
 
+def unet_spec(in_c, out_c, num_downs=7, ngf=64, norm="instance"):
+    """UnetGenerator (arch/generators.py:7-63).  Keys follow the nesting of UnetSkipConnectionBlock.model: the outermost block is
+    [downconv, submodule, ReLU, upconv]; inner blocks [LeakyReLU, downconv, norm, submodule, ReLU, upconv, norm]; the innermost
+    [LeakyReLU, downconv, ReLU, upconv, norm].  ConvTranspose2d weights are [Cin, Cout, 4, 4]."""
+    bias = norm == "instance"
+    s = OrderedDict()
+    # (outer_nc, inner_nc, input_nc) from the outermost block inwards
+    chain = [(out_c, ngf, in_c), (ngf, ngf * 2, ngf), (ngf * 2, ngf * 4, ngf * 2), (ngf * 4, ngf * 8, ngf * 4)]
+    chain += [(ngf * 8, ngf * 8, ngf * 8)] * (num_downs - 5) + [(ngf * 8, ngf * 8, ngf * 8)]
+    pre = "unet_model."
+    for depth, (outer, inner, inp) in enumerate(chain):
+        outermost, innermost = depth == 0, depth == len(chain) - 1
+        if outermost:
+            _conv(s, pre + "model.0", inner, inp, 4, bias)
+            up = (pre + "model.3", inner * 2, outer, True)
+            nxt = pre + "model.1."
+        elif innermost:
+            _conv(s, pre + "model.1", inner, inp, 4, bias)
+            up = (pre + "model.3", inner, outer, bias)
+            nxt = None
+        else:
+            _conv(s, pre + "model.1", inner, inp, 4, bias)
+            if norm == "batch":
+                _bn(s, pre + "model.2", inner)
+            up = (pre + "model.5", inner * 2, outer, bias)
+            nxt = pre + "model.3."
+        pending = (up, pre, outermost, innermost, outer)
+        chain[depth] = pending
+        pre = nxt
+    # the up-convolutions (and their norms) come AFTER the submodule's keys: emit them from the innermost block outwards
+    for (key, cin, cout, b), bpre, outermost, innermost, outer in reversed(chain):
+        s[key + ".weight"] = ((cin, cout, 4, 4), "conv")
+        if b:
+            s[key + ".bias"] = ((cout,), "bias")
+        if not outermost and norm == "batch":
+            _bn(s, bpre + ("model.4" if innermost else "model.6"), outer)
+    return s
+
+
 def pixel_dis_spec(in_c, ndf=64, norm="instance"):
     """PixelDiscriminator (arch/discriminators.py:66-80)."""
     bias = norm == "instance"
@@ -306,6 +345,31 @@ def resnet_generator(sd, x, n_blocks=9, tanh=True, norm="instance", use_dropout=
     y = TF.pad(y, (3, 3, 3, 3), mode="reflect")
     y = q.o(TF.conv2d(y, q.w(sd["res_model.%d.weight" % (t + 3)]), sd["res_model.%d.bias" % (t + 3)]))
     return torch.tanh(y) if tanh else y
+
+
+def unet_generator(sd, x, num_downs=7, norm="instance", train=True):
+    """UnetGenerator.forward (arch/generators.py:7-63).  nn.LeakyReLU(0.2, True) at the head of every inner block's `down` works
+    in place on the block's input, which is also the first operand of the skip concatenation (:44): the skip carries the
+    ACTIVATED tensor.  (nn.ReLU(True) at the head of `up` rewrites the submodule's output, which nobody else reads.)"""
+    def block(pre, h, depth):
+        outermost, innermost = depth == 0, depth == num_downs - 1
+        if outermost:
+            y = TF.conv2d(h, sd[pre + "model.0.weight"], sd.get(pre + "model.0.bias"), 2, 1)
+            y = block(pre + "model.1.", y, depth + 1)
+            return TF.conv_transpose2d(torch.relu(y), sd[pre + "model.3.weight"], sd[pre + "model.3.bias"], 2, 1)
+        ha = TF.leaky_relu(h, 0.2)
+        y = TF.conv2d(ha, sd[pre + "model.1.weight"], sd.get(pre + "model.1.bias"), 2, 1)
+        if innermost:
+            y = TF.conv_transpose2d(torch.relu(y), sd[pre + "model.3.weight"], sd.get(pre + "model.3.bias"), 2, 1)
+            y = _norm(sd, pre + "model.4", y, norm, train)
+        else:
+            y = _norm(sd, pre + "model.2", y, norm, train)
+            y = block(pre + "model.3.", y, depth + 1)
+            y = TF.conv_transpose2d(torch.relu(y), sd[pre + "model.5.weight"], sd.get(pre + "model.5.bias"), 2, 1)
+            y = _norm(sd, pre + "model.6", y, norm, train)
+        return torch.cat([ha, y], 1)
+
+    return block("unet_model.", x, 0)
 
 
 def pixel_discriminator(sd, x, norm="instance", train=True, q=_NOQ):

@@ -2,14 +2,15 @@
 
 In scope: `deeplab` (ResNet-101, output stride 8 - the trained Gis/Gsi, arch/generators.py:320-441)
 and `resnet_{6,9}blocks[_softmax]` (the classic CycleGAN generator - the frozen old_Gis/old_Gsi, :65-95).
-`unet_*`, `enet`, `lednet_*` are never constructed by any driver of the reference and are out of scope
-(SURVEY section 2); asking for them raises.  state_dict keys equal the reference's (checkpoint ABI)."""
+`unet_128` / `unet_256` (:7-63; SURVEY 8(f) N4: reachable through `--gen_net` with `--honour_nets 1`) run on the same kernels.
+`enet`, `lednet_*` are never constructed by any driver of the reference and are out of scope; asking
+for them raises.  state_dict keys equal the reference's (checkpoint ABI)."""
 from torch import nn
 
 from .. import functional as F
 from .._lib import ACT_RELU
-from .ops import (BatchNorm2d, Conv2d, FusedSequential, ReflectionPad2d, ResidualBlock, Tanh, as_norm_layer,
-                  conv_norm_act, conv_norm_relu, dconv_norm_relu, get_norm_layer, init_network)
+from .ops import (BatchNorm2d, Conv2d, ConvTranspose2d, Dropout, FusedSequential, LeakyReLU, ReLU, ReflectionPad2d, ResidualBlock,
+                  Tanh, as_norm_layer, conv_norm_act, conv_norm_relu, dconv_norm_relu, get_norm_layer, init_network)
 
 
 class ResnetGenerator(nn.Module):
@@ -35,6 +36,64 @@ class ResnetGenerator(nn.Module):
 
     def forward(self, x):
         return self.res_model(x)
+
+
+class UnetSkipConnectionBlock(nn.Module):
+    """arch/generators.py:7-45.  x -> cat([x, up(submodule(down(x)))], 1); the outermost block returns up(...) alone.
+
+    The reference's LeakyReLU(0.2, True) at the head of `down` works IN PLACE on x, so the skip branch of every inner block
+    carries the ACTIVATED x (the well-known pix2pix behaviour): restated here explicitly (the activation runs once, both
+    branches read its result)."""
+
+    def __init__(self, outer_nc, inner_nc, input_nc=None, submodule=None, outermost=False, innermost=False,
+                 norm_layer=nn.BatchNorm2d, use_dropout=False):
+        super().__init__()
+        self.outermost = outermost
+        nl = as_norm_layer(norm_layer)
+        use_bias = nl.kind == "instance"
+        if input_nc is None:
+            input_nc = outer_nc
+        downconv = Conv2d(input_nc, inner_nc, 4, 2, 1, bias=use_bias)
+        if outermost:
+            upconv = ConvTranspose2d(inner_nc * 2, outer_nc, 4, 2, 1)
+            upconv.head = True
+            model = [downconv, submodule, ReLU(True), upconv]
+        elif innermost:
+            upconv = ConvTranspose2d(inner_nc, outer_nc, 4, 2, 1, bias=use_bias)
+            model = [LeakyReLU(0.2, True), downconv, ReLU(True), upconv, nl(outer_nc)]
+        else:
+            upconv = ConvTranspose2d(inner_nc * 2, outer_nc, 4, 2, 1, bias=use_bias)
+            model = [LeakyReLU(0.2, True), downconv, nl(inner_nc), submodule, ReLU(True), upconv, nl(outer_nc)]
+            if use_dropout:
+                model.append(Dropout(0.5))
+        self.model = FusedSequential(*model)
+        # everything behind the leading LeakyReLU, as a fused run (not a registered child: the state_dict keys stay the reference's)
+        self.__dict__["_tail"] = None if outermost else FusedSequential(*model[1:])
+
+    def forward(self, x):
+        if self.outermost:
+            return self.model(x)
+        xa = self.model[0](x)                    # the in-place LeakyReLU: both branches see the activated tensor
+        xa, xs = F.split(xa, 2)                  # explicit fan-out: the gradient sum runs in sscg_add
+        return F.cat_channels(xs, self._tail(xa))
+
+
+class UnetGenerator(nn.Module):
+    """arch/generators.py:47-63: num_downs stride-2 4x4 convs down to the bottleneck and back (unet_128: 7, unet_256: 8)."""
+
+    def __init__(self, input_nc, output_nc, num_downs, ngf=64, norm_layer=nn.BatchNorm2d, use_dropout=False):
+        super().__init__()
+        nl = as_norm_layer(norm_layer)
+        block = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=None, norm_layer=nl, innermost=True)
+        for _ in range(num_downs - 5):
+            block = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=block, norm_layer=nl, use_dropout=use_dropout)
+        block = UnetSkipConnectionBlock(ngf * 4, ngf * 8, submodule=block, norm_layer=nl)
+        block = UnetSkipConnectionBlock(ngf * 2, ngf * 4, submodule=block, norm_layer=nl)
+        block = UnetSkipConnectionBlock(ngf, ngf * 2, submodule=block, norm_layer=nl)
+        self.unet_model = UnetSkipConnectionBlock(output_nc, ngf, input_nc=input_nc, submodule=block, outermost=True, norm_layer=nl)
+
+    def forward(self, x):
+        return self.unet_model(x)
 
 
 class Bottleneck(nn.Module):
@@ -119,7 +178,7 @@ class ResNet(nn.Module):
         return self.layer5(x)
 
 
-_OUT_OF_SCOPE = ("unet_128", "unet_256", "enet", "lednet_128", "lednet_256")
+_OUT_OF_SCOPE = ("enet", "lednet_128", "lednet_256")
 
 
 def define_Gen(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, gpu_ids=[0]):
@@ -127,6 +186,8 @@ def define_Gen(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, 
     if netG in ('resnet_9blocks', 'resnet_9blocks_softmax', 'resnet_6blocks', 'resnet_6blocks_softmax'):
         net = ResnetGenerator(input_nc, output_nc, ngf, norm_layer=nl, use_dropout=use_dropout,
                               num_blocks=9 if '9blocks' in netG else 6, softmax=netG.endswith('_softmax'))
+    elif netG in ('unet_128', 'unet_256'):
+        net = UnetGenerator(input_nc, output_nc, 7 if netG == 'unet_128' else 8, ngf, norm_layer=nl, use_dropout=use_dropout)
     elif netG == 'deeplab':
         net = ResNet(in_channels=input_nc, block=Bottleneck, layers=[3, 4, 23, 3], num_classes=output_nc)
     elif netG in _OUT_OF_SCOPE:

@@ -90,8 +90,11 @@ class ConvTranspose2d(nn.Module):
         with torch.no_grad():
             self.weight.copy_(torch.empty(w.shape).normal_(0.0, 0.02))
 
+    head = False     # a network's last layer: fp32 output in bf16 mode (UnetGenerator's outermost up-convolution)
+
     def forward(self, x, act=ACT_NONE, slope=0.0):
-        return F.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope)
+        return F.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope,
+                                  out_f32=self.head)
 
 
 class InstanceNorm2d(nn.Module):

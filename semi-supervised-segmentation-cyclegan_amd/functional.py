@@ -862,7 +862,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
     [Cin][R][S][Cout] - i.e. the [K][R][S][C] weight of a conv Cout->Cin."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, out_pad, act, slope):
+    def forward(ctx, x, w, bias, stride, pad, out_pad, act, slope, out_f32=False):
         x = to_nhwc(x)
         n, cin, h, wd = x.shape
         cin2, cout, r, s = w.shape
@@ -873,7 +873,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
             raise _lib.SscgError("unsupported ConvTranspose2d geometry")
         # the transposed operand copy [Cout][R][S][Cin] comes from the per-parameter cache inside conv2d_dgrad
         y = conv2d_dgrad_param(x, w, (n, cout, oh, ow), (cin, cout, r, s), stride, pad, 1, bias, act, slope,
-                               out_dtype=_out_dtype(False))
+                               out_dtype=_out_dtype(out_f32))
         ctx.cfg = (stride, pad, act, slope)
         ctx.has_bias = bias is not None
         ctx.wref, ctx.bref = w, bias
@@ -910,7 +910,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
             dw = conv2d_wgrad(dy, x, w.shape, stride, pad, 1)
         if want_b and bacc is None:
             db = colsum(n * p * q, k, dy)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class NormActFn(torch.autograd.Function):
@@ -1228,8 +1228,34 @@ def conv2d_norm_stats(x, w, bias, stride, pad, dil, pad_mode, norm):
     return Conv2dFn.apply(x, w, bias, stride, pad, dil, pad_mode, ACT_NONE, 0.0, False, norm)
 
 
-def conv_transpose2d(x, w, bias=None, stride=1, pad=0, out_pad=0, act=ACT_NONE, slope=0.0):
-    return ConvTranspose2dFn.apply(x, w, bias, stride, pad, out_pad, act, slope)
+def conv_transpose2d(x, w, bias=None, stride=1, pad=0, out_pad=0, act=ACT_NONE, slope=0.0, out_f32=False):
+    return ConvTranspose2dFn.apply(x, w, bias, stride, pad, out_pad, act, slope, out_f32)
+
+
+class CatChannelsFn(torch.autograd.Function):
+    """torch.cat([a, b], 1) of two channels-last tensors - the skip connection of UnetSkipConnectionBlock.forward
+    (arch/generators.py:44).  Device copies only (no arithmetic); the gradient is the two channel slices."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_nhwc(a), to_nhwc(b)
+        if a.dtype != b.dtype or a.shape[0] != b.shape[0] or a.shape[2:] != b.shape[2:]:
+            raise _lib.SscgError("cat_channels: tensors of one dtype, batch and spatial size expected")
+        n, ca, h, w = a.shape
+        ctx.ca = ca
+        y = empty_nhwc(n, ca + b.shape[1], h, w, a.device, a.dtype)
+        y[:, :ca].copy_(a)
+        y[:, ca:].copy_(b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = to_nhwc(dy)
+        return dy[:, :ctx.ca].contiguous(memory_format=CL), dy[:, ctx.ca:].contiguous(memory_format=CL)
+
+
+def cat_channels(a, b):
+    return CatChannelsFn.apply(a, b)
 
 
 def instance_norm_act(x, act=ACT_NONE, slope=0.0, residual=None, eps=1e-5, stats=None):

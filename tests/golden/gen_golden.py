@@ -202,7 +202,7 @@ def g1(meta):
 # ------------------------------------------------------------------ G2 networks
 def build_ref(kind, args):
     import arch
-    if kind in ("deeplab", "resnet_9blocks", "resnet_9blocks_softmax"):
+    if kind in ("deeplab", "resnet_9blocks", "resnet_9blocks_softmax", "unet_128"):
         return arch.define_Gen(args[0], args[1], 64, kind, norm="instance", use_dropout=False, gpu_ids=[])
     return arch.define_Dis(args[0], 64, kind, 3, norm="instance", gpu_ids=[])
 

@@ -408,7 +408,7 @@ def _emulated(kind, sd, x, q=None):
     return nets.nlayer_discriminator(sd, x, q=q)
 
 
-IN_NETS = [n for n in FX.NETS if n[1] != "deeplab"]
+IN_NETS = [n for n in FX.NETS if n[1] not in ("deeplab", "unet_128")]      # (the U-Net is an fp32 opt-in: no bf16 emulation of it in oracle/)
 
 
 @pytest.mark.parametrize("net", IN_NETS, ids=[n[0] for n in IN_NETS])

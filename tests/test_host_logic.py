@@ -74,11 +74,25 @@ def test_deeplab_trainable_set_and_frozen_bn():
 def test_out_of_scope_generators_raise():
     import pytest
     arch = load_sub("arch")
-    for name in ("unet_128", "enet", "lednet_256"):
+    for name in ("enet", "lednet_128", "lednet_256"):
         with pytest.raises(NotImplementedError):
             arch.define_Gen(3, 3, 64, name, "instance", False, [])
     with pytest.raises(NotImplementedError):
         arch.define_Dis(3, 64, "nope", 3, "instance", [])
+
+
+def test_unet_state_dict_keys_follow_the_reference_nesting():
+    """UnetGenerator behind define_Gen('unet_128' / 'unet_256'); the keys are the checkpoint ABI
+    (oracle.nets.unet_spec is checked key-for-key against the reference's own module by tests/golden/gen_golden.py)."""
+    from oracle import nets
+    arch = load_sub("arch")
+    for name, downs, norm in (("unet_128", 7, "instance"), ("unet_256", 8, "batch")):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = arch.define_Gen(3, 2, 8, name, norm, False, [])
+        spec = nets.unet_spec(3, 2, downs, 8, norm)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(spec.keys())
+        assert all(tuple(sd[k].shape) == tuple(spec[k][0]) for k in spec)
 
 
 def test_pool_lambda_lr_running_score():

@@ -38,7 +38,7 @@ def gold():
 
 def build(kind, args, dev):
     arch = load_sub("arch")
-    if kind in ("deeplab", "resnet_9blocks", "resnet_9blocks_softmax"):
+    if kind in ("deeplab", "resnet_9blocks", "resnet_9blocks_softmax", "unet_128"):
         return quiet(arch.define_Gen, args[0], args[1], 64, kind, norm="instance", use_dropout=False, gpu_ids=[dev.index or 0])
     return quiet(arch.define_Dis, args[0], 64, kind, 3, norm="instance", gpu_ids=[dev.index or 0])
 
