@@ -283,11 +283,12 @@ class ConvProfile:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, flops, key, e0, e1 in self.records:      # kind = (fwd|dgrad|wgrad, kernel family f32|bf16)
-            s = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0, "shapes": {}})
+        for kind, flops, key, e0, e1, nbytes in self.records:      # kind = (fwd|dgrad|wgrad, kernel family f32|bf16)
+            s = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0, "shapes": {}})
             ms = e0.elapsed_time(e1)
             s["launches"] += 1
             s["flops"] += flops
+            s["bytes"] += nbytes
             s["ms"] += ms
             sh = s["shapes"].setdefault(key, [0, 0.0, 0.0])
             sh[0] += 1
@@ -313,7 +314,11 @@ def _timed(kind, d, fn):
         b16 = d.y_dtype == BF16 and d.w_dtype == BF16
     else:
         b16 = d.x_dtype == BF16 and d.y_dtype == BF16 and d.K >= 32 and d.R * d.S * d.C >= 32
-    prof.records.append(((kind, "bf16" if b16 else "f32"), flops, key, e0, e1))
+    # algorithmic HBM bytes of the launch: every operand read once, the result written once
+    esz = {F32: 4, BF16: 2}
+    nbytes = (d.N * d.H * d.W * d.C * esz[d.x_dtype] + d.N * d.P * d.Q * d.K * esz[d.y_dtype]
+              + d.K * d.R * d.S * d.C * (4 if kind == "wgrad" else esz[d.w_dtype]))
+    prof.records.append(((kind, "bf16" if b16 else "f32"), flops, key, e0, e1, float(nbytes)))
     return r
 
 
