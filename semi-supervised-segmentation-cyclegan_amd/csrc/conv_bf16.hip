@@ -348,8 +348,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         }
     };
     // bf16 results leave through LDS: in the MFMA layout a lane owns single elements of 16 x TM x TN different rows - 64 two-byte
-    // stores per lane and tile, each wave-instruction touching 2 x 64 B.  Staged as an fp32 [BM][BN + 4] tile (the k-loop is
-    // over, its images are dead), every thread then writes 16 bytes = 8 consecutive channels: 8x fewer, full-width stores.
+    // stores per lane and tile, each wave-instruction touching 2 x 64 B.  Staged through LDS (the k-loop is over, its images
+    // are dead), every thread then writes 16 bytes = 8 consecutive channels of a row: 8x fewer, full-width stores.
     const bool staged = STAGE_OUT && !partial && p.out_bf16;
     auto put_stats = [&](int n, bool nok, double s0, double q0, double s1, double q1) {
         // the two lane halves hold different rows of the same column
@@ -363,9 +363,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         }
     };
     if (staged) {
+        // The staging tile holds bf16 PAIRS: a lane's registers 4g, 4g+1 (and 4g+2, 4g+3) are two consecutive rows of one column -
+        // converted and packed into one word they halve the ds_write_b32 count (the 64 B/clk store path is what a short-k 1x1
+        // conv's epilogue waits for) and the tile (33 KB).  Word [row / 2][column]: low half = even row, high half = odd row.
         constexpr int OLD = BN + 4;
-        float* ot = reinterpret_cast<float*>(smem_raw);
-        float* ob = ot + (row_w + 4 * lh) * OLD + col_w + li;        // this lane's corner; every element is a constant offset away
+        uint32_t* ot = reinterpret_cast<uint32_t*>(smem_raw);
+        uint32_t* ob = ot + ((row_w + 4 * lh) / 2) * OLD + col_w + li;        // this lane's corner; every word is a constant offset away
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + col_w + j * 32 + li;
@@ -376,45 +379,73 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
+                for (int e = 0; e < 16; e += 2) {
+                    const int ro = i * 32 + (e & 3) + 8 * (e >> 2);           // even: rows ro, ro + 1
                     const int m = m0 + row_w + 4 * lh + ro;
-                    const float pre = acc[i][j][e] + bv;
-                    if (slow_stats && m < p.M) {
-                        const double d = (double)pre;
-                        if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
+                    const float pre0 = acc[i][j][e] + bv, pre1 = acc[i][j][e + 1] + bv;
+                    if (slow_stats) {
+                        if (m < p.M) {
+                            const double d = (double)pre0;
+                            if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
+                        }
+                        if (m + 1 < p.M) {
+                            const double d = (double)pre1;
+                            if (m + 1 < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
+                        }
                     }
-                    ob[ro * OLD + j * 32] = sscg_act(pre, p.act, p.slope);
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                    const f32x2_t pr = {sscg_act(pre0, p.act, p.slope), sscg_act(pre1, p.act, p.slope)};
+                    const bf16x2_t pk = __builtin_convertvector(pr, bf16x2_t);      // RNE, v_cvt_pk_bf16_f32
+                    ob[(ro / 2) * OLD + j * 32] = __builtin_bit_cast(uint32_t, pk);
                 }
             }
             if (want_stats) put_stats(n, nok, s0, q0, s1, q1);
         }
         __syncthreads();
-        constexpr int TPR = BN / 8;             // threads per output row (8 channels = 16 bytes each)
-        constexpr int RPP = NT / TPR;           // rows per pass
+        constexpr int TPR = BN / 8;             // threads per row PAIR (8 channels = two 16-byte row segments each)
+        constexpr int RPP = NT / TPR;           // row pairs per pass
         const int c8 = (tid % TPR) * 8;
         const int n = n0 + c8;
         bf16* out = reinterpret_cast<bf16*>(p.dst);
-        const float* src = ot + (tid / TPR) * OLD + c8;
+        const uint32_t* src = ot + (tid / TPR) * OLD + c8;
+        auto out_row = [&](int m) -> size_t {
+            if (p.o_step == 1) return (size_t)m;
+            const int img = m / (p.OH * p.OW);          // parity class of a strided data gradient: rows interleave into dx
+            const int rem = m - img * (p.OH * p.OW);
+            const int oi = rem / p.OW;
+            const int oj = rem - oi * p.OW;
+            return (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+        };
 #pragma unroll
-        for (int ps = 0; ps < BM / RPP; ++ps) {
-            const int m = m0 + tid / TPR + ps * RPP;
+        for (int ps = 0; ps < (BM / 2 + RPP - 1) / RPP; ++ps) {
+            const int pr = tid / TPR + ps * RPP;
+            if ((BM / 2) % RPP != 0 && pr >= BM / 2) continue;
+            const int m = m0 + 2 * pr;
             if (m >= p.M || n >= p.Ng) continue;
-            size_t row = (size_t)m;
-            if (p.o_step != 1) {
-                const int img = m / (p.OH * p.OW);
-                const int rem = m - img * (p.OH * p.OW);
-                const int oi = rem / p.OW;
-                const int oj = rem - oi * p.OW;
-                row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
-            }
-            float v[8];
-            ld4<float>(src + ps * RPP * OLD, v);
-            ld4<float>(src + ps * RPP * OLD + 4, v + 4);
-            if (n + 8 <= p.Ng) {
-                st8<bf16>(out + row * p.Ng + n, v);
+            const uint4 w0 = *reinterpret_cast<const uint4*>(src + ps * RPP * OLD);
+            const uint4 w1 = *reinterpret_cast<const uint4*>(src + ps * RPP * OLD + 4);
+            uint4 lo, hi;      // v_perm_b32 D, S0, S1, sel: byte i of D = byte sel[i] of {S0 (bytes 4-7), S1 (bytes 0-3)}
+            lo.x = __builtin_amdgcn_perm(w0.y, w0.x, 0x05040100u); hi.x = __builtin_amdgcn_perm(w0.y, w0.x, 0x07060302u);
+            lo.y = __builtin_amdgcn_perm(w0.w, w0.z, 0x05040100u); hi.y = __builtin_amdgcn_perm(w0.w, w0.z, 0x07060302u);
+            lo.z = __builtin_amdgcn_perm(w1.y, w1.x, 0x05040100u); hi.z = __builtin_amdgcn_perm(w1.y, w1.x, 0x07060302u);
+            lo.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x05040100u); hi.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x07060302u);
+            const bool full = n + 8 <= p.Ng;
+            bf16* r0 = out + out_row(m) * p.Ng + n;
+            if (full) {
+                *reinterpret_cast<uint4*>(r0) = lo;
             } else {
-                for (int e = 0; e < 8 && n + e < p.Ng; ++e) out[row * p.Ng + n + e] = (bf16)v[e];
+                const uint32_t wv[4] = {lo.x, lo.y, lo.z, lo.w};
+                for (int e = 0; e < 8 && n + e < p.Ng; ++e) reinterpret_cast<uint16_t*>(r0)[e] = (uint16_t)(wv[e >> 1] >> (16 * (e & 1)));
+            }
+            if (m + 1 < p.M) {
+                bf16* r1 = out + out_row(m + 1) * p.Ng + n;
+                if (full) {
+                    *reinterpret_cast<uint4*>(r1) = hi;
+                } else {
+                    const uint32_t wv[4] = {hi.x, hi.y, hi.z, hi.w};
+                    for (int e = 0; e < 8 && n + e < p.Ng; ++e) reinterpret_cast<uint16_t*>(r1)[e] = (uint16_t)(wv[e >> 1] >> (16 * (e & 1)));
+                }
             }
         }
         return;
@@ -564,7 +595,7 @@ int launch16(const K16Params& p0, hipStream_t st) {
     const int tiles_m = cdiv(p.M, BM);
     p.tiles = tiles_m * p.tiles_n;
     size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(bf16);
-    const size_t stage = BN >= 64 ? (size_t)BM * (BN + 4) * sizeof(float) : 0;      // output tile of the staged epilogue
+    const size_t stage = BN >= 64 ? (size_t)(BM / 2) * (BN + 4) * sizeof(uint32_t) : 0;      // output tile of the staged epilogue (bf16 row pairs)
     if (stage > smem) smem = stage;
     auto kern = conv16_kernel<MODE, WM, WN, TM, TN, NSTAGE>;
     if (smem > 64 * 1024) {

@@ -505,7 +505,10 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     // Nearly every tile lies inside one group and inside the tensor: its sums are taken four rows at a time in fp32 (a lane's
     // registers 4g .. 4g+3 are four consecutive rows) and only the 4-row sums go to fp64 - a quarter of the fp64 work of the
     // element-wise walk, which cost the short-k 1x1 convs 8 % (relative error of a 4-term fp32 sum: 1e-7, not accumulating).
-    const bool slow_stats = want_stats && (m0 + BM > gb || m0 + BM > p.M);
+    // fp32 tensors take the 4-row shortcut only with bf16-rounded contractions (precision 1: the stems of the bf16 networks);
+    // the exact-fp32 path keeps every element in fp64: a 1e-7 change of a BatchNorm statistic is one more sample of DeepLab's
+    // chaotic fp32 trajectory, and the chained-loss parity test (4 x the reference's own fp32 noise) then sits on its edge.
+    const bool slow_stats = want_stats && (p.precision == 0 || m0 + BM > gb || m0 + BM > p.M);
     const bool fast_stats = want_stats && !slow_stats;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

@@ -220,7 +220,7 @@ class semisuper_cycleGAN(object):
         gen_loss = F.weighted_sum(
             [lab_loss_CE, lab_loss_MSE, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss] + extra_terms,
             [a.lab_CE_weight, a.lab_MSE_weight, a.adversarial_weight, a.adversarial_weight, 1.0, a.lamda_gt] + extra_weights)
-        gen_loss.backward()                                                          # :472
+        F.backward(gen_loss)                                                         # :472
         F.ForkStream.join(l_img.device)
         F.SideStream.join(l_img.device)            # side stream: weight gradients + frozen generators are complete
         resnet_recon_img.record_stream(torch.cuda.current_stream(l_img.device))
@@ -301,7 +301,7 @@ class semisuper_cycleGAN(object):
         cycle_img_dis_loss = F.weighted_sum([r_c, f_c], [1.0, 1.0])                  # :534
         dis_loss = F.weighted_sum([img_dis_loss, gt_dis_loss, cycle_img_dis_loss],
                                   [a.discriminator_weight, a.discriminator_weight, 1.0])  # :538
-        dis_loss.backward()                                                          # :539
+        F.backward(dis_loss)                                                         # :539
         F.SideStream.join(l_img.device)
         if self.dp is not None:
             self.dp.sync_grads(self.d_optimizer)
@@ -412,7 +412,7 @@ class supervised_model(object):
         self.gsi_optimizer.zero_grad()
         out = F.upsample_bilinear(self.Gsi(l_img), self.crop)
         loss = F.cross_entropy(out, l_gt.reshape(l_gt.shape[0], l_gt.shape[2], l_gt.shape[3]))
-        loss.backward()
+        F.backward(loss)
         if self.dp is not None:
             F.SideStream.join(l_img.device)
             self.dp.sync_grads(self.gsi_optimizer)

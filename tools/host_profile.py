@@ -19,6 +19,7 @@ import bench  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--single-thread-backward", action="store_true", help="run the autograd engine on the calling thread (its Python time becomes visible)")
 ap.add_argument("out", nargs="?")
 a = ap.parse_args()
 PKG = bench.PKG
@@ -30,6 +31,8 @@ args = cli.get_args(["--model", "semisupervised_cycleGAN", "--dataset", "citysca
                      "--batch_size", "2", "--checkpoint_dir", "/tmp/sscg_hp_ckpt", "--dtype", a.dtype])
 args.gpu_ids, args.as_written, args.overlap_d = [0], True, True
 torch.cuda.set_device(0)
+if a.single_thread_backward:
+    torch.autograd.set_multithreading_enabled(False)
 F.set_conv_precision(a.dtype)
 with contextlib.redirect_stdout(io.StringIO()):
     m = md.semisuper_cycleGAN(args)
@@ -40,6 +43,13 @@ unl = list(data.SyntheticLoader(2, 20, 64, 64, n, 2, device=dev))
 for i in range(4):
     m.step(lab[i][0], lab[i][1], unl[i][0])
 torch.cuda.synchronize()
+import time  # noqa: E402
+t0 = time.perf_counter()
+for i in range(4, n):
+    m.step(lab[i][0], lab[i][1], unl[i][0])
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print("host issue time without the profiler: %.2f ms/step" % ((t1 - t0) * 1e3 / a.steps))
 pr = cProfile.Profile()
 pr.enable()
 for i in range(4, n):
