@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 6
+#define SSCG_ABI_VERSION 7
 
 /* element types of activation / weight tensors */
 #define SSCG_F32 0
@@ -129,12 +129,14 @@ int sscg_norm_apply(const void* x, const float* mean, const float* rstd, const f
 /* eval-mode BatchNorm: mean = running_mean, rstd = 1/sqrt(running_var + eps) */
 int sscg_rstd_from_var(const float* var, float* rstd, int n, float eps, void* stream);
 /* backward of norm_apply (+ of the statistics): dx always; dres (= masked dy) if non-NULL;
- * dgamma/dbeta accumulate (+=) if non-NULL.  `y` (the forward output) supplies the activation mask.
+ * dgamma/dbeta accumulate (+=) if non-NULL.  `y` (the forward output) supplies the activation mask; with ReLU / LeakyReLU
+ * and NO residual in the forward, y may be NULL: the mask is then recomputed as gamma * xhat + beta > 0 (the forward's own
+ * expression; beta is only read in that case) and the kernels read one tensor less.
  * With stats_grad == 0 the statistics are treated as constants (eval-mode BN). */
 size_t sscg_norm_bwd_workspace(int G, int64_t L, int C);
 int sscg_norm_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
-                  const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int dtype, int G, int64_t L, int C,
-                  int act, float slope, int stats_grad, void* ws, size_t ws_bytes, void* stream);   /* dy, x, y, dx, dres share `dtype` */
+                  const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int dtype, int G,
+                  int64_t L, int C, int act, float slope, int stats_grad, void* ws, size_t ws_bytes, void* stream);   /* dy, x, y, dx, dres share `dtype` */
 
 /* ------------------------------------------------------------------ pointwise / pooling / resize */
 /* standalone activation (nn.ReLU / nn.LeakyReLU / nn.Tanh not adjacent to a norm) */

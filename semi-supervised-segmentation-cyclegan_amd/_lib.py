@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 F32, BF16 = 0, 1     # SSCG_F32 / SSCG_BF16
 
@@ -61,7 +61,7 @@ SIGNATURES = {
     "sscg_norm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _p]),
     "sscg_rstd_from_var": (_i, [_p, _p, _i, _f, _p]),
     "sscg_norm_bwd_workspace": (_sz, [_i, _i64, _i]),
-    "sscg_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
+    "sscg_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
     "sscg_act_fwd": (_i, [_p, _p, _i, _i64, _i, _f, _p]),
     "sscg_act_bwd": (_i, [_p, _p, _p, _i, _i64, _i, _f, _p]),
     "sscg_add": (_i, [_p, _p, _p, _i, _i64, _p]),

@@ -21,6 +21,8 @@ struct RedParams {
     const void* __restrict__ y;      // BWD: forward output (activation mask)
     const float* __restrict__ mean;  // BWD [G][C]
     const float* __restrict__ rstd;  // BWD [G][C]
+    const float* __restrict__ gamma; // BWD, y == NULL: the activation mask is recomputed as gamma * xhat + beta > 0
+    const float* __restrict__ beta;
     double* __restrict__ part;       // [G][chunks][C][2]
     long L;
     int C;
@@ -73,17 +75,22 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s0[e] = 0.0; s1[e] = 0.0; }
 
-    float mu[VEC], rs[VEC];
+    float mu[VEC], rs[VEC], ga[VEC], be[VEC];
+    const bool remask = MODE == RM_BWD && p.act != SSCG_ACT_NONE && p.y == nullptr;   // no residual joined the forward: y = act(gamma * xhat + beta)
     if (MODE == RM_BWD && cok) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { mu[e] = p.mean[(size_t)g * p.C + c + e]; rs[e] = p.rstd[(size_t)g * p.C + c + e]; }
+        for (int e = 0; e < VEC; ++e) {
+            mu[e] = p.mean[(size_t)g * p.C + c + e]; rs[e] = p.rstd[(size_t)g * p.C + c + e];
+            ga[e] = (remask && p.gamma) ? p.gamma[c + e] : 1.f;
+            be[e] = (remask && p.beta) ? p.beta[c + e] : 0.f;
+        }
     }
 
     if (cok) {
         const long r_begin = (long)chunk * p.rows_per_chunk;
         const long r_end = min(p.L, r_begin + p.rows_per_chunk);
         const size_t base = (size_t)g * p.L * p.C + c;
-        const bool has_y = MODE == RM_BWD && p.act != SSCG_ACT_NONE;  // y may be NULL without an activation
+        const bool has_y = MODE == RM_BWD && p.act != SSCG_ACT_NONE && !remask;  // y may be NULL without an activation / with the recomputed mask
         for (long r0 = r_begin + rl; r0 < r_end; r0 += (long)RW * U) {
             float xv[U][VEC], dv[U][VEC], yv[U][VEC];
             bool ok[U];
@@ -114,8 +121,10 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
                         s0[e] += d;
                         s1[e] += d * d;
                     } else {
-                        float gg = act_grad(dv[u][e], yv[u][e], p.act, p.slope);
                         float xh = (xv[u][e] - mu[e]) * rs[e];
+                        float ym = yv[u][e];
+                        if (remask) ym = xh * ga[e] + be[e];      // the forward's own expression (norm_apply_kernel): same sign
+                        float gg = act_grad(dv[u][e], ym, p.act, p.slope);
                         s0[e] += (double)gg;
                         s1[e] += (double)gg * (double)xh;
                     }
@@ -337,6 +346,7 @@ struct BwdApplyParams {
     const float* __restrict__ mean;
     const float* __restrict__ rstd;
     const float* __restrict__ gamma;
+    const float* __restrict__ beta;  // y == NULL with an activation: mask recomputed as gamma * xhat + beta > 0
     const float* __restrict__ coef;  // [G][C][2] or null when stats are constants
     void* __restrict__ dx;
     void* __restrict__ dres;
@@ -362,19 +372,21 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdApplyParams p) {
         const int c = ((int)i - row * CG) * VEC;
         const int g = fd_div(row, p.div_l);
         const size_t o = (size_t)i * VEC;
+        const bool remask = p.act != SSCG_ACT_NONE && py == nullptr;
         float dv[VEC], xv[VEC], yv[VEC];
         ldv<T, VEC>(pdy + o, dv);
         ldv<T, VEC>(px + o, xv);
-        if (p.act != SSCG_ACT_NONE) ldv<T, VEC>(py + o, yv);
+        if (p.act != SSCG_ACT_NONE && !remask) ldv<T, VEC>(py + o, yv);
         float gx[VEC], gr[VEC];
-        float mu[VEC], rsv[VEC], ga[VEC], c1[VEC], c2[VEC];
+        float mu[VEC], rsv[VEC], ga[VEC], be[VEC], c1[VEC], c2[VEC];
         const size_t s = (size_t)g * p.C + c;
         ldv<float, VEC>(p.rstd + s, rsv);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { ga[e] = 1.f; mu[e] = 0.f; c1[e] = 0.f; c2[e] = 0.f; }
+        for (int e = 0; e < VEC; ++e) { ga[e] = 1.f; be[e] = 0.f; mu[e] = 0.f; c1[e] = 0.f; c2[e] = 0.f; }
         if (p.gamma) ldv<float, VEC>(p.gamma + c, ga);
+        if (remask && p.beta) ldv<float, VEC>(p.beta + c, be);
+        if (p.coef || remask) ldv<float, VEC>(p.mean + s, mu);
         if (p.coef) {
-            ldv<float, VEC>(p.mean + s, mu);
             if constexpr (VEC == 1) {
                 c1[0] = p.coef[s * 2]; c2[0] = p.coef[s * 2 + 1];
             } else {
@@ -387,13 +399,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdApplyParams p) {
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float gg = p.act != SSCG_ACT_NONE ? act_grad(dv[e], yv[e], p.act, p.slope) : dv[e];
+            const float xh = (xv[e] - mu[e]) * rsv[e];
+            float ym = yv[e];
+            if (remask) ym = xh * ga[e] + be[e];
+            float gg = p.act != SSCG_ACT_NONE ? act_grad(dv[e], ym, p.act, p.slope) : dv[e];
             gr[e] = gg;
             float v = gg;
-            if (p.coef) {
-                float xh = (xv[e] - mu[e]) * rsv[e];
-                v = gg - c1[e] - xh * c2[e];
-            }
+            if (p.coef) v = gg - c1[e] - xh * c2[e];
             gx[e] = v * rsv[e] * ga[e];
         }
         stv<T, VEC>(pdx + o, gx);
@@ -605,17 +617,20 @@ static void launch_bwd_apply(const BwdApplyParams& q, int vec, hipStream_t st) {
 }
 
 extern "C" int sscg_norm_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
-                             const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int dtype, int G, int64_t L,
-                             int C, int act, float slope, int stats_grad, void* ws, size_t ws_bytes, void* stream) {
+                             const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int dtype, int G,
+                             int64_t L, int C, int act, float slope, int stats_grad, void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !mean || !rstd || !dx || G <= 0 || L <= 0 || C <= 0 || (dtype != SSCG_F32 && dtype != SSCG_BF16)) return SSCG_ERR_BAD_ARG;
-    if (act != SSCG_ACT_NONE && !y) return SSCG_ERR_BAD_ARG;
+    // y == NULL with ReLU / LeakyReLU: the mask is recomputed from x (only valid when no residual joined the forward);
+    // tanh needs the forward value itself
+    if (act == SSCG_ACT_TANH && !y) return SSCG_ERR_BAD_ARG;
+    if (act != SSCG_ACT_NONE && !y && dres) return SSCG_ERR_BAD_ARG;      // a residual joined the forward: the mask needs y
     hipStream_t st = (hipStream_t)stream;
     const bool need_red = stats_grad || dgamma || dbeta;
     float* coef = nullptr;
     if (need_red) {
         if (!ws || ws_bytes < sscg_norm_bwd_workspace(G, L, C)) return SSCG_ERR_WORKSPACE;
         RedParams p = {};
-        p.x = x; p.dy = dy; p.y = y; p.mean = mean; p.rstd = rstd;
+        p.x = x; p.dy = dy; p.y = y; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta;
         p.part = reinterpret_cast<double*>(ws); p.L = L; p.C = C; p.act = act; p.slope = slope;
         int rc = launch_reduce<RM_BWD>(p, G, dtype, st);
         if (rc) return rc;
@@ -626,7 +641,7 @@ extern "C" int sscg_norm_bwd(const void* dy, const void* x, const void* y, const
         SSCG_LAUNCH_CHECK();
     }
     BwdApplyParams q = {};
-    q.dy = dy; q.x = x; q.y = y; q.mean = mean; q.rstd = rstd; q.gamma = gamma;
+    q.dy = dy; q.x = x; q.y = y; q.mean = mean; q.rstd = rstd; q.gamma = gamma; q.beta = beta;
     q.coef = stats_grad ? coef : nullptr;
     q.dx = dx; q.dres = dres; q.L = L; q.C = C; q.act = act; q.slope = slope;
     const int vec = vec_for(C, dtype);

@@ -476,13 +476,14 @@ def norm_apply(x, mean, rstd, gamma, beta, residual, per_sample, act=ACT_NONE, s
 
 
 def norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad=True, want_dres=False, dgamma=None,
-             dbeta=None):
+             dbeta=None, beta=None):
+    """y None (ReLU / LeakyReLU, no residual in the forward): the activation mask is recomputed from x, gamma, beta."""
     g, l, c = _glc(x, per_sample)
     dx = torch.empty_like(x, memory_format=CL)
     dres = torch.empty_like(x, memory_format=CL) if want_dres else None
     nb = _cached_size(lib.sscg_norm_bwd_workspace, g, l, c)
     ws = _WS.get(nb, x.device)
-    check(lib.sscg_norm_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
+    check(lib.sscg_norm_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta),
                             dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _same_dtype(x, dy, y), g, l, c, act, slope,
                             1 if stats_grad else 0, ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_bwd")
     return dx, dres
@@ -940,12 +941,15 @@ class NormActFn(torch.autograd.Function):
         y = norm_apply(x, mean, rstd, gamma, beta, residual, per_sample, act, slope)
         ctx.cfg = (per_sample, act, slope, use_batch_stats, residual is not None)
         ctx.gref, ctx.betaref = gamma, beta
-        ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, rstd, gamma)
+        # y supplies the activation mask of the backward; without a residual (and for ReLU / LeakyReLU) the mask is the sign of
+        # gamma * xhat + beta, which the backward kernels recompute from x: one tensor less to read in both of them
+        need_y = act != ACT_NONE and (residual is not None or act not in (ACT_RELU, ACT_LRELU))
+        ctx.save_for_backward(x, y if need_y else None, mean, rstd, gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, rstd, gamma = ctx.saved_tensors
+        x, y, mean, rstd, gamma, beta = ctx.saved_tensors
         per_sample, act, slope, stats_grad, has_res = ctx.cfg
         dy = to_nhwc(dy)
         want_g = gamma is not None and ctx.needs_input_grad[1]
@@ -963,7 +967,7 @@ class NormActFn(torch.autograd.Function):
                 gacc = bacc = None
                 ret_g, ret_b = dgamma, dbeta
         dx, dres = norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad,
-                            want_dres=has_res and ctx.needs_input_grad[3], dgamma=dgamma, dbeta=dbeta)
+                            want_dres=has_res and ctx.needs_input_grad[3], dgamma=dgamma, dbeta=dbeta, beta=beta)
         if gacc is not None:
             # The sums were produced beside dx on this stream; their accumulation into the optimiser's arena runs on the
             # parameter's own side lane, like every other gradient of that parameter (two forward lanes may both reach

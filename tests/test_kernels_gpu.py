@@ -505,3 +505,29 @@ def test_conv_bf16_contraction_mode(shape, F, dev):
     assert 1e-4 < rel_err(y, exact) < 3e-2
     assert rel_err(dx, xr.grad) < 2e-5
     assert rel_err(dw, wr.grad) < 5e-5
+
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("affine", [True, False])
+@pytest.mark.parametrize("act", ["relu", "lrelu"])
+def test_norm_bwd_mask_recomputed_from_x_equals_mask_from_y(act, affine, dtype, dev):
+    """sscg_norm_bwd with y == NULL (no residual joined the forward): the activation mask recomputed as gamma * xhat + beta > 0 is the
+    mask the forward's output carries - dx, dgamma, dbeta are bitwise those of the call that reads y."""
+    F = load_sub("functional")
+    code, slope = (F.ACT_RELU, 0.0) if act == "relu" else (F.ACT_LRELU, 0.2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 72, 19, 23, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(4, 72, 19, 23, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    gamma = (torch.randn(72, generator=g) * 0.5 + 1.0).to(dev) if affine else None
+    beta = (torch.randn(72, generator=g) * 0.3).to(dev) if affine else None
+    for per in (False, True, 2):
+        mean, rstd = F.norm_stats(x, per)
+        y = F.norm_apply(x, mean, rstd, gamma, beta, None, per, code, slope)
+        outs = []
+        for yy in (y, None):
+            dg, db = torch.zeros(72, device=dev), torch.zeros(72, device=dev)
+            dx, _ = F.norm_bwd(dy, x, yy, mean, rstd, gamma, per, code, slope, True, False, dg if affine else None, db if affine else None, beta=beta)
+            outs.append((dx, dg, db))
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
