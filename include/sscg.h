@@ -132,7 +132,8 @@ int sscg_rstd_from_var(const float* var, float* rstd, int n, float eps, void* st
  * dgamma/dbeta accumulate (+=) if non-NULL.  `y` (the forward output) supplies the activation mask; with ReLU / LeakyReLU
  * and NO residual in the forward, y may be NULL: the mask is then recomputed as gamma * xhat + beta > 0 (the forward's own
  * expression; beta is only read in that case) and the kernels read one tensor less.
- * With stats_grad == 0 the statistics are treated as constants (eval-mode BN). */
+ * stats_grad bit 0: 0 = the statistics are constants (eval-mode BN); bit 1 (value 2): dgamma / dbeta are WRITTEN instead of
+ * accumulated (the caller then needs no zero-fill). */
 size_t sscg_norm_bwd_workspace(int G, int64_t L, int C);
 int sscg_norm_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int dtype, int G,

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __res
 // c1 = sum_g / L, c2 = sum_g_xhat / L  per (g, c);  dgamma/dbeta += sums (over g)
 __global__ __launch_bounds__(256) void finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ coef,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C,
-                                                            int chunks, long L) {
+                                                            int chunks, long L, int overwrite) {
     __shared__ double sm[512];
     const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
     const bool cok = c < C;
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void finalize_bwd_kernel(const double* __restr
             tg += sx;
         }
     }
-    if (lead && dgamma) dgamma[c] += (float)tg;
-    if (lead && dbeta) dbeta[c] += (float)tb;
+    if (lead && dgamma) dgamma[c] = (overwrite ? 0.f : dgamma[c]) + (float)tg;
+    if (lead && dbeta) dbeta[c] = (overwrite ? 0.f : dbeta[c]) + (float)tb;
 }
 
 struct ApplyParams {
@@ -625,6 +625,8 @@ extern "C" int sscg_norm_bwd(const void* dy, const void* x, const void* y, const
     if (act == SSCG_ACT_TANH && !y) return SSCG_ERR_BAD_ARG;
     if (act != SSCG_ACT_NONE && !y && dres) return SSCG_ERR_BAD_ARG;      // a residual joined the forward: the mask needs y
     hipStream_t st = (hipStream_t)stream;
+    const int overwrite = (stats_grad >> 1) & 1;      // bit 1: dgamma / dbeta are written, not accumulated
+    stats_grad &= 1;
     const bool need_red = stats_grad || dgamma || dbeta;
     float* coef = nullptr;
     if (need_red) {
@@ -637,7 +639,7 @@ extern "C" int sscg_norm_bwd(const void* dy, const void* x, const void* y, const
         RedPlan pl = plan_reduce(G, L, C, dtype);
         coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + part_bytes(G, L, C));
         hipLaunchKernelGGL(finalize_bwd_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, st, p.part, coef, dgamma, dbeta, G, C,
-                           pl.chunks, (long)L);
+                           pl.chunks, (long)L, overwrite);
         SSCG_LAUNCH_CHECK();
     }
     BwdApplyParams q = {};

@@ -98,7 +98,8 @@ class SideStream:
 
     @classmethod
     def join(cls, device=None):
-        """Make the current stream wait for everything queued on the side stream(s)."""
+        """Make the current stream wait for everything queued on the side stream(s) (deferred work is launched first)."""
+        flush_side_work(device)
         for (dev, _), s in cls._streams.items():
             if device is None or dev == device:
                 torch.cuda.current_stream(dev).wait_stream(s)
@@ -134,13 +135,25 @@ def d_stream(device):
     return SideStream.get(device, SideStream.lanes - 1)
 
 
-def run_on_side_stream(device, tensors, fn, lane=0):
+def run_on_side_stream(device, tensors, fn, lane=0, defer=False):
     """Launch `fn`'s kernels on the side stream after everything queued so far on the current stream.
-    `tensors` are the buffers fn reads: the allocator must not recycle them before the side stream is done."""
+    `tensors` are the buffers fn reads: the allocator must not recycle them before the side stream is done.
+
+    defer=True (weight / bias gradient kernels: nothing reads their result before SideStream.join): the call is queued per lane
+    and launched in batches of SIDE_BATCH - one stream switch (current_stream + wait_stream + stream guard + record_stream:
+    ~20 us of host time) per batch instead of per convolution; 440 switches per step were the largest single item of the
+    backward's issue cost.  A parameter's gradient kernels keep their order (FIFO on their own lane)."""
     if not SideStream.enabled:
         return fn()
+    lane %= SideStream.lanes
+    if defer and SIDE_BATCH[0] > 1:
+        q = _SIDE_PENDING.setdefault((device, lane), [])
+        q.append((fn, tensors, _stream()))
+        if len(q) >= SIDE_BATCH[0]:
+            _flush_lane(device, lane)
+        return None
     main = torch.cuda.current_stream(device)
-    side = SideStream.get(device, lane % SideStream.lanes)
+    side = SideStream.get(device, lane)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         r = fn()
@@ -148,6 +161,53 @@ def run_on_side_stream(device, tensors, fn, lane=0):
         if t is not None:
             t.record_stream(side)
     return r
+
+
+SIDE_BATCH = [int(os.environ.get("SSCG_SIDE_BATCH", "8"))]
+_SIDE_PENDING = {}      # (device, lane) -> [(fn, tensors, raw handle of the stream that produced the tensors)]
+_STREAM_BY_HANDLE = {}  # raw stream handle -> torch.cuda.Stream (built once per stream: the object costs ~6 us to make)
+
+
+def _stream_object(device, handle):
+    so = _STREAM_BY_HANDLE.get((device, handle))
+    if so is None:
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream == handle:
+            so = cur
+        else:       # a producer stream that is not current any more: every stream this package creates is in the two registries
+            for reg in (SideStream._streams, ForkStream._streams):
+                for (dev, _), st in reg.items():
+                    if dev == device and st.cuda_stream == handle:
+                        so = st
+            if so is None:
+                so = torch.cuda.ExternalStream(handle, device=device)
+        _STREAM_BY_HANDLE[(device, handle)] = so
+    return so
+
+
+def _flush_lane(device, lane):
+    q = _SIDE_PENDING.get((device, lane))
+    if not q:
+        return
+    _SIDE_PENDING[(device, lane)] = []
+    side = SideStream.get(device, lane)
+    for h in {h for _, _, h in q}:
+        if h != side.cuda_stream:
+            side.wait_stream(_stream_object(device, h))      # behind everything its producers have queued so far
+    with torch.cuda.stream(side):
+        for fn, _, _ in q:
+            fn()
+    for _, tensors, _ in q:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+
+
+def flush_side_work(device=None):
+    """Launch every deferred side-lane call (SideStream.join does this first)."""
+    for (dev, lane) in list(_SIDE_PENDING.keys()):
+        if device is None or dev == device:
+            _flush_lane(dev, lane)
 
 
 def empty_nhwc(n, c, h, w, device, dtype=torch.float32):
@@ -476,7 +536,7 @@ def norm_apply(x, mean, rstd, gamma, beta, residual, per_sample, act=ACT_NONE, s
 
 
 def norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad=True, want_dres=False, dgamma=None,
-             dbeta=None, beta=None):
+             dbeta=None, beta=None, overwrite=False):
     """y None (ReLU / LeakyReLU, no residual in the forward): the activation mask is recomputed from x, gamma, beta."""
     g, l, c = _glc(x, per_sample)
     dx = torch.empty_like(x, memory_format=CL)
@@ -485,7 +545,7 @@ def norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad=Tru
     ws = _WS.get(nb, x.device)
     check(lib.sscg_norm_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta),
                             dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _same_dtype(x, dy, y), g, l, c, act, slope,
-                            1 if stats_grad else 0, ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_bwd")
+                            (1 if stats_grad else 0) | (2 if overwrite else 0), ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_bwd")
     return dx, dres
 
 
@@ -853,7 +913,7 @@ class Conv2dFn(torch.autograd.Function):
 
         if wacc is not None or bacc is not None:
             # nothing on the backward critical path reads these: run them beside the data-gradient chain
-            run_on_side_stream(dy.device, (x, dy), arena_grads, lane=getattr(ctx.wref, "_sscg_lane", 0))
+            run_on_side_stream(dy.device, (x, dy), arena_grads, lane=getattr(ctx.wref, "_sscg_lane", 0), defer=True)
         if want_w and wacc is None:
             dw = conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode)
         if want_b and bacc is None:
@@ -911,7 +971,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
                 colsum(n * p * q, k, dy, out=bacc, accumulate=True)
 
         if wacc is not None or bacc is not None:
-            run_on_side_stream(dy.device, (x, dy), arena_grads, lane=getattr(ctx.wref, "_sscg_lane", 0))
+            run_on_side_stream(dy.device, (x, dy), arena_grads, lane=getattr(ctx.wref, "_sscg_lane", 0), defer=True)
         if want_w and wacc is None:
             dw = conv2d_wgrad(dy, x, w.shape, stride, pad, 1)
         if want_b and bacc is None:
@@ -959,23 +1019,28 @@ class NormActFn(torch.autograd.Function):
         if want_g:
             gacc = _acc_target(ctx.gref)
             bacc = _acc_target(ctx.betaref)
-            dgamma = torch.empty_like(gamma)
-            dbeta = torch.empty_like(gamma)
-            fill_(dgamma, 0.0)
-            fill_(dbeta, 0.0)
+            dgb = torch.empty((2, gamma.numel()), dtype=torch.float32, device=gamma.device)     # written (not accumulated) by the kernel: no zero fill
+            dgamma, dbeta = dgb[0], dgb[1]
             if gacc is None or bacc is None:
                 gacc = bacc = None
                 ret_g, ret_b = dgamma, dbeta
         dx, dres = norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad,
-                            want_dres=has_res and ctx.needs_input_grad[3], dgamma=dgamma, dbeta=dbeta, beta=beta)
+                            want_dres=has_res and ctx.needs_input_grad[3], dgamma=dgamma, dbeta=dbeta, beta=beta, overwrite=True)
         if gacc is not None:
             # The sums were produced beside dx on this stream; their accumulation into the optimiser's arena runs on the
             # parameter's own side lane, like every other gradient of that parameter (two forward lanes may both reach
-            # this layer: a read-modify-write of the arena slice from two streams would lose updates).
+            # this layer: a read-modify-write of the arena slice from two streams would lose updates).  weight and bias of a
+            # norm layer are neighbours in the arena: one launch adds both.
+            n_c = gacc.numel()
+            adjacent = bacc.data_ptr() == gacc.data_ptr() + 4 * n_c
+
             def arena_grads():
-                check(lib.sscg_add(gacc.data_ptr(), dgamma.data_ptr(), gacc.data_ptr(), gacc.numel(), _stream()), "sscg_add")
-                check(lib.sscg_add(bacc.data_ptr(), dbeta.data_ptr(), bacc.data_ptr(), bacc.numel(), _stream()), "sscg_add")
-            run_on_side_stream(dy.device, (dgamma, dbeta), arena_grads, lane=getattr(ctx.gref, "_sscg_lane", 0))
+                if adjacent:
+                    check(lib.sscg_add(gacc.data_ptr(), dgb.data_ptr(), gacc.data_ptr(), F32, 2 * n_c, _stream()), "sscg_add")
+                else:
+                    check(lib.sscg_add(gacc.data_ptr(), dgamma.data_ptr(), gacc.data_ptr(), F32, n_c, _stream()), "sscg_add")
+                    check(lib.sscg_add(bacc.data_ptr(), dbeta.data_ptr(), bacc.data_ptr(), F32, n_c, _stream()), "sscg_add")
+            run_on_side_stream(dy.device, (dgb,), arena_grads, lane=getattr(ctx.gref, "_sscg_lane", 0), defer=True)
         if not ctx.needs_input_grad[0]:
             dx = None
         return dx, ret_g, ret_b, dres, None, None, None, None, None, None, None, None, None, None

@@ -531,3 +531,35 @@ def test_norm_bwd_mask_recomputed_from_x_equals_mask_from_y(act, affine, dtype, 
             outs.append((dx, dg, db))
         assert torch.equal(outs[0][0], outs[1][0])
         assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_trainable_batchnorm_affine_under_the_arena_optimiser(dev):
+    """A BatchNorm whose weight / bias are trained (the ResNet generators with --norm batch under --honour_nets; DeepLab freezes
+    them): dgamma / dbeta are written by the backward kernels and added into the optimiser's gradient arena on the parameter's
+    side lane - twice accumulated here (two backward passes), against torch's fp64 BatchNorm."""
+    F = load_sub("functional")
+    optim = load_sub("optim")
+    ops = load_sub("arch.ops")
+    torch.manual_seed(0)
+    conv = ops.Conv2d(8, 64, 3, 1, 1, bias=False).to(dev)
+    bn = ops.BatchNorm2d(64).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(64) + 0.5)
+        bn.bias.copy_(torch.randn(64) * 0.2)
+    opt = optim.FusedAdam(list(conv.parameters()) + list(bn.parameters()), lr=1e-3)
+    opt.zero_grad()
+    x = torch.randn(4, 8, 13, 11)
+    gy = torch.randn(4, 64, 13, 11)
+    for _ in range(2):
+        y = ops.conv_norm_act(conv, bn, gpu(x, dev), F.ACT_RELU)
+        F.backward((y * gpu(gy, dev)).sum())
+    F.SideStream.join(dev)
+    torch.cuda.synchronize()
+    wr = conv.weight.detach().double().cpu().requires_grad_(True)
+    gr = bn.weight.detach().double().cpu().requires_grad_(True)
+    br = bn.bias.detach().double().cpu().requires_grad_(True)
+    yr = torch.relu(TF.batch_norm(TF.conv2d(x.double(), wr, None, 1, 1), None, None, gr, br, True, 0.1, 1e-5))
+    (yr * gy.double()).sum().backward()
+    assert rel_err(bn.weight._sscg_grad, 2 * gr.grad) < 2e-5
+    assert rel_err(bn.bias._sscg_grad, 2 * br.grad) < 2e-5
+    assert rel_err(conv.weight._sscg_grad, 2 * wr.grad) < 2e-5
