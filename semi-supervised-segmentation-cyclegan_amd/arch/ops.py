@@ -8,6 +8,8 @@ the conv's tile loader, and every tensor is channels-last in memory.
 """
 import functools
 
+import os
+
 import torch
 from torch import nn
 
@@ -248,8 +250,22 @@ def conv_norm_act(conv, norm, x, act=ACT_NONE, slope=0.0, residual=None, reflect
     if spec is None:
         y = conv(x, reflect=reflect) if isinstance(conv, Conv2d) else conv(x)
         return norm(y, act, slope, residual=residual)
-    y, stats = conv.forward_stats(x, spec, reflect)
-    return norm(y, act, slope, residual=residual, stats=stats)
+    if not ONE_NODE[0]:
+        y, stats = conv.forward_stats(x, spec, reflect)
+        return norm(y, act, slope, residual=residual, stats=stats)
+    # one autograd node for the whole unit (the same kernels; half the host's per-layer cost)
+    per_sample, eps, rmean, rvar, momentum = spec
+    x, pad, mode = conv._geometry(x, reflect)
+    if isinstance(norm, BatchNorm2d):
+        norm._pending += _BATCH_GROUPS[0]          # num_batches_tracked, as BatchNorm2d.forward counts it
+        gamma, beta = norm.weight, norm.bias
+    else:
+        gamma = beta = None
+    return F.conv_norm_act(x, conv.weight, conv.bias, conv.stride, pad, conv.dilation, mode, gamma, beta, residual, rmean, rvar,
+                           per_sample, eps, momentum, act, slope)
+
+
+ONE_NODE = [os.environ.get("SSCG_ONE_NODE", "1") != "0"]       # A/B aid: conv and norm as two autograd nodes
 
 
 class FusedSequential(nn.Sequential):

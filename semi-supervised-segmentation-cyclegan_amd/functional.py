@@ -894,31 +894,38 @@ class Conv2dFn(torch.autograd.Function):
         dy = to_nhwc(dy)
         if act != ACT_NONE:
             dy = act_bwd(dy, y, act, slope)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            if pad_mode == PAD_REFLECT:
-                raise _lib.SscgError("input gradient through a reflection-padded conv: use ReflectPadFn + pad=0 conv")
-            dx = conv2d_dgrad_param(dy, ctx.wref, x.shape, w.shape, stride, pad, dil, out_dtype=x.dtype)
-        want_w = ctx.needs_input_grad[1]
-        want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        wacc = _acc_target(ctx.wref) if want_w else None
-        bacc = _acc_target(ctx.bref) if want_b else None
-        n, k, p, q = dy.shape
-
-        def arena_grads():      # accumulate straight into the optimiser's gradient arena
-            if wacc is not None:
-                conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode, out=wacc, accumulate=True)
-            if bacc is not None:
-                colsum(n * p * q, k, dy, out=bacc, accumulate=True)
-
-        if wacc is not None or bacc is not None:
-            # nothing on the backward critical path reads these: run them beside the data-gradient chain
-            run_on_side_stream(dy.device, (x, dy), arena_grads, lane=getattr(ctx.wref, "_sscg_lane", 0), defer=True)
-        if want_w and wacc is None:
-            dw = conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode)
-        if want_b and bacc is None:
-            db = colsum(n * p * q, k, dy)
+        dx, dw, db = _conv_backward(dy, x, w, ctx.wref, ctx.bref if ctx.has_bias else None, (stride, pad, dil, pad_mode),
+                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def _conv_backward(dy, x, w, wref, bref, geom, want_x, want_w, want_b):
+    """Backward of y = conv(x, w) + bias for the gradient dy of the PRE-activation output: (dx, dw, db).  Weight / bias gradients of
+    parameters owned by optim.FusedAdam go straight into its gradient arena on the parameter's side lane (dw, db then None)."""
+    stride, pad, dil, pad_mode = geom
+    dx = dw = db = None
+    if want_x:
+        if pad_mode == PAD_REFLECT:
+            raise _lib.SscgError("input gradient through a reflection-padded conv: use ReflectPadFn + pad=0 conv")
+        dx = conv2d_dgrad_param(dy, wref, x.shape, w.shape, stride, pad, dil, out_dtype=x.dtype)
+    wacc = _acc_target(wref) if want_w else None
+    bacc = _acc_target(bref) if want_b else None
+    n, k, p, q = dy.shape
+
+    def arena_grads():      # accumulate straight into the optimiser's gradient arena
+        if wacc is not None:
+            conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode, out=wacc, accumulate=True)
+        if bacc is not None:
+            colsum(n * p * q, k, dy, out=bacc, accumulate=True)
+
+    if wacc is not None or bacc is not None:
+        # nothing on the backward critical path reads these: run them beside the data-gradient chain
+        run_on_side_stream(dy.device, (x, dy), arena_grads, lane=getattr(wref, "_sscg_lane", 0), defer=True)
+    if want_w and wacc is None:
+        dw = conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode)
+    if want_b and bacc is None:
+        db = colsum(n * p * q, k, dy)
+    return dx, dw, db
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
@@ -1011,39 +1018,88 @@ class NormActFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, mean, rstd, gamma, beta = ctx.saved_tensors
         per_sample, act, slope, stats_grad, has_res = ctx.cfg
-        dy = to_nhwc(dy)
-        want_g = gamma is not None and ctx.needs_input_grad[1]
-        dgamma = dbeta = None
-        ret_g = ret_b = None
-        gacc = bacc = None
-        if want_g:
-            gacc = _acc_target(ctx.gref)
-            bacc = _acc_target(ctx.betaref)
-            dgb = torch.empty((2, gamma.numel()), dtype=torch.float32, device=gamma.device)     # written (not accumulated) by the kernel: no zero fill
-            dgamma, dbeta = dgb[0], dgb[1]
-            if gacc is None or bacc is None:
-                gacc = bacc = None
-                ret_g, ret_b = dgamma, dbeta
-        dx, dres = norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad,
-                            want_dres=has_res and ctx.needs_input_grad[3], dgamma=dgamma, dbeta=dbeta, beta=beta, overwrite=True)
-        if gacc is not None:
-            # The sums were produced beside dx on this stream; their accumulation into the optimiser's arena runs on the
-            # parameter's own side lane, like every other gradient of that parameter (two forward lanes may both reach
-            # this layer: a read-modify-write of the arena slice from two streams would lose updates).  weight and bias of a
-            # norm layer are neighbours in the arena: one launch adds both.
-            n_c = gacc.numel()
-            adjacent = bacc.data_ptr() == gacc.data_ptr() + 4 * n_c
-
-            def arena_grads():
-                if adjacent:
-                    check(lib.sscg_add(gacc.data_ptr(), dgb.data_ptr(), gacc.data_ptr(), F32, 2 * n_c, _stream()), "sscg_add")
-                else:
-                    check(lib.sscg_add(gacc.data_ptr(), dgamma.data_ptr(), gacc.data_ptr(), F32, n_c, _stream()), "sscg_add")
-                    check(lib.sscg_add(bacc.data_ptr(), dbeta.data_ptr(), bacc.data_ptr(), F32, n_c, _stream()), "sscg_add")
-            run_on_side_stream(dy.device, (dgb,), arena_grads, lane=getattr(ctx.gref, "_sscg_lane", 0), defer=True)
+        dx, ret_g, ret_b, dres = _norm_backward(to_nhwc(dy), x, y, mean, rstd, gamma, beta, ctx.gref, ctx.betaref, per_sample, act, slope,
+                                                stats_grad, gamma is not None and ctx.needs_input_grad[1],
+                                                has_res and ctx.needs_input_grad[3])
         if not ctx.needs_input_grad[0]:
             dx = None
         return dx, ret_g, ret_b, dres, None, None, None, None, None, None, None, None, None, None
+
+
+def _norm_backward(dy, x, y, mean, rstd, gamma, beta, gref, betaref, per_sample, act, slope, stats_grad, want_g, want_dres):
+    """Backward of y = act(norm(x) [+ residual]): (dx, dgamma, dbeta, dres).  dgamma / dbeta of parameters owned by optim.FusedAdam are
+    added into its gradient arena on the parameter's side lane (returned as None)."""
+    dgamma = dbeta = dgb = None
+    ret_g = ret_b = None
+    gacc = bacc = None
+    if want_g:
+        gacc = _acc_target(gref)
+        bacc = _acc_target(betaref)
+        dgb = torch.empty((2, gamma.numel()), dtype=torch.float32, device=gamma.device)     # written (not accumulated) by the kernel: no zero fill
+        dgamma, dbeta = dgb[0], dgb[1]
+        if gacc is None or bacc is None:
+            gacc = bacc = None
+            ret_g, ret_b = dgamma, dbeta
+    dx, dres = norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad,
+                        want_dres=want_dres, dgamma=dgamma, dbeta=dbeta, beta=beta, overwrite=True)
+    if gacc is not None:
+        # The sums were produced beside dx on this stream; their accumulation into the optimiser's arena runs on the
+        # parameter's own side lane, like every other gradient of that parameter (two forward lanes may both reach
+        # this layer: a read-modify-write of the arena slice from two streams would lose updates).  weight and bias of a
+        # norm layer are neighbours in the arena: one launch adds both.
+        n_c = gacc.numel()
+        adjacent = bacc.data_ptr() == gacc.data_ptr() + 4 * n_c
+
+        def arena_grads():
+            if adjacent:
+                check(lib.sscg_add(gacc.data_ptr(), dgb.data_ptr(), gacc.data_ptr(), F32, 2 * n_c, _stream()), "sscg_add")
+            else:
+                check(lib.sscg_add(gacc.data_ptr(), dgamma.data_ptr(), gacc.data_ptr(), F32, n_c, _stream()), "sscg_add")
+                check(lib.sscg_add(bacc.data_ptr(), dbeta.data_ptr(), bacc.data_ptr(), F32, n_c, _stream()), "sscg_add")
+        run_on_side_stream(dy.device, (dgb,), arena_grads, lane=getattr(gref, "_sscg_lane", 0), defer=True)
+    return dx, ret_g, ret_b, dres
+
+
+class ConvNormActFn(torch.autograd.Function):
+    """The reference's fusion unit as ONE autograd node: conv -> InstanceNorm / BatchNorm (batch statistics, from the conv's
+    epilogue where the library can fuse them) [+ residual] -> activation (arch/ops.py:40-57; Bottleneck conv+bn pairs,
+    arch/generators.py:345-365).  The same kernels as Conv2dFn + NormActFn; one node instead of two halves the host's per-layer
+    autograd cost (575 such pairs per step).  cfg = (stride, pad, dil, pad_mode, per_sample, eps, momentum, act, slope)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, residual, running_mean, running_var, cfg):
+        stride, pad, dil, pad_mode, per_sample, eps, momentum, act, slope = cfg
+        x = to_nhwc(x)
+        if residual is not None:
+            residual = to_nhwc(residual)
+        n, _, h, wd = x.shape
+        p, q = conv_out_size(h, w.shape[2], stride, pad, dil), conv_out_size(wd, w.shape[3], stride, pad, dil)
+        g, l, c = _glc_shape((n, w.shape[0], p, q), per_sample)
+        y, cs = conv2d_fwd(x, w, bias, stride, pad, dil, pad_mode, ACT_NONE, 0.0, False, stats=(g, l))
+        if cs is not None:
+            mean, rstd = norm_stats_from_conv(cs, (g, l, c), eps, running_mean, running_var, momentum)
+        else:
+            upd = running_mean is not None and per_sample is not True
+            mean, rstd = norm_stats(y, per_sample, eps, running_mean if upd else None, running_var if upd else None, momentum)
+        z = norm_apply(y, mean, rstd, gamma, beta, residual, per_sample, act, slope)
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.wref, ctx.bref, ctx.gref, ctx.betaref = w, bias, gamma, beta
+        need_z = act != ACT_NONE and (residual is not None or act not in (ACT_RELU, ACT_LRELU))
+        ctx.save_for_backward(x, w, y, z if need_z else None, mean, rstd, gamma, beta)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, y, z, mean, rstd, gamma, beta = ctx.saved_tensors
+        stride, pad, dil, pad_mode, per_sample, eps, momentum, act, slope = ctx.cfg
+        ni = ctx.needs_input_grad
+        dy, ret_g, ret_b, dres = _norm_backward(to_nhwc(dz), y, z, mean, rstd, gamma, beta, ctx.gref, ctx.betaref, per_sample, act, slope,
+                                                True, gamma is not None and ni[3], ctx.has_res and ni[5])
+        dx, dw, db = _conv_backward(dy, x, w, ctx.wref, ctx.bref if ctx.has_bias else None, (stride, pad, dil, pad_mode),
+                                    ni[0], ni[1], ctx.has_bias and ni[2])
+        return dx, dw, db, ret_g, ret_b, dres, None, None, None
 
 
 class ActFn(torch.autograd.Function):
@@ -1303,6 +1359,13 @@ def backward(loss):
     not depend on the thread)."""
     with torch.autograd.set_multithreading_enabled(False):
         loss.backward()
+
+
+def conv_norm_act(x, w, bias, stride, pad, dil, pad_mode, gamma, beta, residual, running_mean, running_var, per_sample, eps, momentum,
+                  act=ACT_NONE, slope=0.0):
+    """conv -> norm (batch statistics) [+ residual] -> activation as one autograd node (training-mode normalisation only)."""
+    return ConvNormActFn.apply(x, w, bias, gamma, beta, residual, running_mean, running_var,
+                               (stride, pad, dil, pad_mode, per_sample, eps, momentum, act, slope))
 
 
 def conv2d_norm_stats(x, w, bias, stride, pad, dil, pad_mode, norm):
