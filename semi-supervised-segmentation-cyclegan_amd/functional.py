@@ -24,7 +24,7 @@ CL = torch.channels_last
 
 # ----------------------------------------------------------------------------- plumbing
 _raw_stream = torch._C._cuda_getCurrentRawStream     # the handle only: torch.cuda.current_stream() builds a Stream object (~6 us)
-_cur_dev = torch.cuda.current_device
+_cur_dev = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)     # the binding itself: torch.cuda.current_device() adds a lazy-init check per call
 
 
 def _stream():

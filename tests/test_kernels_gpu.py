@@ -563,3 +563,37 @@ def test_trainable_batchnorm_affine_under_the_arena_optimiser(dev):
     assert rel_err(bn.weight._sscg_grad, 2 * gr.grad) < 2e-5
     assert rel_err(bn.bias._sscg_grad, 2 * br.grad) < 2e-5
     assert rel_err(conv.weight._sscg_grad, 2 * wr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+def test_one_node_unit_equals_the_two_node_path_bitwise(norm, dev):
+    """arch.ops.conv_norm_act as one autograd node (ConvNormActFn) launches the kernels of Conv2dFn + NormActFn: output, input
+    gradient, parameter gradients and BatchNorm state are bitwise those of the two-node path."""
+    F = load_sub("functional")
+    ops = load_sub("arch.ops")
+    torch.manual_seed(1)
+    conv = ops.Conv2d(16, 64, 3, 1, 1, bias=(norm == "instance")).to(dev)
+    nl = ops.BatchNorm2d(64).to(dev) if norm == "batch" else ops.InstanceNorm2d(64).to(dev)
+    x0 = torch.randn(3, 16, 17, 13)
+    r0 = torch.randn(3, 64, 17, 13)
+    gy = gpu(torch.randn(3, 64, 17, 13), dev)
+    outs = []
+    for one in (True, False):
+        ops.ONE_NODE[0] = one
+        try:
+            if norm == "batch":
+                nl.running_mean.zero_(); nl.running_var.fill_(1.0)
+            for p in list(conv.parameters()) + list(nl.parameters()):
+                p.grad = None
+            x, r = gpu(x0, dev).requires_grad_(True), gpu(r0, dev).requires_grad_(True)
+            y = ops.conv_norm_act(conv, nl, x, F.ACT_RELU, residual=r)
+            F.backward((y * gy).sum())
+            F.SideStream.join(dev)
+            torch.cuda.synchronize()
+            outs.append([y.detach().clone(), x.grad.clone(), r.grad.clone(), conv.weight.grad.clone()] +
+                        ([nl.weight.grad.clone(), nl.bias.grad.clone(), nl.running_mean.clone(), nl.running_var.clone()] if norm == "batch"
+                         else [conv.bias.grad.clone()]))
+        finally:
+            ops.ONE_NODE[0] = True
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
