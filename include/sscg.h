@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 7
+#define SSCG_ABI_VERSION 8
 
 /* element types of activation / weight tensors */
 #define SSCG_F32 0
@@ -151,6 +151,10 @@ int sscg_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t
 /* utils.GaussianNoise (utils.py:116-140; call site model.py:486-488): y = x + sigma * x * n, n ~ N(0, 1) drawn from a
  * counter-based hash of (seed, element index) through Box-Muller. */
 int sscg_gauss_noise(const float* x, float* y, int64_t n, float sigma, uint64_t seed, void* stream);
+/* nn.MaxPool2d(2, 2) (floor mode: P = H / 2, Q = W / 2) of torchvision's VGG16 features (utils.Vgg16, utils.py:147-164);
+ * idx = window position 0..3 of the first max */
+int sscg_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int N, int H, int W, int C, void* stream);
+int sscg_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int N, int H, int W, int C, void* stream);
 /* nn.MaxPool2d(3, 2, 1, ceil_mode=True) (arch/generators.py:394); idx = window position 0..8 of the first max */
 int sscg_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int N, int H, int W, int C, int P, int Q, void* stream);
 int sscg_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int N, int H, int W, int C, int P, int Q, void* stream);
@@ -202,10 +206,13 @@ int sscg_ce_bwd(const float* logits, const int64_t* labels, int64_t rows, int C,
 /* nn.MSELoss against a constant target map of ones/zeros (LSGAN; model.py:445-446,452,521-528) */
 int sscg_mse_const_fwd(const float* x, int64_t n, float target, float* loss, void* ws, size_t ws_bytes, void* stream);
 int sscg_mse_const_bwd(const float* x, int64_t n, float target, const float* gscale, float w, float* dx, void* stream);
+/* nn.MSELoss between two tensors (utils.perceptual_loss, utils.py:205-206): gradient to a, and to b when db != NULL */
+int sscg_mse_fwd(const float* a, const float* b, int64_t n, float* loss, void* ws, size_t ws_bytes, void* stream);
+int sscg_mse_bwd(const float* a, const float* b, int64_t n, const float* gscale, float w, float* da, float* db, void* stream);
 /* nn.L1Loss (model.py:271; call :461) */
 int sscg_l1_fwd(const float* a, const float* b, int64_t n, float* loss, void* ws, size_t ws_bytes, void* stream);
 int sscg_l1_bwd(const float* a, const float* b, int64_t n, const float* gscale, float w, float* da, void* stream);
-/* out = sum_i w[i] * (*terms[i]) for up to 8 device scalars (gen_loss / discriminator_loss, model.py:464-468,538) */
+/* out = sum_i w[i] * (*terms[i]) for up to 16 device scalars (gen_loss / discriminator_loss, model.py:464-468,538) */
 int sscg_weighted_sum(const float* const* terms, const float* w, int n, float* out, void* stream);
 
 /* ------------------------------------------------------------------ optimiser (K14)

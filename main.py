@@ -46,7 +46,10 @@ def get_args(argv=None):
     parser.add_argument("--honour_nets", type=int, default=0,
                         help="1: build the generators / discriminators --gen_net / --dis_net name (the reference ignores both flags)")
     parser.add_argument("--variants", type=str, default="",
-                        help="comma list of loss terms the reference has commented out: l1_cycle, lab_gt_dis")
+                        help="comma list of what the reference has commented out / disabled: l1_cycle, lab_gt_dis, gauss_noise, "
+                             "perceptual (weights --lamda_perceptual / --lab_perceptual_weight)")
+    parser.add_argument("--vgg_weights", type=str, default=None,
+                        help="torchvision VGG16 state dict for --variants perceptual (the reference downloads vgg16(pretrained=True))")
     parser.add_argument("--testing_gen", type=str, default="resnet_9blocks_softmax",
                         help="generator testing.py builds (the reference hard-codes resnet_9blocks_softmax, testing.py:40)")
     return parser.parse_args(argv)

@@ -400,3 +400,30 @@ def conv_norm_act(w, b, x, stride, pad, norm, act, slope=0.2, transposed=False, 
         y = TF.conv2d(x, w, b, stride, pad)
     y = TF.instance_norm(y, eps=EPS) if norm == "instance" else y
     return torch.relu(y) if act == "relu" else TF.leaky_relu(y, slope)
+
+
+# utils.Vgg16 / utils.perceptual_loss (utils.py:145-208).  PARITY UNPINNED for this pair: the reference builds
+# torchvision.models.vgg16(pretrained=True) - torchvision and the weights are absent in the build container, so the restatement
+# below follows the reference's text and torchvision's published VGG16 layer table, not a run of the reference.
+VGG16_CONVS = ((0, 3, 64), (2, 64, 64), (5, 64, 128), (7, 128, 128), (10, 128, 256), (12, 256, 256), (14, 256, 256),
+               (17, 256, 512), (19, 512, 512), (21, 512, 512))
+_VGG_SLICE = {0: 1, 2: 1, 5: 2, 7: 2, 10: 3, 12: 3, 14: 3, 17: 4, 19: 4, 21: 4}
+
+
+def vgg16_relu2_2(sd, x):
+    """slice1 = conv-relu-conv-relu, slice2 = maxpool(2,2)-conv-relu-conv-relu (features[0:9])."""
+    def cr(h, idx):
+        k = "slice%d.%d" % (_VGG_SLICE[idx], idx)
+        return torch.relu(TF.conv2d(h, sd[k + ".weight"], sd[k + ".bias"], 1, 1))
+    h = cr(cr(x, 0), 2)
+    h = TF.max_pool2d(h, 2, 2)
+    return cr(cr(h, 5), 7)
+
+
+def perceptual_loss(sd, x, y):
+    """utils.py:181-208 as written (u * std + mean after x / 2 + 1 / 2)."""
+    mean = torch.tensor([0.485, 0.456, 0.406], dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], dtype=x.dtype).view(1, 3, 1, 1)
+    u = (x * 0.5 + 0.5) * std + mean
+    v = (y * 0.5 + 0.5) * std + mean
+    return TF.mse_loss(vgg16_relu2_2(sd, v), vgg16_relu2_2(sd, u))

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 F32, BF16 = 0, 1     # SSCG_F32 / SSCG_BF16
 
@@ -67,6 +67,8 @@ SIGNATURES = {
     "sscg_add": (_i, [_p, _p, _p, _i, _i64, _p]),
     "sscg_dropout": (_i, [_p, _p, _i, _i64, _f, C.c_uint64, _p]),
     "sscg_gauss_noise": (_i, [_p, _p, _i64, _f, C.c_uint64, _p]),
+    "sscg_maxpool2x2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "sscg_maxpool2x2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "sscg_maxpool3x3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "sscg_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "sscg_upsample_bilinear_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -87,6 +89,8 @@ SIGNATURES = {
     "sscg_ce_bwd": (_i, [_p, _p, _i64, _i, _p, _f, _p, _p, _p]),
     "sscg_mse_const_fwd": (_i, [_p, _i64, _f, _p, _p, _sz, _p]),
     "sscg_mse_const_bwd": (_i, [_p, _i64, _f, _p, _f, _p, _p]),
+    "sscg_mse_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
+    "sscg_mse_bwd": (_i, [_p, _p, _i64, _p, _f, _p, _p, _p]),
     "sscg_l1_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
     "sscg_l1_bwd": (_i, [_p, _p, _i64, _p, _f, _p, _p]),
     "sscg_weighted_sum": (_i, [C.POINTER(_p), C.POINTER(_f), _i, _p, _p]),

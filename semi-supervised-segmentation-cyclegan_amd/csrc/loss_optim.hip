@@ -187,9 +187,29 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
     }
 }
 
+// nn.MSELoss()(a, b) between two tensors (utils.perceptual_loss, utils.py:205-206); gradient to a (and to b when db != NULL)
+__global__ void mse_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, double* __restrict__ part) {
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double d = (double)a[i] - (double)b[i];
+        acc += d * d;
+    }
+    block_sum_to(acc, part + blockIdx.x);
+}
+
+__global__ void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, const float* __restrict__ gscale,
+                               float w, float* __restrict__ da, float* __restrict__ db) {
+    const float g = (gscale ? *gscale : 1.f) * w;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = (a[i] - b[i]) * g;
+        da[i] = d;
+        if (db) db[i] = -d;
+    }
+}
+
 struct WsumArgs {
-    const float* t[8];
-    float w[8];
+    const float* t[16];
+    float w[16];
     int n;
 };
 
@@ -350,10 +370,30 @@ extern "C" int sscg_l1_bwd(const float* a, const float* b, int64_t n, const floa
     return SSCG_OK;
 }
 
+extern "C" int sscg_mse_fwd(const float* a, const float* b, int64_t n, float* loss, void* ws, size_t ws_bytes, void* stream) {
+    if (!a || !b || !loss || n <= 0) return SSCG_ERR_BAD_ARG;
+    if (!ws || ws_bytes < sscg_loss_workspace(n)) return SSCG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ew_blocks(n, LOSS_BLOCKS);
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3(nb), dim3(256), 0, st, a, b, (size_t)n, part);
+    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)n, loss);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_mse_bwd(const float* a, const float* b, int64_t n, const float* gscale, float w, float* da, float* db, void* stream) {
+    if (!a || !b || !da || n <= 0) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, (size_t)n, gscale,
+                       2.f * w / (float)n, da, db);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
 extern "C" int sscg_weighted_sum(const float* const* terms, const float* w, int n, float* out, void* stream) {
-    if (!terms || !w || !out || n <= 0 || n > 8) return SSCG_ERR_BAD_ARG;
+    if (!terms || !w || !out || n <= 0 || n > 16) return SSCG_ERR_BAD_ARG;
     WsumArgs a;
-    for (int i = 0; i < 8; ++i) { a.t[i] = i < n ? terms[i] : nullptr; a.w[i] = i < n ? w[i] : 0.f; }
+    for (int i = 0; i < 16; ++i) { a.t[i] = i < n ? terms[i] : nullptr; a.w[i] = i < n ? w[i] : 0.f; }
     a.n = n;
     hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out);
     SSCG_LAUNCH_CHECK();

@@ -162,6 +162,53 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
     }
 }
 
+// nn.MaxPool2d(kernel_size=2, stride=2) (floor mode; torchvision VGG16 features[4,9,16], utils.py:147-164): one thread per output
+// element, first maximum wins (the window index 2 * ky + kx goes to idx for the backward)
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int N, int H, int W, int C,
+                                    int P, int Q) {
+    size_t total = (size_t)N * P * Q * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c = (int)(i % C);
+        size_t t = i / C;
+        int ox = (int)(t % Q); t /= Q;
+        int oy = (int)(t % P);
+        int n = (int)(t / P);
+        const T* base = x + ((size_t)(n * H + oy * 2) * W + ox * 2) * C + c;
+        float best = ld1<T>(base);
+        int bi = 0;
+        float v = ld1<T>(base + C);
+        if (v > best) { best = v; bi = 1; }
+        v = ld1<T>(base + (size_t)W * C);
+        if (v > best) { best = v; bi = 2; }
+        v = ld1<T>(base + (size_t)W * C + C);
+        if (v > best) { best = v; bi = 3; }
+        st1<T>(y + i, best);
+        idx[i] = (uint8_t)bi;
+    }
+}
+
+// windows do not overlap: every input element belongs to at most one output (rows / columns past 2P, 2Q get zero)
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int N, int H, int W,
+                                    int C, int P, int Q) {
+    size_t total = (size_t)N * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c = (int)(i % C);
+        size_t t = i / C;
+        int ix = (int)(t % W); t /= W;
+        int iy = (int)(t % H);
+        int n = (int)(t / H);
+        int oy = iy >> 1, ox = ix >> 1;
+        float g = 0.f;
+        if (oy < P && ox < Q) {
+            size_t o = ((size_t)(n * P + oy) * Q + ox) * C + c;
+            if (idx[o] == (uint8_t)((iy & 1) * 2 + (ix & 1))) g = ld1<T>(dy + o);
+        }
+        st1<T>(dx + i, g);
+    }
+}
+
 // bilinear, align_corners=True (torch upsample_bilinear2d arithmetic: src = scale * dst in fp32)
 __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
                                     int OH, int OW, float sh, float sw) {
@@ -393,6 +440,30 @@ extern "C" int sscg_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* d
         hipLaunchKernelGGL(maxpool_bwd_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, BF(dy), idx, BFW(dx), N, H, W, C, P, Q);
     else
         hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, FP(dy), idx, FPW(dx), N, H, W, C, P, Q);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int N, int H, int W, int C, void* stream) {
+    const int P = H / 2, Q = W / 2;
+    if (!x || !y || !idx || N <= 0 || C <= 0 || P <= 0 || Q <= 0 || !SSCG_DT_OK(dtype)) return SSCG_ERR_BAD_ARG;
+    size_t total = (size_t)N * P * Q * C;
+    if (dtype == SSCG_BF16)
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, BF(x), BFW(y), idx, N, H, W, C, P, Q);
+    else
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, FP(x), FPW(y), idx, N, H, W, C, P, Q);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int N, int H, int W, int C, void* stream) {
+    const int P = H / 2, Q = W / 2;
+    if (!dy || !idx || !dx || N <= 0 || C <= 0 || P <= 0 || Q <= 0 || !SSCG_DT_OK(dtype)) return SSCG_ERR_BAD_ARG;
+    size_t total = (size_t)N * H * W * C;
+    if (dtype == SSCG_BF16)
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, BF(dy), idx, BFW(dx), N, H, W, C, P, Q);
+    else
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, FP(dy), idx, FPW(dx), N, H, W, C, P, Q);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

@@ -1219,6 +1219,34 @@ class MaxPoolFn(torch.autograd.Function):
         return maxpool_bwd(to_nhwc(dy), idx, ctx.xshape)
 
 
+class MaxPool2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) (utils.Vgg16: torchvision VGG16 features[4, 9, 16])."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h // 2, w // 2, x.device, x.dtype)
+        idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device)
+        check(lib.sscg_maxpool2x2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _stream()), "sscg_maxpool2x2_fwd")
+        ctx.xshape = (n, c, h, w)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        n, c, h, w = ctx.xshape
+        dx = empty_nhwc(n, c, h, w, dy.device, dy.dtype)
+        check(lib.sscg_maxpool2x2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), _dt(dy), n, h, w, c, _stream()), "sscg_maxpool2x2_bwd")
+        return dx
+
+
+def maxpool2x2(x):
+    return MaxPool2Fn.apply(x)
+
+
 class UpsampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, oh, ow):
@@ -1319,6 +1347,33 @@ class L1Fn(torch.autograd.Function):
         da = torch.empty_like(a, memory_format=CL)
         check(lib.sscg_l1_bwd(a.data_ptr(), b.data_ptr(), a.numel(), g.data_ptr(), 1.0, da.data_ptr(), _stream()), "sscg_l1_bwd")
         return da, None
+
+
+class MseFn(torch.autograd.Function):
+    """nn.MSELoss()(a, b) between two tensors (utils.perceptual_loss, utils.py:205-206); gradients to both."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_hip(a, f32_only=True)
+        _need_hip(b, f32_only=True)
+        a, b = to_nhwc(a), to_nhwc(b)
+        loss = _scalar(a.device)
+        ws = _loss_ws(a.device)
+        check(lib.sscg_mse_fwd(a.data_ptr(), b.data_ptr(), a.numel(), loss.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "sscg_mse_fwd")
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a, memory_format=CL)
+        db = torch.empty_like(b, memory_format=CL) if ctx.needs_input_grad[1] else None
+        check(lib.sscg_mse_bwd(a.data_ptr(), b.data_ptr(), a.numel(), g.data_ptr(), 1.0, da.data_ptr(), _ptr(db), _stream()), "sscg_mse_bwd")
+        return da, db
+
+
+def mse_loss(a, b):
+    return MseFn.apply(a, b)
 
 
 class WeightedSumFn(torch.autograd.Function):

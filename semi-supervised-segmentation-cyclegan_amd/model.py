@@ -49,9 +49,9 @@ class semisuper_cycleGAN(object):
         gen = args.gen_net if honour else 'deeplab'
         dis = args.dis_net if honour else 'pixel'
         self.variants = set(v for v in str(getattr(args, "variants", "") or "").split(",") if v)
-        unknown = self.variants - {"l1_cycle", "lab_gt_dis", "gauss_noise"}
+        unknown = self.variants - {"l1_cycle", "lab_gt_dis", "gauss_noise", "perceptual"}
         if unknown:
-            raise ValueError("unknown --variants %s (the perceptual loss needs pretrained VGG16 weights)" % sorted(unknown))
+            raise ValueError("unknown --variants %s" % sorted(unknown))
         # model.py:281,486-488: `if torch.rand(1) < 0.0` never fires, but draws one number from torch's CPU generator per
         # step (the stream DataLoader shuffling also draws from).  The draw is kept; the variant raises the threshold to 1.
         self.gauss_noise = utils.GaussianNoise(sigma=0.2)
@@ -201,6 +201,15 @@ class semisuper_cycleGAN(object):
             extras["img_cycle_l1"] = F.l1_loss(recon_img_l1, unl_img)
             extra_terms.append(extras["img_cycle_l1"])
             extra_weights.append(a.lamda_img)
+        if "perceptual" in self.variants:                                            # :454,:462 (commented out; weights main.py:23,28)
+            if getattr(self, "vgg", None) is None:
+                self.vgg = utils.Vgg16(requires_grad=False, weights=getattr(a, "vgg_weights", None)).to(dev)
+            recon_img, recon_img_p = F.split(recon_img, 2)
+            fake_img_l1, fake_img_p = F.split(fake_img_l1, 2)
+            extras["img_cycle_loss_perceptual"] = utils.perceptual_loss(recon_img_p, unl_img, a.gpu_ids, self.vgg)
+            extras["lab_loss_perceptual"] = utils.perceptual_loss(fake_img_p, l_img, a.gpu_ids, self.vgg)
+            extra_terms += [extras["img_cycle_loss_perceptual"], extras["lab_loss_perceptual"]]
+            extra_weights += [a.lamda_perceptual, a.lab_perceptual_weight]
         if "lab_gt_dis" in self.variants:                                            # :439,:447 (commented out)
             extras["gt_label_gen_loss"] = F.mse_const(self.Ds(lab_gt), 1.0)
             extra_terms.append(extras["gt_label_gen_loss"])

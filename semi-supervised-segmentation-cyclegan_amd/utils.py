@@ -68,6 +68,81 @@ class GaussianNoise(object):
         return x
 
 
+class _MaxPool2(torch.nn.Module):
+    """nn.MaxPool2d(kernel_size=2, stride=2) (torchvision VGG16 features[4, 9, 16, 23])."""
+
+    def forward(self, x):
+        return F.maxpool2x2(x)
+
+
+class Vgg16(torch.nn.Module):
+    """utils.py:145-177: the first 23 layers of torchvision's VGG16 `features`, cut into four slices (relu1_2, relu2_2, relu3_3,
+    relu4_3); state-dict keys `slice{1..4}.{features index}.{weight,bias}`.  The reference loads `vgg16(pretrained=True)`; there is
+    no network here, so the weights are He-initialised unless `weights` names a torchvision VGG16 state dict (`features.N.*`)."""
+
+    _LAYOUT = (("slice1", ((0, 3, 64), (2, 64, 64))),
+               ("slice2", ((4, None, None), (5, 64, 128), (7, 128, 128))),
+               ("slice3", ((9, None, None), (10, 128, 256), (12, 256, 256), (14, 256, 256))),
+               ("slice4", ((16, None, None), (17, 256, 512), (19, 512, 512), (21, 512, 512))))
+
+    def __init__(self, requires_grad=False, weights=None):
+        super().__init__()
+        from .arch import ops
+        for name, layers in self._LAYOUT:
+            seq = ops.FusedSequential()
+            for idx, cin, cout in layers:
+                if cin is None:
+                    seq.add_module(str(idx), _MaxPool2())
+                else:
+                    conv = ops.Conv2d(cin, cout, 3, 1, 1)
+                    conv.head = True          # the features stay fp32 in bf16 mode (they feed a loss)
+                    with torch.no_grad():
+                        conv.weight.copy_(torch.empty(conv.weight.shape).normal_(0.0, (2.0 / (cin * 9)) ** 0.5))
+                    seq.add_module(str(idx), conv)
+                    seq.add_module(str(idx + 1), ops.ReLU(True))
+            setattr(self, name, seq)
+        if weights is not None:
+            sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
+            own = self.state_dict()
+            for k in own:
+                own[k] = sd["features." + k.split(".", 1)[1]]
+            self.load_state_dict(own, strict=True)
+        if not requires_grad:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def forward(self, x):
+        h1 = self.slice1(x)
+        h2 = self.slice2(h1)
+        h3 = self.slice3(h2)
+        h4 = self.slice4(h3)
+        return {"relu1_2": h1, "relu2_2": h2, "relu3_3": h3, "relu4_3": h4}
+
+    def relu2_2(self, x):
+        return self.slice2(self.slice1(x))
+
+
+_TRANS_MEAN = (0.485, 0.456, 0.406)
+_TRANS_STD = (0.229, 0.224, 0.225)
+
+
+def perceptual_loss(x, y, gpu_ids=None, vgg=None):
+    """utils.py:181-208 as written: u = x / 2 + 1 / 2, then per channel u * std + mean (sic: the reference multiplies by the
+    ImageNet std and adds the mean), both images through VGG16 up to relu2_2, nn.MSELoss between the features.
+    `vgg`: a Vgg16 to reuse (the reference builds - and downloads - a new one on every call)."""
+    dev = x.device
+    if vgg is None:
+        vgg = Vgg16(requires_grad=False).to(dev)
+    a = torch.tensor([0.5 * s for s in _TRANS_STD], device=dev)
+    b = torch.tensor([0.5 * s + m for s, m in zip(_TRANS_STD, _TRANS_MEAN)], device=dev)
+    zero, one = torch.zeros(3, device=dev), torch.full((3,), 1.0 - 1e-5, device=dev)
+
+    def prep(t):        # per-channel affine = the eval-mode BatchNorm kernel with mean 0, var + eps = 1
+        return F.batch_norm_act(t, a, b, zero, one, False, 0.0, 1e-5)
+
+    return F.mse_loss(vgg.relu2_2(prep(y)), vgg.relu2_2(prep(x)))
+
+
 class LambdaLR():
     """Linear decay to zero after `decay_epoch` (utils.py:434-441)."""
 

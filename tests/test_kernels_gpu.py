@@ -597,3 +597,52 @@ def test_one_node_unit_equals_the_two_node_path_bitwise(norm, dev):
             ops.ONE_NODE[0] = True
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_maxpool2x2_and_mse_between_tensors(F, dev):
+    """sscg_maxpool2x2_* (torchvision VGG16's MaxPool2d(2, 2), odd sizes floor) and sscg_mse_* (nn.MSELoss between two tensors)."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 24, 13, 18, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    yr = TF.max_pool2d(xr, 2, 2)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xg = gpu(x, dev).requires_grad_(True)
+    yg = F.maxpool2x2(xg)
+    assert rel_err(yg, yr) < 1e-7          # (the fp32 rounding of the fp64 input)
+    yg.backward(gpu(gy, dev))
+    assert rel_err(xg.grad, xr.grad) < 1e-7
+    a = torch.randn(2, 8, 9, 7, generator=g, dtype=torch.float64)
+    b = torch.randn(2, 8, 9, 7, generator=g, dtype=torch.float64)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lr = TF.mse_loss(ar, br)
+    (3.0 * lr).backward()
+    ag, bg = gpu(a, dev).requires_grad_(True), gpu(b, dev).requires_grad_(True)
+    lg = F.mse_loss(ag, bg)
+    assert rel_err(lg, lr) < 1e-6
+    F.weighted_sum([lg], [3.0]).backward()
+    assert rel_err(ag.grad, ar.grad) < 1e-6 and rel_err(bg.grad, br.grad) < 1e-6
+
+
+def test_perceptual_loss_vs_restatement(dev):
+    """utils.perceptual_loss (commented out at model.py:454,462): VGG16 to relu2_2 on both images, MSE between the
+    features - against oracle.nets.perceptual_loss in fp64 on the same weights (loss and gradient to the generated image)."""
+    from oracle import nets
+    utils = load_sub("utils")
+    torch.manual_seed(4)
+    vgg = utils.Vgg16(requires_grad=False).to(dev)
+    sd = {k: v.detach().double().cpu() for k, v in vgg.state_dict().items()}
+    assert list(sd.keys())[:4] == ["slice1.0.weight", "slice1.0.bias", "slice1.2.weight", "slice1.2.bias"] and "slice4.21.bias" in sd
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 3, 24, 40, generator=g, dtype=torch.float64) * 2 - 1
+    y = torch.rand(2, 3, 24, 40, generator=g, dtype=torch.float64) * 2 - 1
+    xr = x.clone().requires_grad_(True)
+    lr = nets.perceptual_loss(sd, xr, y)
+    lr.backward()
+    xg = gpu(x, dev).requires_grad_(True)
+    lg = utils.perceptual_loss(xg, gpu(y, dev), [0], vgg)
+    assert rel_err(lg, lr) < 1e-5
+    lg.backward()
+    assert rel_err(xg.grad, xr.grad) < 1e-4
+    out = vgg(gpu(x, dev))
+    assert tuple(out["relu4_3"].shape) == (2, 512, 3, 5)

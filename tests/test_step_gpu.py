@@ -203,19 +203,20 @@ def test_first_step_other_datasets_vs_live_oracle(cfg, dev):
 
 def test_opt_in_nets_and_loss_variants(dev):
     """--honour_nets builds what --gen_net/--dis_net name (ResNet-6 generators, PatchGAN discriminators) and
-    --variants adds the L1 image-cycle and the lab_gt discriminator terms the reference has commented out.  No reference
+    --variants adds the L1 image-cycle, lab_gt discriminator and VGG16 perceptual terms the reference has commented out and its dead Gaussian-noise branch.  No reference
     behaviour to pin (the reference never executes these): the step must run, stay finite and move every network."""
     md = load_sub("model")
     args = FX.make_args(dataset="voc2012", crop_height=64, crop_width=64, batch_size=2, gpu_ids=[dev.index or 0],
                         checkpoint_dir="/tmp/sscg_test_ckpt_n4", as_written=True)
-    args.honour_nets, args.gen_net, args.dis_net, args.variants = 1, "resnet_6blocks", "n_layers", "l1_cycle,lab_gt_dis"
+    args.honour_nets, args.gen_net, args.dis_net, args.variants = 1, "resnet_6blocks", "n_layers", "l1_cycle,lab_gt_dis,perceptual,gauss_noise"
+    args.lamda_perceptual, args.lab_perceptual_weight = 1, 1
     args.no_dropout = True
     torch.manual_seed(3)
     m = quiet(md.semisuper_cycleGAN, args)
     before = {k: next(getattr(m, k).parameters()).detach().clone() for k in ("Gis", "Gsi", "Di", "Ds")}
     l_img, l_gt, unl_img = FX.step_batch("n4", 0, 21, 64, 64, 2)
     out = m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev))
-    assert set(ostep.LOSS_KEYS) | {"img_cycle_l1", "gt_label_gen_loss"} == set(out)
+    assert set(ostep.LOSS_KEYS) | {"img_cycle_l1", "gt_label_gen_loss", "img_cycle_loss_perceptual", "lab_loss_perceptual"} == set(out)
     assert all(bool(torch.isfinite(v)) for v in out.values())
     for k, w0 in before.items():
         assert not torch.equal(next(getattr(m, k).parameters()).detach(), w0), k
