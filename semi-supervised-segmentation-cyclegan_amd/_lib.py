@@ -99,6 +99,9 @@ SIGNATURES = {
 }
 
 
+HOOK_GEN = [0]     # bumped by every call of a sscg_debug_* tuning hook
+
+
 class SscgError(RuntimeError):
     pass
 
@@ -116,6 +119,14 @@ def _load():
     v = lib.sscg_abi_version()
     if v != ABI_VERSION:
         raise ImportError("libsscg.so ABI version %d != binding version %d" % (v, ABI_VERSION))
+    # the two tuning hooks change what the planners answer: callers that cache a plan-dependent size key it with HOOK_GEN
+    for name in ("sscg_debug_set_conv_cfg", "sscg_debug_set_wgrad_plan"):
+        raw = getattr(lib, name)
+
+        def hook(*a, _raw=raw):
+            HOOK_GEN[0] += 1
+            return _raw(*a)
+        setattr(lib, name, hook)
     if os.environ.get("SSCG_TRACE"):
         return _Traced(lib)
     return lib

@@ -304,9 +304,25 @@ def _prec():
     return 0 if _MODE[0] == "f32" else 1
 
 
+_PLAN_SIZES = {}
+
+
 def _ws_bytes(d, which):
-    """Workspace size of a conv entry point (asked every time: the split plans also depend on the debug hooks)."""
-    return getattr(lib, "sscg_conv2d_%s_workspace" % which)(C.byref(d))
+    """Workspace size of a conv entry point.  The split plans depend on the geometry and on the tuning hooks: cached per
+    (descriptor object - one per geometry / dtype, make_desc - , entry point, hook generation)."""
+    key = (id(d), which, _lib.HOOK_GEN[0])
+    v = _PLAN_SIZES.get(key)
+    if v is None:
+        v = _PLAN_SIZES[key] = getattr(lib, "sscg_conv2d_%s_workspace" % which)(C.byref(d))
+    return v
+
+
+def _stats_bytes(d, g, l):
+    key = (id(d), "stats", g, l, _lib.HOOK_GEN[0])
+    v = _PLAN_SIZES.get(key)
+    if v is None:
+        v = _PLAN_SIZES[key] = lib.sscg_conv2d_fwd_stats_bytes(C.byref(d), g, l)
+    return v
 
 
 def _build_desc(xshape, wshape, stride, pad, dil, pad_mode, act, slope):
@@ -406,7 +422,7 @@ def conv2d_fwd(x, w, bias, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_N
     y = empty_nhwc(d.N, d.K, d.P, d.Q, x.device, ydt)
     ws = _WS.get(_ws_bytes(d, "fwd"), x.device)
     if stats is not None:
-        nb = lib.sscg_conv2d_fwd_stats_bytes(C.byref(d), int(stats[0]), int(stats[1]))
+        nb = _stats_bytes(d, int(stats[0]), int(stats[1]))
         if nb:
             sbuf = torch.empty(nb, dtype=torch.uint8, device=x.device)
             _timed("fwd", d, lambda: check(lib.sscg_conv2d_fwd_stats(C.byref(d), x.data_ptr(), wop.data_ptr(), _ptr(bias), y.data_ptr(),
