@@ -1,19 +1,20 @@
 #!/usr/bin/env python
 """How busy the GPU is over a rocprofv3 --kernel-trace run: union of the kernel intervals of all streams against the wall span,
-per-stream busy time, and the distribution of the gaps with NO kernel in flight.  usage: python tools/gpu_idle.py <results.db> [skip_frac]
-(the first skip_frac of the span - warm-up - is ignored; default 0.4)"""
+per-stream busy time, and the distribution of the gaps with NO kernel in flight.  usage: python tools/gpu_idle.py <results.db> [steps]
+The window is the last `steps` (default 4) training steps, delimited by the optimiser launches (two adam_kernel launches per step)."""
 import sqlite3
 import sys
 
 
 def main():
     db = sqlite3.connect(sys.argv[1])
-    skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     rows = db.execute("select start, end, stream_id, name from kernels order by start").fetchall()
-    t0, t1 = rows[0][0], max(r[1] for r in rows)
-    lo = t0 + skip * (t1 - t0)
-    rows = [r for r in rows if r[0] >= lo]
-    span = max(r[1] for r in rows) - rows[0][0]
+    adam = [r[1] for r in rows if "adam_kernel" in r[3]]
+    lo, hi = adam[-1 - 2 * steps], adam[-1]
+    rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
+    span = hi - lo
+    print("window: %d steps, %.2f ms per step" % (steps, span / steps / 1e6))
     busy = 0
     cur_s, cur_e = rows[0][0], rows[0][1]
     gaps = []
