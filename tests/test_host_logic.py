@@ -140,7 +140,6 @@ def test_checkpoints_interchange_with_the_reference_modules(tmp_path):
     format, model.py:646-655) loads into this build's networks with strict=True, and a checkpoint written by this build loads
     into the reference's modules - for the DeepLab generators and the pixel / PatchGAN discriminators.  Runs where
     /root/reference exists (the build container); no tensor arithmetic, so no GPU is needed."""
-    import importlib
     import subprocess
     import sys
     code = r'''
