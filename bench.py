@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 PKG = "semi-supervised-segmentation-cyclegan_amd"
 
 # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 256 CU x 2.4 GHz; dense bf16 MFMA (no sparsity)
-PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16c": 2500.0}
+PEAK = {"f32": 157.3, "f32s": 157.3, "bf16": 2500.0, "bf16c": 2500.0}
 # conv FLOP of one as-written step per labeled/unlabeled pair (BASELINE.md section 2 / SURVEY 8(d), forward hooks on every conv)
 CONFIGS = {
     2: dict(dataset="voc2012", C=21, H=256, W=256, B=8, dtype="f32", tflop_per_pair=1.983,
@@ -42,7 +42,8 @@ CONFIGS = {
             label="Cityscapes 20-class 256x512 semisupervised_cycleGAN as-written G+D step"),
 }
 DTYPE_TEXT = {"f32": "fp32", "bf16": "bf16 (bf16 activations + conv weight operands in HBM, fp32 accumulate / master weights / norm statistics / losses)",
-              "bf16c": "bf16 conv contractions (fp32 tensors)"}
+              "bf16c": "bf16 conv contractions (fp32 tensors)",
+              "f32s": "fp32 tensors, fp32-accurate contractions as six bf16 piece products on the bf16 matrix cores (experimental split mode)"}
 
 
 def main():
@@ -56,7 +57,7 @@ def main():
     ap.add_argument("--no-elided", action="store_true")
     ap.add_argument("--no-small", action="store_true", help="skip the 64x64 batch-2 host-bound figure")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16c"], default=None, help="default: the configuration's")
+    ap.add_argument("--dtype", choices=["f32", "f32s", "bf16", "bf16c"], default=None, help="default: the configuration's")
     ap.add_argument("--no-bf16", action="store_true", help="config 2: skip the secondary bf16 figure")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -156,6 +157,16 @@ def main():
         out["bf16"] = {"value": round(world * bsz * a.steps / dtb, 4), "unit": "img/s", "ms_per_step": round(1e3 * dtb / a.steps, 3),
                        "losses_finite": all(bool(torch.isfinite(v)) for v in lb.values()),
                        "note": "not the headline (this configuration is fp32): " + DTYPE_TEXT["bf16"]}
+
+    # experimental: the same fp32 step with the contractions of the heavy convs run as split-bf16 products
+    if dtype == "f32" and not a.no_bf16:
+        F.set_conv_precision("f32s")
+        run(a.warmup + a.steps)
+        dts, ls = timed(a.warmup, a.steps)
+        F.set_conv_precision("f32")
+        out["f32_split"] = {"value": round(world * bsz * a.steps / dts, 4), "unit": "img/s", "ms_per_step": round(1e3 * dts / a.steps, 3),
+                            "losses_finite": all(bool(torch.isfinite(v)) for v in ls.values()),
+                            "note": "not the headline: " + DTYPE_TEXT["f32s"]}
 
     # The reference's own default is batch 2 (main.py:14) on small crops: there the step is bound by the host's issue rate, not by
     # the GPU.  One line beside the headline, single rank only (a second, small model: 64x64, batch 2, same dtype).

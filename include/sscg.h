@@ -59,7 +59,9 @@ typedef struct sscg_conv_desc {
     int32_t w_dtype;    /* ... of the weight operand handed to forward ([K][R][S][C]) / dgrad ([C][R][S][K]) */
     int32_t y_dtype;    /* ... of the [N][P][Q][K] tensor (forward output, dgrad / wgrad dy) */
     int32_t precision;  /* fp32 tensors only: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = operands rounded to bf16
-                         * (RNE) between LDS and the matrix cores, v_mfma_f32_32x32x16_bf16, fp32 accumulation */
+                         * (RNE) between LDS and the matrix cores, v_mfma_f32_32x32x16_bf16, fp32 accumulation; 2 = every
+                         * operand split into three bf16 pieces, six exact piece products per pair accumulated in fp32
+                         * (fp32-accurate; the LDS-DMA tile classes, exact fp32 elsewhere) */
 } sscg_conv_desc;
 /* Supported dtype combinations.  forward: (x, w) both fp32 -> y fp32|bf16 (fp32 MFMA kernel: stems and few-channel
  * inputs); (x, w) both bf16 with C % 64 == 0 -> y fp32|bf16 (bf16 MFMA kernel, bf16 LDS tiles).  dgrad: the same with

@@ -40,7 +40,7 @@ def get_args(argv=None):
     parser.add_argument("--as_written", type=int, default=1, help="1: also run the forwards whose outputs the reference never uses")
     parser.add_argument("--data", type=str, choices=["auto", "real", "synthetic"], default="auto",
                         help="real: the datasets under ./data (reference layout); synthetic: seeded random batches; auto: real if present")
-    parser.add_argument("--dtype", type=str, choices=["f32", "bf16", "bf16c"], default="f32",
+    parser.add_argument("--dtype", type=str, choices=["f32", "f32s", "bf16", "bf16c"], default="f32",
                         help="f32: the reference's arithmetic (exact fp32 MFMA); bf16: bf16 activations / weight operands in HBM, "
                              "fp32 master weights, statistics and losses (BASELINE configs 3/5); bf16c: fp32 tensors, bf16 contractions")
     parser.add_argument("--honour_nets", type=int, default=0,

@@ -6,6 +6,20 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = h + m + l exactly to 2^-24 |x|: three bfloat16 pieces of an fp32 value (round to nearest each time; the residuals are
+// exact in fp32).  The "split" contraction mode multiplies the pieces on the bf16 matrix cores: a0*b0 + a0*b1 + a1*b0 + a0*b2 +
+// a1*b1 + a2*b0 (products of 8-bit mantissas are exact, the accumulation is fp32) - the terms left out are below 2^-24 |a*b|.
+struct sscg_bf3 { __bf16 h, m, l; };
+__device__ __forceinline__ sscg_bf3 sscg_split3(float x) {
+    sscg_bf3 t;
+    t.h = (__bf16)x;
+    const float r1 = x - (float)t.h;
+    t.m = (__bf16)r1;
+    const float r2 = r1 - (float)t.m;
+    t.l = (__bf16)r2;
+    return t;
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 

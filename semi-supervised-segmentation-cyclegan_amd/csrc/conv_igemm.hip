@@ -81,7 +81,7 @@ __device__ __forceinline__ void store_out(void* dst, size_t idx, float v, int ou
 // 256 B of zeros: the source of LDS-DMA lanes that fall into padding / outside the tile
 __device__ float sscg_zero_page[64];
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false, bool BF16 = false, bool N4 = false>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false, int BF16 = 0, bool N4 = false>
 __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     // N4: at most four output columns (the 3-channel heads).  The 256 x 32 tile is staged exactly like any other, but the
     // contraction runs on v_mfma_f32_4x4x1_f32 - 16 independent 4x4 outer products per instruction = 64 rows x 4 columns x
@@ -419,6 +419,37 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
             if (kt + 1 < nk) load_tile();
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {      // two MFMAs of k = 16: lane half h contributes the k-groups (2*g2, 2*g2+1), slot h
+                if constexpr (BF16 == 2) {
+                    // split mode (precision 2): fp32-accurate products on the bf16 matrix cores - 6 MFMAs of 32 cycles instead
+                    // of 8 fp32 MFMAs of 64 per 16 k
+                    bf16x8 a0[TM], a1[TM], a2[TM], b0[TN], b1[TN], b2[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            { const sscg_bf3 t3 = sscg_split3(ga[2 * g2][i][e]); a0[i][e] = t3.h; a1[i][e] = t3.m; a2[i][e] = t3.l; }
+                            { const sscg_bf3 t3 = sscg_split3(ga[2 * g2 + 1][i][e]); a0[i][4 + e] = t3.h; a1[i][4 + e] = t3.m; a2[i][4 + e] = t3.l; }
+                        }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            { const sscg_bf3 t3 = sscg_split3(gb[2 * g2][j][e]); b0[j][e] = t3.h; b1[j][e] = t3.m; b2[j][e] = t3.l; }
+                            { const sscg_bf3 t3 = sscg_split3(gb[2 * g2 + 1][j][e]); b0[j][4 + e] = t3.h; b1[j][4 + e] = t3.m; b2[j][4 + e] = t3.l; }
+                        }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b0[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b2[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                        }
+                    continue;
+                }
                 bf16x8 pa[TM], pb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -508,7 +539,7 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
     // fp32 tensors take the 4-row shortcut only with bf16-rounded contractions (precision 1: the stems of the bf16 networks);
     // the exact-fp32 path keeps every element in fp64: a 1e-7 change of a BatchNorm statistic is one more sample of DeepLab's
     // chaotic fp32 trajectory, and the chained-loss parity test (4 x the reference's own fp32 noise) then sits on its edge.
-    const bool slow_stats = want_stats && (p.precision == 0 || m0 + BM > gb || m0 + BM > p.M);
+    const bool slow_stats = want_stats && (p.precision != 1 || m0 + BM > gb || m0 + BM > p.M);
     const bool fast_stats = want_stats && !slow_stats;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -686,7 +717,7 @@ static size_t kc_split_bytes(const KcSplit& sp, int M, int Ng) {
     return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false, bool BF16 = false, bool N4 = false>
+template <int MODE, int WM, int WN, int TM, int TN, int VEC, bool FAST, int NBUF = 2, bool DMA = false, int BF16 = 0, bool N4 = false>
 int launch_kc(const KcParams& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -735,8 +766,9 @@ int dispatch_kc(const KcParams& p, hipStream_t st) {
         case 4: if (p.precision == 1) return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST, 2, false, true>(p, st);
                 return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST>(p, st);
         case 5: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 1>(p, st);   // 128x128, single LDS image (experimental)
-        case 6: if constexpr (FAST) { if (p.precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
-        case 7: if constexpr (FAST) { if (p.precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, true>(p, st); return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
+        // (precision 2, the split mode, exists on the two LDS-DMA tile classes only - every heavy conv; elsewhere it means exact fp32)
+        case 6: if constexpr (FAST) { if (p.precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, 1>(p, st); if (p.precision == 2) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, 2>(p, st); return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
+        case 7: if constexpr (FAST) { if (p.precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, 1>(p, st); if (p.precision == 2) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, 2>(p, st); return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
         case 8: if constexpr (FAST) return launch_kc<MODE, 4, 1, 2, 1, VEC, FAST, 2, true, false, true>(p, st); else return SSCG_ERR_UNSUPPORTED;   // 256 x (<= 4): 4x4x1 MFMA
         default: return SSCG_ERR_BAD_ARG;
     }
@@ -777,7 +809,7 @@ static int check_desc(const sscg_conv_desc* d) {
     if (!d) return SSCG_ERR_BAD_ARG;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0) return SSCG_ERR_BAD_ARG;
     if (d->stride <= 0 || d->dil <= 0 || d->pad < 0) return SSCG_ERR_BAD_ARG;
-    if (!dt_ok(d->x_dtype) || !dt_ok(d->w_dtype) || !dt_ok(d->y_dtype) || (d->precision != 0 && d->precision != 1)) return SSCG_ERR_BAD_ARG;
+    if (!dt_ok(d->x_dtype) || !dt_ok(d->w_dtype) || !dt_ok(d->y_dtype) || (d->precision < 0 || d->precision > 2)) return SSCG_ERR_BAD_ARG;
     int P = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
     int Q = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
     if (P != d->P || Q != d->Q) return SSCG_ERR_BAD_ARG;

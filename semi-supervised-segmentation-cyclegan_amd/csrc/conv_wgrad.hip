@@ -44,7 +44,7 @@ __device__ float sscg_zero_page[64];
 // TX / TY: element types of x / dy in HBM (the LDS image and the contraction are fp32 either way; bf16 operands are widened by
 // the register-staged loader - the mixed pairs are the layers at a network's fp32 boundary: stems read fp32 images, heads emit
 // fp32 logits, everything between is bf16 and runs on conv_bf16.hip)
-template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false, bool BF16 = false, typename TX = float, typename TY = float>
+template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false, int BF16 = 0, typename TX = float, typename TY = float>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     static_assert(!DMA || (VA == 4 && VB == 4), "LDS-DMA staging needs 16-byte granules");
     static_assert(!DMA || (sizeof(TX) == 4 && sizeof(TY) == 4), "LDS-DMA copies fp32 tiles");
@@ -244,6 +244,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
             // the lane half h keeps the pixel parity it has in the fp32 walk, A and B alike
 #pragma unroll
             for (int g2 = 0; g2 < BKP / 16; ++g2) {
+                if constexpr (BF16 == 2) {      // split mode (common.h sscg_split3): fp32-accurate on the bf16 matrix cores
+                    bf16x8 a0[TM], a1[TM], a2[TM], b0[TN], b1[TN], b2[TN];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int kp = g2 * 8 + e;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) { const sscg_bf3 t3 = sscg_split3((float)a[kp * 2 * LDA + i * 32]); a0[i][e] = t3.h; a1[i][e] = t3.m; a2[i][e] = t3.l; }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) { const sscg_bf3 t3 = sscg_split3((float)b[kp * 2 * LDB + j * 32]); b0[j][e] = t3.h; b1[j][e] = t3.m; b2[j][e] = t3.l; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b0[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b2[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                        }
+                    continue;
+                }
                 bf16x8 pa[TM], pb[TN];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -387,7 +410,7 @@ WgPlan plan_wgrad(const sscg_conv_desc* d) {
     return pl;
 }
 
-template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false, bool BF16 = false, typename TX = float, typename TY = float>
+template <int WM, int WN, int TM, int TN, int VA, int VB, bool DMA = false, int BF16 = 0, typename TX = float, typename TY = float>
 int launch_wg(WgParams p, int splits, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -409,9 +432,11 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
 template <int VA, int VB>
 int dispatch_wg(const WgParams& p, const WgPlan& pl, int precision, hipStream_t st) {
     switch (pl.cfg) {
-        case 0: if (precision == 1) return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4), true>(p, pl.splits, st);
+        case 0: if (precision == 1) return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4), 1>(p, pl.splits, st);
+                if constexpr (VA == 4 && VB == 4) { if (precision == 2) return launch_wg<2, 2, 2, 2, VA, VB, true, 2>(p, pl.splits, st); }
                 return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);   // LDS-DMA staging when vectorisable
-        case 1: if (precision == 1) return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4), true>(p, pl.splits, st);
+        case 1: if (precision == 1) return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4), 1>(p, pl.splits, st);
+                if constexpr (VA == 4 && VB == 4) { if (precision == 2) return launch_wg<2, 2, 1, 1, VA, VB, true, 2>(p, pl.splits, st); }
                 return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);
         case 2: if (precision == 1) return launch_wg<1, 4, 1, 1, VA, VB, false, true>(p, pl.splits, st);
                 return launch_wg<1, 4, 1, 1, VA, VB>(p, pl.splits, st);

@@ -254,10 +254,13 @@ def set_conv_precision(mode):
       "bf16"  (BASELINE configs 3/5): activations and conv-weight operand copies are bfloat16 in HBM, bf16 LDS tiles,
               v_mfma_f32_32x32x16_bf16 with fp32 accumulation; network inputs/outputs, norm statistics, losses, weight
               gradients, master weights and Adam moments stay fp32;
-      "bf16c" (round-1 mode): fp32 tensors, operands rounded to bf16 between LDS and the matrix cores."""
-    m = {"f32": "f32", "fp32": "f32", "float32": "f32", "bf16": "bf16", "bfloat16": "bf16", "bf16c": "bf16c"}.get(str(mode).lower())
+      "bf16c" (round-1 mode): fp32 tensors, operands rounded to bf16 between LDS and the matrix cores;
+      "f32s"  (experimental): fp32 tensors and fp32-accurate contractions on the BF16 matrix cores - every operand is split into
+              three bfloat16 pieces between LDS and the matrix cores and six piece products (exact) are accumulated in fp32
+              (sscg_conv_desc.precision = 2; the heavy LDS-DMA tile classes only, everything else stays exact fp32)."""
+    m = {"f32": "f32", "fp32": "f32", "float32": "f32", "bf16": "bf16", "bfloat16": "bf16", "bf16c": "bf16c", "f32s": "f32s"}.get(str(mode).lower())
     if m is None:
-        raise _lib.SscgError("conv precision must be 'f32', 'bf16' or 'bf16c', got %r" % (mode,))
+        raise _lib.SscgError("conv precision must be 'f32', 'f32s', 'bf16' or 'bf16c', got %r" % (mode,))
     _MODE[0] = m
 
 
@@ -299,8 +302,14 @@ def make_desc(xshape, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, act=ACT_NONE
     return d
 
 
-def _prec():
-    """`precision` field for fp32-tensor contractions: bf16 rounding between LDS and the matrix cores in both bf16 modes."""
+SPLIT_KINDS = {"fwd", "dgrad", "wgrad"}      # which products the experimental split mode covers (bisection aid)
+
+
+def _prec(kind="fwd"):
+    """`precision` field for fp32-tensor contractions: bf16 rounding between LDS and the matrix cores in both bf16 modes; 2 = the
+    split-bf16 mode (fp32-accurate)."""
+    if _MODE[0] == "f32s":
+        return 2 if kind in SPLIT_KINDS else 0
     return 0 if _MODE[0] == "f32" else 1
 
 
@@ -460,7 +469,7 @@ def weight_transposed(w, dtype=torch.float32):
 def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0, out_dtype=torch.float32):
     """dx = act(dgrad(dy, wt) + bias); `wt` is the transposed operand copy [C][R][S][K] (weight_transposed), fp32 for an
     fp32 dy, bf16 for a bf16 dy."""
-    d = make_desc(xshape, wshape, stride, pad, dil, xdt=_DT[out_dtype], wdt=_dt(wt), ydt=_dt(dy), prec=_prec())
+    d = make_desc(xshape, wshape, stride, pad, dil, xdt=_DT[out_dtype], wdt=_dt(wt), ydt=_dt(dy), prec=_prec("dgrad"))
     dx = empty_nhwc(d.N, d.C, d.H, d.W, dy.device, out_dtype)
     ws = _WS.get(_ws_bytes(d, "dgrad"), dy.device)
     _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wt.data_ptr(), _ptr(bias), dx.data_ptr(),
@@ -481,7 +490,7 @@ def conv2d_dgrad_param(dy, w, xshape, wshape, stride, pad, dil, bias=None, act=A
 
 
 def conv2d_wgrad(x, dy, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, out=None, accumulate=False):
-    d = make_desc(x.shape, wshape, stride, pad, dil, pad_mode, xdt=_dt(x), ydt=_dt(dy), prec=_prec())
+    d = make_desc(x.shape, wshape, stride, pad, dil, pad_mode, xdt=_dt(x), ydt=_dt(dy), prec=_prec("wgrad"))
     if out is None:
         k, c, r, s = wshape
         out = torch.empty((k, c, r, s), dtype=torch.float32, device=x.device, memory_format=CL)

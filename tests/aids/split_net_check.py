@@ -1,0 +1,107 @@
+#!/usr/bin/env python
+"""Bisection aid for the experimental split-bf16 contraction mode: which conv product moves a ResnetGenerator's input gradient
+away from the fp64 golden (keyed weights / inputs of the network goldens).  usage: python tests/aids/split_net_check.py"""
+import contextlib
+import importlib
+import io
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import fixtures as FX  # noqa: E402
+
+F = importlib.import_module("semi-supervised-segmentation-cyclegan_amd.functional")
+arch = importlib.import_module("semi-supervised-segmentation-cyclegan_amd.arch")
+dev = torch.device("cuda", 0)
+g2 = np.load(os.path.join(ROOT, "tests", "golden", "g2_nets.npz"))
+name, kind, args, xshape = [n for n in FX.NETS if n[0] == "resnet9sm_3_21"][0]
+with contextlib.redirect_stdout(io.StringIO()):
+    net = arch.define_Gen(args[0], args[1], 64, kind, "instance", False, [0])
+net.load_state_dict(FX.net_weights(name, kind, args), strict=True)
+net.train()
+x0 = FX.net_input(name, xshape)
+dx64 = torch.from_numpy(g2[name + "/dx/f64"])
+y64 = torch.from_numpy(g2[name + "/y/f64"])
+
+
+def run(mode, kinds):
+    F.set_conv_precision(mode)
+    F.SPLIT_KINDS.clear()
+    F.SPLIT_KINDS.update(kinds)
+    x = x0.to(dev).requires_grad_(True)
+    y = net(x)
+    gy = FX.net_grad_out(name, y.shape).to(dev)
+    y.backward(F.to_nhwc(gy))
+    torch.cuda.synchronize()
+    F.set_conv_precision("f32")
+    return y.detach().double().cpu(), x.grad.double().cpu()
+
+
+def rel(a, b):
+    return "L2 %.2e max %.2e" % (float((a - b).norm() / b.norm()), float((a - b).abs().max() / b.abs().max()))
+
+
+y0, d0 = run("f32", ())
+print("f32 vs golden: y %s | dx %s" % (rel(y0, y64), rel(d0, dx64)))
+for kinds in (("fwd",), ("dgrad",), ("wgrad",), ("fwd", "dgrad", "wgrad")):
+    y, d = run("f32s", kinds)
+    print("split %-16s vs golden: y %s | dx %s   || vs f32 mode: dx %s" % ("+".join(kinds), rel(y, y64), rel(d, dx64), rel(d, d0)))
+
+
+# ---- layer by layer: forward outputs and the gradients arriving at every module, f32 vs split-forward
+def trace(mode, kinds):
+    F.set_conv_precision(mode)
+    F.SPLIT_KINDS.clear()
+    F.SPLIT_KINDS.update(kinds)
+    acts, grads, hooks = {}, {}, []
+    for nm, mod in net.named_modules():
+        if len(list(mod.children())) == 0:
+            def fh(m, i, o, nm=nm):
+                acts[nm] = o.detach().double().cpu()
+                acts[nm + "/in"] = i[0].detach().double().cpu()
+            hooks.append(mod.register_forward_hook(fh))
+            hooks.append(mod.register_full_backward_hook(lambda m, gi, go, nm=nm: grads.__setitem__(nm, go[0].detach().double().cpu())))
+    x = x0.to(dev).requires_grad_(True)
+    y = net(x)
+    y.backward(F.to_nhwc(FX.net_grad_out(name, y.shape).to(dev)))
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    F.set_conv_precision("f32")
+    return acts, grads
+
+
+F.ONE = None
+ops = importlib.import_module("semi-supervised-segmentation-cyclegan_amd.arch.ops")
+ops.ONE_NODE[0] = False          # module-level hooks need the two-node path
+a0, g0 = trace("f32", ())
+a1, g1 = trace("f32s", ("fwd",))
+print("forward outputs (first 12 with rel L2 > 1e-5):")
+n = 0
+for k in a0:
+    e = float((a1[k] - a0[k]).norm() / a0[k].norm().clamp_min(1e-30))
+    if e > 1e-5 and n < 12:
+        print("   %-40s %.2e  shape %s" % (k, e, tuple(a0[k].shape)))
+        n += 1
+print("gradients arriving (in backward order, first 12 with rel L2 > 1e-5):")
+n = 0
+for k in g0:
+    if k in g1:
+        e = float((g1[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30))
+        if e > 1e-5 and n < 12:
+            print("   %-40s %.2e" % (k, e))
+            n += 1
+
+k = "res_model.7.res_block.1.1/in"
+xa, xb = a0[k], a1[k]
+va = xa.var((2, 3), unbiased=False)
+print("conv %s output: per-channel variance min %.3e median %.3e; |mean| max %.3e" % (k, float(va.min()), float(va.median()), float(xa.mean((2, 3)).abs().max())))
+xh_a = (xa - xa.mean((2, 3), keepdim=True))
+xh_b = (xb - xb.mean((2, 3), keepdim=True))
+flips = ((xh_a > 0) != (xh_b > 0))
+print("sign flips of x - mean between the modes: %d of %d; in channels: %s" % (int(flips.sum()), flips.numel(), sorted(set(flips.nonzero()[:, 1].tolist()))[:10]))
+print("max |difference| of the conv output: %.3e (max |value| %.3e)" % (float((xa - xb).abs().max()), float(xa.abs().max())))

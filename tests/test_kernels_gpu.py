@@ -646,3 +646,36 @@ def test_perceptual_loss_vs_restatement(dev):
     assert rel_err(xg.grad, xr.grad) < 1e-4
     out = vgg(gpu(x, dev))
     assert tuple(out["relu4_3"].shape) == (2, 512, 3, 5)
+
+
+@pytest.mark.parametrize("case", [(8, 256, 33, 33, 256, 3, 1, 2, 2), (2, 256, 64, 64, 256, 3, 1, 1, 1), (4, 256, 33, 33, 1024, 1, 1, 0, 1)],
+                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_s%d_p%d_d%d" % c)
+def test_split_bf16_contraction_is_fp32_accurate(case, F, dev):
+    """--dtype f32s (sscg_conv_desc.precision = 2): every fp32 operand as three bfloat16 pieces, six exact piece products per pair
+    on the bf16 matrix cores, fp32 accumulation.  Against fp64: the same error class as the exact fp32 kernels (a few 1e-7), three
+    orders of magnitude below the bf16-rounded contraction."""
+    n, c, h, w, k, r, s, p, d = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, r, r, generator=g) * (1.0 / (c * r * r) ** 0.5)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yr = TF.conv2d(xr, wr, None, s, p, d)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    errs = {}
+    for mode in ("f32", "f32s"):
+        F.set_conv_precision(mode)
+        try:
+            xg, wg = gpu(x, dev), gpu(wt, dev)
+            y = F.conv2d_fwd(xg, wg, None, s, p, d)
+            wtt = F.weight_transposed(wg)
+            dx = F.conv2d_dgrad(gpu(gy, dev), wtt, x.shape, wt.shape, s, p, d)
+            dw = F.conv2d_wgrad(xg, gpu(gy, dev), wt.shape, s, p, d)
+            errs[mode] = (rel_err(y, yr), rel_err(dx, xr.grad), rel_err(dw, wr.grad))
+        finally:
+            F.set_conv_precision("f32")
+    print("split-bf16 vs exact fp32, error against fp64 (fwd, dgrad, wgrad):", errs)
+    for e in errs["f32s"]:
+        assert e < 2e-6
+    for a, b in zip(errs["f32s"], errs["f32"]):
+        assert a < 4 * b + 2e-7
