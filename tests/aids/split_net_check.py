@@ -75,7 +75,6 @@ def trace(mode, kinds):
     return acts, grads
 
 
-F.ONE = None
 ops = importlib.import_module("semi-supervised-segmentation-cyclegan_amd.arch.ops")
 ops.ONE_NODE[0] = False          # module-level hooks need the two-node path
 a0, g0 = trace("f32", ())
