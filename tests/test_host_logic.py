@@ -194,3 +194,23 @@ def test_bench_cpu_baseline_leg_runs_and_reports(monkeypatch):
     assert "32x32" in r["sample"] and "1 warm-up + 3 timed" in r["sample"] and r["cpu_model"] in r["sample"]
     assert r["elided_dead_work"]["value"] > 0
     json.dumps(r)
+
+
+def test_plan_size_cache_follows_the_tuning_hooks():
+    """functional caches the plan-dependent workspace sizes per (descriptor, entry point, tuning-hook generation): a tuning hook
+    call (tests, tools/) must invalidate them - the planners answer differently under a forced tile class."""
+    import ctypes as C
+    F = load_sub("functional")
+    L = load_sub("_lib")
+    d = F.make_desc((16, 256, 33, 65), (256, 256, 3, 3), 1, 2, 2, xdt=L.BF16, wdt=L.BF16, ydt=L.BF16)
+    try:
+        a = F._ws_bytes(d, "fwd")
+        assert a == L.lib.sscg_conv2d_fwd_workspace(C.byref(d)) and F._ws_bytes(d, "fwd") == a
+        g0 = L.HOOK_GEN[0]
+        L.lib.sscg_debug_set_conv_cfg(101)          # 64x64 tiles: a different tail split, a different workspace
+        assert L.HOOK_GEN[0] == g0 + 1
+        b = F._ws_bytes(d, "fwd")
+        assert b == L.lib.sscg_conv2d_fwd_workspace(C.byref(d)) and b != a
+    finally:
+        L.lib.sscg_debug_set_conv_cfg(-1)
+    assert F._ws_bytes(d, "fwd") == a
