@@ -175,3 +175,27 @@ def test_bf16_emulation_rounds_where_the_build_stores_bf16():
     xin = FX.net_input("pixel_3", (2, 3, 32, 32), torch.float64)
     y0, y1 = nets.pixel_discriminator(sd, xin), nets.pixel_discriminator(sd, xin, q=q)
     assert 1e-5 < rel(y1, y0) < 5e-2
+
+
+def test_perceptual_loss_restatement_against_torch_modules():
+    """oracle.nets.perceptual_loss (utils.py:145-208; UNPINNED against the live reference: torchvision is absent) against an
+    independent composition of torch.nn modules laid out like torchvision's VGG16 `features[0:9]` (configuration D: 64, 64, M,
+    128, 128) with the reference's preprocessing (x / 2 + 1 / 2, then per channel * std + mean, in place)."""
+    from torch import nn
+    torch.manual_seed(0)
+    feats = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(True), nn.Conv2d(64, 64, 3, padding=1), nn.ReLU(True),
+                          nn.MaxPool2d(2, 2), nn.Conv2d(64, 128, 3, padding=1), nn.ReLU(True), nn.Conv2d(128, 128, 3, padding=1),
+                          nn.ReLU(True)).double()
+    sd = {}
+    for idx, sl in ((0, 1), (2, 1), (5, 2), (7, 2)):
+        sd["slice%d.%d.weight" % (sl, idx)] = feats[idx].weight.detach()
+        sd["slice%d.%d.bias" % (sl, idx)] = feats[idx].bias.detach()
+    x = torch.rand(2, 3, 17, 22, dtype=torch.float64) * 2 - 1
+    y = torch.rand(2, 3, 17, 22, dtype=torch.float64) * 2 - 1
+    u, v = x * 0.5 + 0.5, y * 0.5 + 0.5
+    for i, (m, s) in enumerate(zip((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))):
+        u[:, i, :, :] = u[:, i, :, :] * s + m
+        v[:, i, :, :] = v[:, i, :, :] * s + m
+    want = nn.MSELoss()(feats(v), feats(u))
+    got = nets.perceptual_loss(sd, x, y)
+    assert abs(float(got) - float(want)) <= 1e-12 * abs(float(want))
