@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Throughput of the hot path: full G+D training steps of the semi-supervised CycleGAN on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|3]
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
     (N > 1 without a launcher: bench.py starts its own N ranks through torch.distributed.run)
 
 --config 2 (default) = BASELINE.json configs[1], the configuration the metric is quoted on: VOC2012 21-class, 256x256,
@@ -40,6 +40,12 @@ CONFIGS = {
             label="VOC2012 21-class 256x256 semisupervised_cycleGAN as-written G+D step"),
     3: dict(dataset="cityscapes", C=20, H=256, W=512, B=16, dtype="bf16", tflop_per_pair=3.914,
             label="Cityscapes 20-class 256x512 semisupervised_cycleGAN as-written G+D step"),
+    # the per-rank workloads of the two 8-GPU configurations (run them with --gpus 8): configs[3] = config 2 on every rank
+    # (global batch 64), configs[4] = Cityscapes 512x1024, global batch 32 = batch 4 per rank, bf16
+    4: dict(dataset="voc2012", C=21, H=256, W=256, B=8, dtype="f32", tflop_per_pair=1.983,
+            label="VOC2012 21-class 256x256 semisupervised_cycleGAN as-written G+D step"),
+    5: dict(dataset="cityscapes", C=20, H=512, W=1024, B=4, dtype="bf16", tflop_per_pair=15.387,
+            label="Cityscapes 20-class 512x1024 semisupervised_cycleGAN as-written G+D step"),
 }
 DTYPE_TEXT = {"f32": "fp32", "bf16": "bf16 (bf16 activations + conv weight operands in HBM, fp32 accumulate / master weights / norm statistics / losses)",
               "bf16c": "bf16 conv contractions (fp32 tensors)",
