@@ -8,6 +8,8 @@
     semisupervised_cycleGAN, batch 8 per GPU, fp32.
 --config 3 = BASELINE.json configs[2]: Cityscapes 20-class, 256x512, batch 16 per GPU, bf16 (bf16 activations and conv
     weight operands in HBM, fp32 master weights / statistics / losses).
+--config 4 / 5 = the per-rank workloads of configs[3] (config 2 on each of 8 ranks) and configs[4] (Cityscapes 512x1024, global
+    batch 32 = batch 4 per rank, bf16): meant for `--gpus 8`.
 Random-init weights (the reference's N(0,0.02) init), synthetic image/label batches already resident in HBM.
 One step = one iteration of /root/reference model.py:370-552 as written (all seven networks, both optimisers).
 Weak scaling: every rank runs the per-GPU batch; `value` = N * batch * K / (max-over-ranks wall time of K steps).
@@ -17,7 +19,10 @@ Besides the contract line this prints, in the same JSON object:
                  extra (untimed) step: algorithmic FLOP / kernel time against the MFMA peak of the arithmetic
                  (fp32: 157.3 TFLOP/s; bf16: 2500 TFLOP/s dense);
   cpu_baseline - oracle/ (the CPU restatement of the reference) timed on this box's host cores on a bounded
-                 sample (rank 0, N = 1 only).
+                 sample (rank 0, N = 1 only);
+  secondary figures, never the headline: elided_dead_work (the step without the reference's unused forwards), bf16 and f32_split
+                 (the fp32 configuration in the bf16 / experimental split-bf16 arithmetic), host_bound_case (64x64, batch 2: the
+                 host's issue cost of a step), host_issue_ms_per_step.
 """
 import argparse
 import contextlib
