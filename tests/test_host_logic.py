@@ -214,3 +214,26 @@ def test_plan_size_cache_follows_the_tuning_hooks():
     finally:
         L.lib.sscg_debug_set_conv_cfg(-1)
     assert F._ws_bytes(d, "fwd") == a
+
+
+def test_bench_spawns_its_own_ranks_when_no_launcher_is_present(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE re-executes itself under torch.distributed.run (one rank per GPU, 127.0.0.1
+    rendezvous, the caller's flags passed through); on a box with fewer GPUs the ranks share GPU 0 over gloo."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--config", "3"])
+    assert bench.spawn_ranks(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--config", "3"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    if torch.cuda.device_count() < 4:
+        assert seen["env"]["SSCG_DP_SHARED_GPU"] == "1" and seen["env"]["SSCG_DP_BACKEND"] == "gloo"
