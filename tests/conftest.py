@@ -25,6 +25,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs (a kernel that never returns) must not take the box with it: with pytest-timeout installed every
+    gpu test gets a 20-minute ceiling, enforced from a watchdog thread (a blocked HIP call never returns to a signal handler)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(1200, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def F():
     return load_sub("functional")
