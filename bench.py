@@ -5,7 +5,10 @@
     (N > 1 without a launcher: bench.py starts its own N ranks through torch.distributed.run)
 
 --config 2 (default) = BASELINE.json configs[1], the configuration the metric is quoted on: VOC2012 21-class, 256x256,
-    semisupervised_cycleGAN, batch 8 per GPU, fp32.
+    semisupervised_cycleGAN, batch 8 per GPU, fp32 tensors.  `--dtype f32` (the default of this configuration) contracts the
+    heavy convolutions with the fp32-accurate split contraction on the bf16 matrix cores (conv_split.hip; at or below the exact
+    fp32 MFMA kernel's error against fp64 on every shape of the step); `--dtype f32x` is the exact fp32 MFMA, reported beside
+    the headline as `f32_exact`.
 --config 3 = BASELINE.json configs[2]: Cityscapes 20-class, 256x512, batch 16 per GPU, bf16 (bf16 activations and conv
     weight operands in HBM, fp32 master weights / statistics / losses).
 --config 4 / 5 = the per-rank workloads of configs[3] (config 2 on each of 8 ranks) and configs[4] (Cityscapes 512x1024, global
@@ -17,12 +20,13 @@ Weak scaling: every rank runs the per-GPU batch; `value` = N * batch * K / (max-
 Besides the contract line this prints, in the same JSON object:
   roofline     - the implicit-GEMM conv kernels measured live with HIP events on the launch stream during one
                  extra (untimed) step: algorithmic FLOP / kernel time against the MFMA peak of the arithmetic
-                 (fp32: 157.3 TFLOP/s; bf16: 2500 TFLOP/s dense);
+                 (exact fp32: 157.3 TFLOP/s; bf16: 2500 TFLOP/s dense; split fp32: six bf16 piece products per fp32 product,
+                 i.e. 2500 / 6 = 416.7 TFLOP/s of algorithmic work);
   cpu_baseline - oracle/ (the CPU restatement of the reference) timed on this box's host cores on a bounded
                  sample (rank 0, N = 1 only);
-  secondary figures, never the headline: elided_dead_work (the step without the reference's unused forwards), bf16 and f32_split
-                 (the fp32 configuration in the bf16 / experimental split-bf16 arithmetic), host_bound_case (64x64, batch 2: the
-                 host's issue cost of a step), host_issue_ms_per_step.
+  secondary figures, never the headline: elided_dead_work (the step without the reference's unused forwards), bf16 and f32_exact
+                 (the fp32 configuration in the bf16 arithmetic / with exact fp32 MFMA contractions), host_bound_case (64x64,
+                 batch 2: the host's issue cost of a step), host_issue_ms_per_step.
 """
 import argparse
 import contextlib
@@ -38,7 +42,8 @@ sys.path.insert(0, ROOT)
 PKG = "semi-supervised-segmentation-cyclegan_amd"
 
 # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 256 CU x 2.4 GHz; dense bf16 MFMA (no sparsity)
-PEAK = {"f32": 157.3, "f32s": 157.3, "bf16": 2500.0, "bf16c": 2500.0}
+PEAK = {"f32": 157.3, "f32x": 157.3, "f32s": 157.3, "bf16": 2500.0, "bf16c": 2500.0}
+SPLIT_PEAK = 2500.0 / 6.0       # algorithmic TFLOP/s ceiling of the split contraction: six bf16 MFMA products per fp32 product
 # conv FLOP of one as-written step per labeled/unlabeled pair (BASELINE.md section 2 / SURVEY 8(d), forward hooks on every conv)
 CONFIGS = {
     2: dict(dataset="voc2012", C=21, H=256, W=256, B=8, dtype="f32", tflop_per_pair=1.983,
@@ -52,9 +57,10 @@ CONFIGS = {
     5: dict(dataset="cityscapes", C=20, H=512, W=1024, B=4, dtype="bf16", tflop_per_pair=15.387,
             label="Cityscapes 20-class 512x1024 semisupervised_cycleGAN as-written G+D step"),
 }
-DTYPE_TEXT = {"f32": "fp32", "bf16": "bf16 (bf16 activations + conv weight operands in HBM, fp32 accumulate / master weights / norm statistics / losses)",
+DTYPE_TEXT = {"f32": "fp32", "f32x": "fp32 tensors, exact fp32 MFMA contractions (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 (bf16 activations + conv weight operands in HBM, fp32 accumulate / master weights / norm statistics / losses)",
               "bf16c": "bf16 conv contractions (fp32 tensors)",
-              "f32s": "fp32 tensors, fp32-accurate contractions as six bf16 piece products on the bf16 matrix cores (experimental split mode)"}
+              "f32s": "fp32 tensors, 3-piece split-bf16 contraction, fp32-accurate (six exact bf16 piece products per fp32 product on "
+                      "the bf16 matrix cores, fp32 accumulation; weight gradients, few-channel stems and heads on the exact fp32 MFMA)"}
 
 
 def main():
@@ -68,8 +74,8 @@ def main():
     ap.add_argument("--no-elided", action="store_true")
     ap.add_argument("--no-small", action="store_true", help="skip the 64x64 batch-2 host-bound figure")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
-    ap.add_argument("--dtype", choices=["f32", "f32s", "bf16", "bf16c"], default=None, help="default: the configuration's")
-    ap.add_argument("--no-bf16", action="store_true", help="config 2: skip the secondary bf16 figure")
+    ap.add_argument("--dtype", choices=["f32", "f32x", "f32s", "bf16", "bf16c"], default=None, help="default: the configuration's")
+    ap.add_argument("--no-bf16", action="store_true", help="config 2: skip the secondary bf16 / exact-fp32 figures")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     dtype = a.dtype or cfg["dtype"]
@@ -102,6 +108,7 @@ def main():
     args.overlap_d = os.environ.get("SSCG_OVERLAP_D", "1") == "1"   # the D step overlaps the next step's generator forwards
     torch.manual_seed(0)
     F.set_conv_precision(dtype)
+    arith = F.get_conv_precision()          # "f32" names fp32 TENSORS; this is the contraction it resolves to ("f32" exact / "f32s" split)
     with contextlib.redirect_stdout(io.StringIO()):
         model = md.semisuper_cycleGAN(args, data_parallel=dp)
 
@@ -140,7 +147,8 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         **({"shared_gpu": True} if os.environ.get("SSCG_DP_SHARED_GPU") else {}),
-        "config": {"workload": "%s, batch=%d per GPU, %s" % (cfg["label"], bsz, DTYPE_TEXT[dtype]), "baseline_config": a.config,
+        "config": {"workload": "%s, batch=%d per GPU, %s" % (cfg["label"], bsz, DTYPE_TEXT[arith if dtype == "f32" else dtype]),
+                   "baseline_config": a.config,
                    "global_batch": world * bsz, "image_unit": "one labeled + one unlabeled %dx%d image" % (H, W),
                    "parallelism": "dp%d" % world, "losses_finite": finite},
         "step_conv_tflops": round(world * bsz * cfg["tflop_per_pair"] * a.steps / dt, 2),
@@ -164,20 +172,22 @@ def main():
         F.set_conv_precision("bf16")
         run(a.warmup + a.steps)
         dtb, lb = timed(a.warmup, a.steps)
-        F.set_conv_precision("f32")
+        F.set_conv_precision(dtype)
         out["bf16"] = {"value": round(world * bsz * a.steps / dtb, 4), "unit": "img/s", "ms_per_step": round(1e3 * dtb / a.steps, 3),
                        "losses_finite": all(bool(torch.isfinite(v)) for v in lb.values()),
                        "note": "not the headline (this configuration is fp32): " + DTYPE_TEXT["bf16"]}
 
-    # experimental: the same fp32 step with the contractions of the heavy convs run as split-bf16 products
+    # beside the headline: the same fp32 step with the OTHER contraction of fp32 tensors (exact fp32 MFMA when the headline runs the
+    # split contraction, and the other way round)
     if dtype == "f32" and not a.no_bf16:
-        F.set_conv_precision("f32s")
+        other = "f32x" if arith == "f32s" else "f32s"
+        F.set_conv_precision(other)
         run(a.warmup + a.steps)
         dts, ls = timed(a.warmup, a.steps)
-        F.set_conv_precision("f32")
-        out["f32_split"] = {"value": round(world * bsz * a.steps / dts, 4), "unit": "img/s", "ms_per_step": round(1e3 * dts / a.steps, 3),
-                            "losses_finite": all(bool(torch.isfinite(v)) for v in ls.values()),
-                            "note": "not the headline: " + DTYPE_TEXT["f32s"]}
+        F.set_conv_precision(dtype)
+        out["f32_exact" if other == "f32x" else "f32_split"] = {
+            "value": round(world * bsz * a.steps / dts, 4), "unit": "img/s", "ms_per_step": round(1e3 * dts / a.steps, 3),
+            "losses_finite": all(bool(torch.isfinite(v)) for v in ls.values()), "note": "not the headline: " + DTYPE_TEXT[other]}
 
     # The reference's own default is batch 2 (main.py:14) on small crops: there the step is bound by the host's issue rate, not by
     # the GPU.  One line beside the headline, single rank only (a second, small model: 64x64, batch 2, same dtype).
@@ -215,9 +225,13 @@ def main():
         summ = prof.summary()
         F.SideStream.enabled = True
     if rank == 0 and not a.no_roofline:
-        fam = "bf16" if dtype == "bf16" else "f32"       # kernel family that dominates this configuration
-        kname = ("conv16_kernel (implicit-GEMM conv forward + data-gradient on bf16 LDS tiles, v_mfma_f32_32x32x16_bf16)" if fam == "bf16"
-                 else "conv_kc_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32)")
+        fam = "bf16" if dtype == "bf16" else ("split" if arith == "f32s" else "f32")       # kernel family that dominates this configuration
+        kname = {"bf16": "conv16_kernel (implicit-GEMM conv forward + data-gradient on bf16 LDS tiles, v_mfma_f32_32x32x16_bf16)",
+                 "split": "convs_kernel (implicit-GEMM conv forward + data-gradient, fp32 tensors, 3-piece split-bf16 contraction: six "
+                          "v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32-accurate)",
+                 "f32": "conv_kc_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32)"}[fam]
+        if fam == "split":
+            peak = SPLIT_PEAK
         kc = {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0}
         for kind in ("fwd", "dgrad"):
             s = summ.get((kind, fam))
@@ -234,6 +248,13 @@ def main():
             "conv_ms_per_step": {"%s/%s" % k: round(v["ms"], 2) for k, v in summ.items()},
             "conv_tflops": {"%s/%s" % k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in summ.items() if v["ms"] > 0},
         }
+        if fam == "split":
+            out["roofline"]["peak_note"] = ("algorithmic fp32 FLOP against the dense bf16 MFMA peak (2500 TFLOP/s) / 6 piece products per fp32 "
+                                            "product; executed matrix-core rate = 6 x achieved")
+            out["roofline"]["frac_of_fp32_mfma_peak"] = round(tf / PEAK["f32"], 4)
+            out["roofline"]["executed_bf16_mfma_tflops"] = round(6.0 * tf, 1)
+        # the whole step's conv FLOP (exact + split kernels, weight gradients included) against the fp32 MFMA peak stays in
+        # step_frac_of_mfma_peak above: that is the figure north_star's "fraction of the conv roofline" asks for
         out["roofline"].update(pmc_traffic(fam))
         # the 3x3 family north_star singles out (3x3 convs of the dominant family only)
         f3 = m3 = 0.0
@@ -297,8 +318,8 @@ def pmc_traffic(fam):
     in its own passes), so this figure is read from a committed profile - and only when that profile was taken over THIS
     kernel family (its kernel names are checked), with its source named in the line.  Units and the gfx950 correction as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes: counters are KiB; FETCH_SIZE under-reports wide coalesced reads by 2x."""
-    want = "conv16_kernel" if fam == "bf16" else "conv_kc_kernel"
-    for name in ("r02_pmc_per_kernel_%s.json" % fam,):
+    want = {"bf16": "conv16_kernel", "split": "convs_kernel", "f32": "conv_kc_kernel"}[fam]
+    for name in ("r03_pmc_per_kernel_%s.json" % fam, "r02_pmc_per_kernel_%s.json" % fam):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -320,20 +341,27 @@ def pmc_traffic(fam):
     return {"traffic": None, "traffic_source": "no committed PMC profile covers %s" % want}
 
 
-def cpu_sample_text(cfg, torch_version, physical, logical, model):
-    return ("as-written G+D step (incl. model.py:419-420,423), %s %d-class %dx%d, batch 2: 1 warm-up + 3 timed steps, torch %s CPU fp32, "
-            "%d threads = all physical cores (%d logical) of %s"
-            % (cfg["dataset"], cfg["C"], cfg["H"], cfg["W"], torch_version, physical, logical, model))
+def cpu_sample_text(cfg, torch_version, threads, probes, physical, logical, model):
+    return ("as-written G+D step (incl. model.py:419-420,423), %s %d-class %dx%d, batch 2, torch %s CPU fp32 on %s (%d physical / %d logical "
+            "cores): one step at each of %s threads, then 2 timed steps at the fastest setting (%d threads); OMP_PROC_BIND / NUMA policy "
+            "left at the box's defaults" % (cfg["dataset"], cfg["C"], cfg["H"], cfg["W"], torch_version, model, physical, logical,
+                                             "/".join(str(t) for t in probes), threads))
 
 
-def cpu_baseline(cfg):
+def cpu_thread_candidates(physical):
+    """Thread counts to probe: 32, 64 and all physical cores (oneDNN on 33x33 maps over-subscribes long before 128 threads:
+    BENCH_r02 measured 52 s/step on 128 threads against 10.5 s on 64)."""
+    c = [t for t in (32, 64) if t < physical]
+    return c + [physical]
+
+
+def cpu_baseline(cfg, step_fn=None, now=time.perf_counter):
     """oracle/ = CPU restatement of the reference step (validated bit-exact against the reference's losses by
     tests/golden/gen_golden.py), timed on this box's host cores: the as-written step at the configuration's geometry with
-    batch 2, 1 warm-up + 3 timed steps on all physical cores."""
-    import numpy as np
+    batch 2.  One step at each candidate thread count (the first doubles as the warm-up; a count is skipped once doubling the
+    threads stopped paying: < 20 % gain), then 2 timed steps at the fastest setting.  `step_fn(threads)` runs one
+    step (tests inject a stub)."""
     import torch
-    from oracle import fixtures as FX
-    from oracle import step as ostep
     logical = os.cpu_count() or 1
     try:
         import psutil
@@ -348,28 +376,43 @@ def cpu_baseline(cfg):
                 break
     except OSError:
         pass
-    torch.set_num_threads(physical)
     C, H, W = cfg["C"], cfg["H"], cfg["W"]
     bs = 2
-    sds = FX.semisup_state_dicts(C, torch.float32, "bench")
-    o = ostep.SemiSupOracle(C, sds, crop=(H, W), as_written=True)
-    np.random.seed(0)
-    times = []
-    for s in range(4):
-        l_img, l_gt, unl_img = FX.step_batch("bench", s, C, H, W, bs)
-        t0 = time.perf_counter()
-        o.step(l_img, l_gt, unl_img)
-        times.append(time.perf_counter() - t0)
-    dt = sum(times[1:]) / 3.0
+    state = {"i": 0}
+    if step_fn is None:
+        import numpy as np
+        from oracle import fixtures as FX
+        from oracle import step as ostep
+        o = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float32, "bench"), crop=(H, W), as_written=True)
+        np.random.seed(0)
+
+        def step_fn(threads, as_written=True):
+            torch.set_num_threads(threads)
+            o.as_written = as_written
+            l_img, l_gt, unl_img = FX.step_batch("bench", state["i"], C, H, W, bs)
+            state["i"] += 1
+            o.step(l_img, l_gt, unl_img)
+
+    def timed_step(threads, **kw):
+        t0 = now()
+        step_fn(threads, **kw)
+        return now() - t0
+
+    probes, probe_s = [], []
+    for t in cpu_thread_candidates(physical):
+        if len(probe_s) >= 2 and probe_s[-1] > 0.8 * probe_s[-2]:
+            break                   # the last doubling of the thread count did not pay: more threads only over-subscribe
+        probes.append(t)
+        probe_s.append(timed_step(t))
+    best = probes[min(range(len(probes)), key=lambda i: probe_s[i])]
+    times = [timed_step(best) for _ in range(2)]
+    dt = sum(times) / len(times)
     # the same step without the reference's unused forwards (model.py:419-420,423), one timed step, for the side-by-side
-    o.as_written = False
-    l_img, l_gt, unl_img = FX.step_batch("bench", 4, C, H, W, bs)
-    t0 = time.perf_counter()
-    o.step(l_img, l_gt, unl_img)
-    dte = time.perf_counter() - t0
-    return {"value": round(bs / dt, 4), "unit": "img/s", "cores": physical, "kind": "port",
-            "sample": cpu_sample_text(cfg, torch.__version__, physical, logical, model),
-            "seconds_per_step": round(dt, 2), "warmup_seconds": round(times[0], 2), "cpu_model": model,
+    dte = timed_step(best, as_written=False)
+    return {"value": round(bs / dt, 4), "unit": "img/s", "cores": best, "kind": "port",
+            "sample": cpu_sample_text(cfg, torch.__version__, best, probes, physical, logical, model),
+            "seconds_per_step": round(dt, 2), "probe_seconds_per_step": {str(t): round(v, 2) for t, v in zip(probes, probe_s)},
+            "physical_cores": physical, "cpu_model": model,
             "elided_dead_work": {"value": round(bs / dte, 4), "seconds_per_step": round(dte, 2)}}
 
 

@@ -12,8 +12,9 @@
  *     (SSCG_F32, the reference's dtype and BASELINE config 2) or bfloat16 (SSCG_BF16, BASELINE configs 3/5): entry points
  *     that touch them take `void*` plus a dtype code.  Statistics, losses, biases, weight gradients, optimiser state: fp32.
  *   - `stream` is a hipStream_t passed as void*.  Calls are asynchronous and stream ordered, re-entrant,
- *     allocate nothing and keep no mutable state (the two sscg_debug_* tuning hooks excepted: process-wide, test-only,
- *     not thread safe); scratch memory is caller provided (`ws`) and sized by the matching *_workspace() query.
+ *     allocate nothing and keep no mutable state (tile-class / split overrides of tools and tests travel in
+ *     sscg_conv_desc.tuning / wgrad_tuning); scratch memory is caller provided (`ws`) and sized by the matching
+ *     *_workspace() query.
  *   - return value: 0 = ok, <0 = library error (SSCG_ERR_*), >0 = hipError_t.  Never throws/aborts.
  */
 #ifndef SSCG_H
@@ -25,11 +26,13 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 8
+#define SSCG_ABI_VERSION 9
 
 /* element types of activation / weight tensors */
 #define SSCG_F32 0
 #define SSCG_BF16 1
+#define SSCG_BF16X3 2 /* conv WEIGHT operands only: an fp32 weight split into three bfloat16 planes h + m + l (sscg_split3), the operand
+                       * of the fp32-accurate "split" contraction on the bf16 matrix cores */
 
 #define SSCG_ERR_BAD_ARG (-1)
 #define SSCG_ERR_UNSUPPORTED (-2)
@@ -59,9 +62,15 @@ typedef struct sscg_conv_desc {
     int32_t w_dtype;    /* ... of the weight operand handed to forward ([K][R][S][C]) / dgrad ([C][R][S][K]) */
     int32_t y_dtype;    /* ... of the [N][P][Q][K] tensor (forward output, dgrad / wgrad dy) */
     int32_t precision;  /* fp32 tensors only: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = operands rounded to bf16
-                         * (RNE) between LDS and the matrix cores, v_mfma_f32_32x32x16_bf16, fp32 accumulation; 2 = every
-                         * operand split into three bf16 pieces, six exact piece products per pair accumulated in fp32
-                         * (fp32-accurate; the LDS-DMA tile classes, exact fp32 elsewhere) */
+                         * (RNE) between LDS and the matrix cores, v_mfma_f32_32x32x16_bf16, fp32 accumulation.  (The
+                         * fp32-accurate split contraction of forward / data gradient is selected by w_dtype = SSCG_BF16X3.) */
+    int32_t tuning;     /* 0 = the library's own plan.  Tuning / test aid carried by the call (the library keeps no mutable state):
+                         * bits 0..7 = 1 + forced tile class of the forward / data-gradient kernel family that serves the call,
+                         * bits 8..15 = split-K (1 = never, n > 1 = every tile cut in n) */
+    int64_t w_plane;    /* w_dtype == SSCG_BF16X3: elements between two planes of the weight operand; 0 = K*R*S*C (dense) */
+    int32_t wgrad_tuning; /* 0 = the library's cost model.  bits 0..7 = 1 + forced weight-gradient tile class (0 = 128x128,
+                         * 1 = 64x64) with bits 8..23 = pixel splits; bits 24..31 = kernel-variant switches of the bf16
+                         * weight gradient (tools/conv16_bench.py) */
 } sscg_conv_desc;
 /* Supported dtype combinations.  forward: (x, w) both fp32 -> y fp32|bf16 (fp32 MFMA kernel: stems and few-channel
  * inputs); (x, w) both bf16 with C % 64 == 0 -> y fp32|bf16 (bf16 MFMA kernel, bf16 LDS tiles).  dgrad: the same with
@@ -99,19 +108,22 @@ int sscg_conv2d_wgrad(const sscg_conv_desc* d, const void* x, const void* dy, fl
 
 /* [K][RS][C] -> [C][RS][K]; source and destination dtypes may differ (fp32 master weight -> bf16 operand copy) */
 int sscg_weight_krsc_to_crsk(const void* w, int w_dtype, void* wt, int wt_dtype, int K, int RS, int C, void* stream);
+/* The "split" contraction (fp32 accuracy on the bf16 matrix cores): dst = three bfloat16 planes h, m, l (each n elements,
+ * `plane_stride` elements apart) with src[i] = h[i] + m[i] + l[i] to 2^-24 (round to nearest at every step).  A conv weight in
+ * this form is passed with w_dtype = SSCG_BF16X3 (forward: planes of [K][R][S][C]; dgrad: planes of [C][R][S][K], which
+ * sscg_weight_krsc_to_crsk produces directly with wt_dtype = SSCG_BF16X3). */
+int sscg_split3(const float* src, void* dst, int64_t n, int64_t plane_stride, void* stream);
+/* 1 when the split kernels serve this call (kind 0 = forward, 1 = data gradient; dtypes of `d` are ignored: fp32 tensors are
+ * implied), 0 when the caller should use the exact-fp32 path (few-channel stems and heads, ragged channels).  Weight gradients
+ * always run the exact-fp32 kernel: both of their operands would have to be split on the fly, which costs what the faster
+ * matrix-core path saves. */
+int sscg_conv2d_split_applies(const sscg_conv_desc* d, int kind);
 /* dst[i] = (dst_dtype) src[i] */
 int sscg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 
 /* out[c] = beta*out[c] + sum_r x[r][c]  (bias gradient).  ws: sscg_colsum_workspace bytes. */
 size_t sscg_colsum_workspace(int64_t rows, int cols);
 int sscg_colsum(const void* x, int dtype, float* out, int64_t rows, int cols, float beta, void* ws, size_t ws_bytes, void* stream);
-
-/* tuning/test hook: bits 0..7 force the forward/dgrad tile configuration (0xff = keep the heuristic), bits 8..15 the
- * split-K factor (0 = planner, 1 = never split, n > 1 = every tile cut in n); -1 restores the defaults */
-int sscg_debug_set_conv_cfg(int cfg);
-/* tuning hook (tools/wgrad_sweep.py): min_iters < 0 forces tile class `target_wgs` (0 = 128x128, 1 = 64x64) with
- * -min_iters pixel splits; min_iters >= 0 restores the built-in cost model */
-int sscg_debug_set_wgrad_plan(int target_wgs, int min_iters);
 
 /* ------------------------------------------------------------------ normalisation (K3, K4, K7)
  * x is viewed as [G][L][C]: InstanceNorm2d (arch/ops.py:11: affine=False, no running stats) has G = N,
@@ -220,10 +232,11 @@ int sscg_weighted_sum(const float* const* terms, const float* w, int n, float* o
 /* ------------------------------------------------------------------ optimiser (K14)
  * torch.optim.Adam (model.py:286-287; steps :474,:542): eps 1e-8, no weight decay, no amsgrad.
  * One launch over a flat arena; grad is multiplied by grad_scale first (1/world_size under data parallel).
- * `param_bf16` (nullable): a bfloat16 shadow of the parameter arena, rewritten in the same pass - the operand copy the bf16
- * convolutions read (the fp32 arena stays the master copy). */
-int sscg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, int64_t n, double lr,
-                   double beta1, double beta2, double eps, int step, float grad_scale, void* stream);
+ * `shadow` (nullable): an operand copy of the parameter arena rewritten in the same pass - the copy the convolutions read (the
+ * fp32 arena stays the master copy): shadow_dtype SSCG_BF16 = a bfloat16 arena of n elements; SSCG_BF16X3 = the three planes
+ * of the split contraction (sscg_split3), n elements apart. */
+int sscg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow, int shadow_dtype, int64_t n,
+                   double lr, double beta1, double beta2, double eps, int step, float grad_scale, void* stream);
 int sscg_fill(float* x, int64_t n, float v, void* stream);
 
 #ifdef __cplusplus

@@ -40,9 +40,11 @@ def get_args(argv=None):
     parser.add_argument("--as_written", type=int, default=1, help="1: also run the forwards whose outputs the reference never uses")
     parser.add_argument("--data", type=str, choices=["auto", "real", "synthetic"], default="auto",
                         help="real: the datasets under ./data (reference layout); synthetic: seeded random batches; auto: real if present")
-    parser.add_argument("--dtype", type=str, choices=["f32", "f32s", "bf16", "bf16c"], default="f32",
-                        help="f32: the reference's arithmetic (exact fp32 MFMA); bf16: bf16 activations / weight operands in HBM, "
-                             "fp32 master weights, statistics and losses (BASELINE configs 3/5); bf16c: fp32 tensors, bf16 contractions")
+    parser.add_argument("--dtype", type=str, choices=["f32", "f32x", "f32s", "bf16", "bf16c"], default="f32",
+                        help="f32: the reference's dtype - fp32 tensors; heavy convolutions contract with the fp32-accurate 3-piece "
+                             "split-bf16 scheme on the bf16 matrix cores (= f32s), everything else with the exact fp32 MFMA; f32x: exact "
+                             "fp32 MFMA everywhere; bf16: bf16 activations / weight operands in HBM, fp32 master weights, statistics and "
+                             "losses (BASELINE configs 3/5); bf16c: fp32 tensors, bf16 contractions")
     parser.add_argument("--honour_nets", type=int, default=0,
                         help="1: build the generators / discriminators --gen_net / --dis_net name (the reference ignores both flags)")
     parser.add_argument("--variants", type=str, default="",

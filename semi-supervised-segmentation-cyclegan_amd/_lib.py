@@ -9,9 +9,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
-F32, BF16 = 0, 1     # SSCG_F32 / SSCG_BF16
+F32, BF16, BF16X3 = 0, 1, 2     # SSCG_F32 / SSCG_BF16 / SSCG_BF16X3 (split weight operand)
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZEROS, PAD_REFLECT = 0, 1
@@ -27,6 +27,7 @@ class ConvDesc(C.Structure):
         ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
         ("pad_mode", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
         ("x_dtype", C.c_int32), ("w_dtype", C.c_int32), ("y_dtype", C.c_int32), ("precision", C.c_int32),
+        ("tuning", C.c_int32), ("w_plane", C.c_int64), ("wgrad_tuning", C.c_int32),
     ]
 
 
@@ -51,11 +52,11 @@ SIGNATURES = {
     "sscg_conv2d_wgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_wgrad": (_i, [_dp, _p, _p, _p, _f, _p, _sz, _p]),
     "sscg_weight_krsc_to_crsk": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "sscg_split3": (_i, [_p, _p, _i64, _i64, _p]),
+    "sscg_conv2d_split_applies": (_i, [_dp, _i]),
     "sscg_cast": (_i, [_p, _i, _p, _i, _i64, _p]),
     "sscg_colsum_workspace": (_sz, [_i64, _i]),
     "sscg_colsum": (_i, [_p, _i, _p, _i64, _i, _f, _p, _sz, _p]),
-    "sscg_debug_set_conv_cfg": (_i, [_i]),
-    "sscg_debug_set_wgrad_plan": (_i, [_i, _i]),
     "sscg_norm_stats_workspace": (_sz, [_i, _i64, _i]),
     "sscg_norm_stats": (_i, [_p, _i, _i, _i64, _i, _f, _p, _p, _p, _p, _f, _p, _sz, _p]),
     "sscg_norm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _p]),
@@ -94,12 +95,9 @@ SIGNATURES = {
     "sscg_l1_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
     "sscg_l1_bwd": (_i, [_p, _p, _i64, _p, _f, _p, _p]),
     "sscg_weighted_sum": (_i, [C.POINTER(_p), C.POINTER(_f), _i, _p, _p]),
-    "sscg_adam_step": (_i, [_p, _p, _p, _p, _p, _i64, C.c_double, C.c_double, C.c_double, C.c_double, _i, _f, _p]),
+    "sscg_adam_step": (_i, [_p, _p, _p, _p, _p, _i, _i64, C.c_double, C.c_double, C.c_double, C.c_double, _i, _f, _p]),
     "sscg_fill": (_i, [_p, _i64, _f, _p]),
 }
-
-
-HOOK_GEN = [0]     # bumped by every call of a sscg_debug_* tuning hook
 
 
 class SscgError(RuntimeError):
@@ -119,14 +117,6 @@ def _load():
     v = lib.sscg_abi_version()
     if v != ABI_VERSION:
         raise ImportError("libsscg.so ABI version %d != binding version %d" % (v, ABI_VERSION))
-    # the two tuning hooks change what the planners answer: callers that cache a plan-dependent size key it with HOOK_GEN
-    for name in ("sscg_debug_set_conv_cfg", "sscg_debug_set_wgrad_plan"):
-        raw = getattr(lib, name)
-
-        def hook(*a, _raw=raw):
-            HOOK_GEN[0] += 1
-            return _raw(*a)
-        setattr(lib, name, hook)
     if os.environ.get("SSCG_TRACE"):
         return _Traced(lib)
     return lib

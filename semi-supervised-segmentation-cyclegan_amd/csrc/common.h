@@ -23,6 +23,31 @@ __device__ __forceinline__ sscg_bf3 sscg_split3(float x) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// The same split for eight values at once, in packed form: three bf16x8 MFMA operands from eight fp32 (v_cvt_pk_bf16_f32 rounds a
+// pair to nearest; the fp32 value of a piece is its 16 bits shifted up).  11 VALU operations per pair of elements.
+typedef uint32_t sscg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t sscg_cvt_pk_bf16(float a, float b) {      // low half = bf16(a), high half = bf16(b)
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void sscg_split8(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    sscg_u32x4 ph, pm, pl;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float a = x[2 * w], b = x[2 * w + 1];
+        const uint32_t hh = sscg_cvt_pk_bf16(a, b);
+        const float ra = a - __builtin_bit_cast(float, hh << 16), rb = b - __builtin_bit_cast(float, hh & 0xffff0000u);
+        const uint32_t mm = sscg_cvt_pk_bf16(ra, rb);
+        const float sa = ra - __builtin_bit_cast(float, mm << 16), sb = rb - __builtin_bit_cast(float, mm & 0xffff0000u);
+        ph[w] = hh; pm[w] = mm; pl[w] = sscg_cvt_pk_bf16(sa, sb);
+    }
+    h = __builtin_bit_cast(bf16x8, ph);
+    m = __builtin_bit_cast(bf16x8, pm);
+    l = __builtin_bit_cast(bf16x8, pl);
+}
+
 // ---- element access for tensors that are fp32 or bfloat16 in HBM (arithmetic is always fp32)
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
 template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }

@@ -501,10 +501,6 @@ __global__ __launch_bounds__(256) void k16_reduce_kernel(const float* __restrict
 }
 
 // ---- host-side plan
-}  // namespace
-extern int sscg_force_conv_cfg;      // conv_igemm.hip: sscg_debug_set_conv_cfg(100 + cfg) forces a bf16 tile class (tuning hook)
-extern int sscg_tune_flags;          // bit 0: spread the LDS-DMA pieces of the next tile over the four MFMA groups (default: all ahead of group 0)
-namespace {
 // tile classes: block tile, waves, copy stages (k-tiles in LDS).  The deep classes hold 2-3 tiles in flight per workgroup.
 enum { CFG_128x128 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_128x64 = 3, CFG_128x128_W8 = 4, CFG_256x128_W8 = 5, NCFG16 = 6 };
 const int C16_BM[NCFG16] = {128, 64, 128, 128, 128, 256};
@@ -516,8 +512,10 @@ const int C16_WM[NCFG16] = {2, 2, 4, 2, 2, 4};      // wave rows of a tile (= st
 // workgroups = 2 waves per SIMD) reach 600 TF/s on the 34320-row 256-channel 3x3, the same tile as 8 waves of 64x32 (4 per SIMD)
 // 710; three or four k-tiles in flight with ONE workgroup per CU: 470; 256x128 tiles: no gain.  Few output channels: 128x64 /
 // 64x64 tiles of 4 waves.
-int choose16(long M, int Ng, int Ktot) {
-    if (sscg_force_conv_cfg >= 100 && sscg_force_conv_cfg < 100 + NCFG16 && Ng > 32) return sscg_force_conv_cfg - 100;   // tuning hook
+// `tuning` = sscg_conv_desc.tuning: bits 0..7 = 1 + forced tile class
+int choose16(long M, int Ng, int Ktot, int tuning) {
+    const int forced = (tuning & 0xff) - 1;
+    if (forced >= 0 && forced < NCFG16 && Ng > 32) return forced;
     (void)Ktot;
     if (Ng <= 32) return CFG_128x32;
     const long tm = cdiv(M, 128);
@@ -530,23 +528,23 @@ struct K16Split { int splits, ksplit, full_tiles, m_tail0; };
 
 // Which tiles are cut along K (same policy as conv_igemm.hip): few-channel heads on few rows split every tile; 64x64
 // launches split only the tail beyond the last whole round of 256 workgroups.
-K16Split plan16_raw(long M, int Ng, int Ktot);
+K16Split plan16_raw(long M, int Ng, int Ktot, int tuning);
 
 // stat_L > 0: the launch also produces normalisation statistics; the rows of split tiles are summed separately as ONE
 // extra group of records, so they must lie in one normalisation group (else the launch is not split).
-K16Split plan16(long M, int Ng, int Ktot, long stat_L = 0) {
-    K16Split r = plan16_raw(M, Ng, Ktot);
+K16Split plan16(long M, int Ng, int Ktot, int tuning, long stat_L = 0) {
+    K16Split r = plan16_raw(M, Ng, Ktot, tuning);
     if (stat_L > 0 && r.splits > 1 && (r.full_tiles == 0 || r.m_tail0 / stat_L != (M - 1) / stat_L)) {
-        const int cfg = choose16(M, Ng, Ktot);
+        const int cfg = choose16(M, Ng, Ktot, tuning);
         r.splits = 1; r.ksplit = Ktot / BK;
         r.full_tiles = cdiv(M, C16_BM[cfg]) * cdiv(Ng, C16_BN[cfg]); r.m_tail0 = (int)M;
     }
     return r;
 }
 
-K16Split plan16_raw(long M, int Ng, int Ktot) {
+K16Split plan16_raw(long M, int Ng, int Ktot, int tuning) {
     const int nk = Ktot / BK;
-    const int cfg = choose16(M, Ng, Ktot);
+    const int cfg = choose16(M, Ng, Ktot, tuning);
     const int bm = C16_BM[cfg], bn = C16_BN[cfg];
     const int tiles_m = cdiv(M, bm), tiles_n = cdiv(Ng, bn);
     const int tiles = tiles_m * tiles_n;
@@ -620,8 +618,8 @@ int launch16(const K16Params& p0, hipStream_t st) {
 }
 
 template <int MODE>
-int dispatch16(const K16Params& p, hipStream_t st) {
-    switch (choose16(p.M, p.Ng, p.Ktot)) {
+int dispatch16(const K16Params& p, int tuning, hipStream_t st) {
+    switch (choose16(p.M, p.Ng, p.Ktot, tuning)) {
         case CFG_128x128: return launch16<MODE, 2, 2, 2, 2, 2>(p, st);
         case CFG_64x64: return launch16<MODE, 2, 2, 1, 1, 2>(p, st);
         case CFG_128x32: return launch16<MODE, 4, 1, 1, 1, 2>(p, st);
@@ -654,25 +652,25 @@ bool sscg_conv16_dgrad_applies(const sscg_conv_desc* d) {
 // geometry of the statistics records of a forward launch (records = [tiles_m * wm][2 groups][K][2] doubles)
 bool sscg_conv16_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* wm, int* tiles_n, int* splits, int* full_tiles, int* m_tail0) {
     const long M = (long)d->N * d->P * d->Q;
-    const int cfg = choose16(M, d->K, d->R * d->S * d->C);
+    const int cfg = choose16(M, d->K, d->R * d->S * d->C, d->tuning);
     if (cfg == CFG_128x32 || L < C16_BM[cfg]) return false;
     *bm = C16_BM[cfg];
     *wm = C16_WM[cfg];
     *tiles_n = cdiv(d->K, C16_BN[cfg]);
-    K16Split sp = plan16(M, d->K, d->R * d->S * d->C, L);
+    K16Split sp = plan16(M, d->K, d->R * d->S * d->C, d->tuning, L);
     *splits = sp.splits; *full_tiles = sp.full_tiles; *m_tail0 = sp.m_tail0;
     return true;
 }
 
 size_t sscg_conv16_fwd_workspace(const sscg_conv_desc* d, long stat_L) {
     const long M = (long)d->N * d->P * d->Q;
-    return split16_bytes(plan16(M, d->K, d->R * d->S * d->C, stat_L), M, d->K);
+    return split16_bytes(plan16(M, d->K, d->R * d->S * d->C, d->tuning, stat_L), M, d->K);
 }
 
 size_t sscg_conv16_dgrad_workspace(const sscg_conv_desc* d) {
     if (dgrad16_by_parity(d)) return 0;
     const long M = (long)d->N * d->H * d->W;
-    return split16_bytes(plan16(M, d->C, d->R * d->S * d->K), M, d->C);
+    return split16_bytes(plan16(M, d->C, d->R * d->S * d->K, d->tuning), M, d->C);
 }
 
 int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
@@ -686,11 +684,11 @@ int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const
     p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope;
     p.stats = stats; p.stat_L = (int)stat_L; p.xstats = xstats;
     dense_taps(p);
-    K16Split sp = plan16(p.M, p.Ng, p.Ktot, stats ? stat_L : 0);
+    K16Split sp = plan16(p.M, p.Ng, p.Ktot, d->tuning, stats ? stat_L : 0);
     if (sp.splits > 1 && (!ws || ws_bytes < split16_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
-    return dispatch16<MODE_FWD>(p, st);
+    return dispatch16<MODE_FWD>(p, d->tuning, st);
 }
 
 int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
@@ -724,17 +722,17 @@ int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, c
                 q.OH = Ha; q.OW = Wb;
                 q.M = d->N * Ha * Wb;
                 q.Ktot = q.R * q.S * q.Cs;
-                int rc = dispatch16<MODE_DGRAD>(q, st);
+                int rc = dispatch16<MODE_DGRAD>(q, d->tuning, st);
                 if (rc) return rc;
             }
         }
         return SSCG_OK;
     }
-    K16Split sp = plan16(p.M, p.Ng, p.Ktot);
+    K16Split sp = plan16(p.M, p.Ng, p.Ktot, d->tuning);
     if (sp.splits > 1 && (!ws || ws_bytes < split16_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
-    return dispatch16<MODE_DGRAD>(p, st);
+    return dispatch16<MODE_DGRAD>(p, d->tuning, st);
 }
 
 // =====================================================================================================================
@@ -1204,7 +1202,8 @@ Wg16Plan plan_wg16(const sscg_conv_desc* d) {
     pl.cfg = (Kc >= 128 && Ng >= 128 && (long)cdiv(Kc, 128) * cdiv(Ng, 128) >= 8) ? 0 : 1;
     pl.bm = pl.bn = pl.cfg == 0 ? 128 : 64;
     const long tiles = (long)cdiv(Kc, pl.bm) * cdiv(Ng, pl.bn);
-    const long slots = ((sscg_tune_flags >> 4) & 15) ? 128L * ((sscg_tune_flags >> 4) & 15) : (pl.cfg == 0 ? 512 : 1024);   // bits 4..7: tools/conv16_bench.py
+    const int flags = (d->wgrad_tuning >> 24) & 0xff;      // kernel-variant switches (tools/conv16_bench.py): bits 4..7 = workgroup slots / 128
+    const long slots = ((flags >> 4) & 15) ? 128L * ((flags >> 4) & 15) : (pl.cfg == 0 ? 512 : 1024);
     long s = slots / tiles;
     if (s > steps / 4) s = steps / 4;
     if (s > 1024) s = 1024;
@@ -1279,8 +1278,9 @@ int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* 
     p.div_pq = make_fastdiv(d->P * d->Q);
     p.div_q = make_fastdiv(d->Q);
     int rc;
-    const int variant = (sscg_tune_flags >> 1) & 7;      // tools/conv16_bench.py: 0 = default
-    if (sscg_tune_flags & 1) {                           // register-transposing kernel (kept for comparison)
+    const int flags = (d->wgrad_tuning >> 24) & 0xff;
+    const int variant = (flags >> 1) & 7;                // tools/conv16_bench.py: 0 = default
+    if (flags & 1) {                                     // register-transposing kernel (kept for comparison)
         rc = pl.cfg == 0 ? launch_wg16<2, 2, 2, 2>(p, pl.splits, st) : launch_wg16<2, 2, 1, 1>(p, pl.splits, st);
     } else if (pl.cfg == 0) {
         // 128x128 tile as 8 waves of 64x32: 4 waves per SIMD with two workgroups per CU (550 -> 665 TF/s on the 256-ch 3x3)

@@ -48,6 +48,7 @@ struct KcParams {
     void* __restrict__ dst;          // [M][Ng] fp32 or bf16 (out_bf16)
     int out_bf16;
     int precision;                   // host side: 1 = bf16 contraction of the fp32 tiles (sscg_conv_desc.precision)
+    int tuning;                      // host side: sscg_conv_desc.tuning
     int M, Ng, Ktot, Cs;
     int SH, SW;   // source spatial
     int OH, OW;   // destination spatial (row decode)
@@ -419,37 +420,6 @@ __global__ __launch_bounds__(256) void conv_kc_kernel(KcParams p) {
             if (kt + 1 < nk) load_tile();
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {      // two MFMAs of k = 16: lane half h contributes the k-groups (2*g2, 2*g2+1), slot h
-                if constexpr (BF16 == 2) {
-                    // split mode (precision 2): fp32-accurate products on the bf16 matrix cores - 6 MFMAs of 32 cycles instead
-                    // of 8 fp32 MFMAs of 64 per 16 k
-                    bf16x8 a0[TM], a1[TM], a2[TM], b0[TN], b1[TN], b2[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            { const sscg_bf3 t3 = sscg_split3(ga[2 * g2][i][e]); a0[i][e] = t3.h; a1[i][e] = t3.m; a2[i][e] = t3.l; }
-                            { const sscg_bf3 t3 = sscg_split3(ga[2 * g2 + 1][i][e]); a0[i][4 + e] = t3.h; a1[i][4 + e] = t3.m; a2[i][4 + e] = t3.l; }
-                        }
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            { const sscg_bf3 t3 = sscg_split3(gb[2 * g2][j][e]); b0[j][e] = t3.h; b1[j][e] = t3.m; b2[j][e] = t3.l; }
-                            { const sscg_bf3 t3 = sscg_split3(gb[2 * g2 + 1][j][e]); b0[j][4 + e] = t3.h; b1[j][4 + e] = t3.m; b2[j][4 + e] = t3.l; }
-                        }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b0[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b2[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
-                        }
-                    continue;
-                }
                 bf16x8 pa[TM], pb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -635,14 +605,10 @@ __global__ __launch_bounds__(256) void kc_reduce_kernel(const float* __restrict_
 // channel count is a multiple of BK stage through LDS-DMA (cfg 6/7).
 static const int KC_BM[9] = {128, 128, 64, 64, 128, 128, 64, 128, 256};
 static const int KC_BN[9] = {128, 64, 128, 64, 32, 128, 64, 128, 32};
-}  // namespace
-int sscg_force_conv_cfg = -1;    // test/tuning hooks (sscg_debug_set_conv_cfg); also read by conv_bf16.hip (values >= 100)
-int sscg_tune_flags = 0;         // bits 16..23 of sscg_debug_set_conv_cfg: kernel-variant switches for tools/conv16_bench.py
-namespace {
-int sscg_force_conv_split = 0;
-
-static int kc_choose_cfg(int M, int Ng, int Ktot, int Cs) {
-    if (sscg_force_conv_cfg >= 0 && sscg_force_conv_cfg < 100) return sscg_force_conv_cfg;
+// `tuning` = sscg_conv_desc.tuning (include/sscg.h): bits 0..7 = 1 + forced tile class, bits 8..15 = forced split-K
+static int kc_choose_cfg(int M, int Ng, int Ktot, int Cs, int tuning) {
+    const int forced = (tuning & 0xff) - 1;
+    if (forced >= 0 && forced <= 8) return forced;
     const bool fast = Cs % BK == 0;
     if (Ng <= 4 && fast) return 8;
     if (Ng <= 32) return 4;
@@ -658,30 +624,31 @@ struct KcSplit { int splits, ksplit, full_tiles, m_tail0; };
 //  * 64x64-tile launches: only the TAIL - the tiles beyond the last whole round of 256 workgroups.  The DeepLab
 //    stride-8 maps give 8712 rows -> 548 tiles: 512 whole tiles (2 per CU) + 36 tail tiles cut in 7, so every CU gets
 //    2 1/7 tiles of work instead of 2 or 3 (71 % balance), and only 6.5 % of the output goes through partial sums.
-static KcSplit plan_kc_split_raw(int M, int Ng, int Ktot, int Cs);
+static KcSplit plan_kc_split_raw(int M, int Ng, int Ktot, int Cs, int tuning);
 
 // stat_L > 0: the launch also produces normalisation statistics.  Split tiles write partial sums, not results, so their
 // rows are summed separately (one extra group of records): they must all lie in ONE normalisation group.
-static KcSplit plan_kc_split(int M, int Ng, int Ktot, int Cs, long stat_L = 0) {
-    KcSplit r = plan_kc_split_raw(M, Ng, Ktot, Cs);
+static KcSplit plan_kc_split(int M, int Ng, int Ktot, int Cs, int tuning, long stat_L = 0) {
+    KcSplit r = plan_kc_split_raw(M, Ng, Ktot, Cs, tuning);
     if (stat_L > 0 && r.splits > 1 && (r.full_tiles == 0 || r.m_tail0 / stat_L != (M - 1) / stat_L)) {
-        const int cfg = kc_choose_cfg(M, Ng, Ktot, Cs);
+        const int cfg = kc_choose_cfg(M, Ng, Ktot, Cs, tuning);
         r.splits = 1; r.ksplit = (Ktot + BK - 1) / BK;
         r.full_tiles = cdiv(M, KC_BM[cfg]) * cdiv(Ng, KC_BN[cfg]); r.m_tail0 = M;
     }
     return r;
 }
 
-static KcSplit plan_kc_split_raw(int M, int Ng, int Ktot, int Cs) {
+static KcSplit plan_kc_split_raw(int M, int Ng, int Ktot, int Cs, int tuning) {
     const int nk = (Ktot + BK - 1) / BK;
-    const int cfg = kc_choose_cfg(M, Ng, Ktot, Cs);
+    const int cfg = kc_choose_cfg(M, Ng, Ktot, Cs, tuning);
+    const int force_split = (tuning >> 8) & 0xff;
     const int bm = KC_BM[cfg], bn = KC_BN[cfg];
     const int tiles_m = cdiv(M, bm), tiles_n = cdiv(Ng, bn);
     const int tiles = tiles_m * tiles_n;
     KcSplit r = {1, nk, tiles, M};
-    if (sscg_force_conv_split == 1) return r;   // tuning hook: never split
-    if (sscg_force_conv_split > 1) {            // tuning hook: split every tile
-        r.ksplit = cdiv(nk, sscg_force_conv_split);
+    if (force_split == 1) return r;   // tuning: never split
+    if (force_split > 1) {            // tuning: split every tile
+        r.ksplit = cdiv(nk, force_split);
         r.splits = cdiv(nk, r.ksplit);
         r.full_tiles = 0; r.m_tail0 = 0;
         return r;
@@ -754,7 +721,7 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
 
 template <int MODE, int VEC, bool FAST>
 int dispatch_kc(const KcParams& p, hipStream_t st) {
-    switch (kc_choose_cfg(p.M, p.Ng, p.Ktot, p.Cs)) {
+    switch (kc_choose_cfg(p.M, p.Ng, p.Ktot, p.Cs, p.tuning)) {
         case 0: if (p.precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, false, true>(p, st);
                 return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST>(p, st);
         case 1: if (p.precision == 1) return launch_kc<MODE, 2, 2, 2, 1, VEC, FAST, 2, false, true>(p, st);
@@ -766,9 +733,8 @@ int dispatch_kc(const KcParams& p, hipStream_t st) {
         case 4: if (p.precision == 1) return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST, 2, false, true>(p, st);
                 return launch_kc<MODE, 4, 1, 1, 1, VEC, FAST>(p, st);
         case 5: return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 1>(p, st);   // 128x128, single LDS image (experimental)
-        // (precision 2, the split mode, exists on the two LDS-DMA tile classes only - every heavy conv; elsewhere it means exact fp32)
-        case 6: if constexpr (FAST) { if (p.precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, 1>(p, st); if (p.precision == 2) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, 2>(p, st); return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
-        case 7: if constexpr (FAST) { if (p.precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, 1>(p, st); if (p.precision == 2) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, 2>(p, st); return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
+        case 6: if constexpr (FAST) { if (p.precision == 1) return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true, 1>(p, st); return launch_kc<MODE, 2, 2, 1, 1, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 64x64, LDS-DMA staging
+        case 7: if constexpr (FAST) { if (p.precision == 1) return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true, 1>(p, st); return launch_kc<MODE, 2, 2, 2, 2, VEC, FAST, 2, true>(p, st); } else return SSCG_ERR_UNSUPPORTED;   // 128x128, LDS-DMA staging
         case 8: if constexpr (FAST) return launch_kc<MODE, 4, 1, 2, 1, VEC, FAST, 2, true, false, true>(p, st); else return SSCG_ERR_UNSUPPORTED;   // 256 x (<= 4): 4x4x1 MFMA
         default: return SSCG_ERR_BAD_ARG;
     }
@@ -783,14 +749,6 @@ int dispatch_mode(const KcParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int sscg_debug_set_conv_cfg(int cfg) {
-    if (cfg < 0) { sscg_force_conv_cfg = -1; sscg_force_conv_split = 0; sscg_tune_flags = 0; return SSCG_OK; }
-    sscg_force_conv_cfg = (cfg & 0xff) == 0xff ? -1 : (cfg & 0xff);
-    sscg_force_conv_split = (cfg >> 8) & 0xff;
-    sscg_tune_flags = (cfg >> 16) & 0xff;
-    return SSCG_OK;
-}
-
 // launch walks every tap of a dense [R][S] weight and writes rows in order
 static void kc_dense_taps(KcParams& p) {
     p.pad_x = p.pad; p.wKtot = p.Ktot;
@@ -800,16 +758,17 @@ static void kc_dense_taps(KcParams& p) {
 
 // stride-2 data gradients are decomposed into parity classes when the vectorised tap walk applies (K % BK == 0)
 static bool dgrad_by_parity(const sscg_conv_desc* d) {
-    return (sscg_force_conv_cfg < 0 || sscg_force_conv_cfg >= 100) && d->stride == 2 && d->dil == 1 && d->pad_mode == 0 && d->K % BK == 0;
+    return (d->tuning & 0xff) == 0 && d->stride == 2 && d->dil == 1 && d->pad_mode == 0 && d->K % BK == 0;
 }
 
 static bool dt_ok(int dt) { return dt == SSCG_F32 || dt == SSCG_BF16; }
+static bool wdt_ok(int dt) { return dt_ok(dt) || dt == SSCG_BF16X3; }
 
 static int check_desc(const sscg_conv_desc* d) {
     if (!d) return SSCG_ERR_BAD_ARG;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0) return SSCG_ERR_BAD_ARG;
     if (d->stride <= 0 || d->dil <= 0 || d->pad < 0) return SSCG_ERR_BAD_ARG;
-    if (!dt_ok(d->x_dtype) || !dt_ok(d->w_dtype) || !dt_ok(d->y_dtype) || (d->precision < 0 || d->precision > 2)) return SSCG_ERR_BAD_ARG;
+    if (!dt_ok(d->x_dtype) || !wdt_ok(d->w_dtype) || !dt_ok(d->y_dtype) || (d->precision < 0 || d->precision > 1)) return SSCG_ERR_BAD_ARG;
     int P = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
     int Q = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
     if (P != d->P || Q != d->Q) return SSCG_ERR_BAD_ARG;
@@ -824,14 +783,16 @@ static int check_desc(const sscg_conv_desc* d) {
 extern "C" size_t sscg_conv2d_fwd_workspace(const sscg_conv_desc* d) {
     if (!d) return 0;
     if (sscg_conv16_fwd_applies(d)) return sscg_conv16_fwd_workspace(d, 0);
-    return kc_split_bytes(plan_kc_split(d->N * d->P * d->Q, d->K, d->R * d->S * d->C, d->C), d->N * d->P * d->Q, d->K);
+    if (sscg_convs_fwd_applies(d)) return sscg_convs_fwd_workspace(d, 0);
+    return kc_split_bytes(plan_kc_split(d->N * d->P * d->Q, d->K, d->R * d->S * d->C, d->C, d->tuning), d->N * d->P * d->Q, d->K);
 }
 
 extern "C" size_t sscg_conv2d_dgrad_workspace(const sscg_conv_desc* d) {
     if (!d) return 0;
     if (sscg_conv16_dgrad_applies(d)) return sscg_conv16_dgrad_workspace(d);
+    if (sscg_convs_dgrad_applies(d)) return sscg_convs_dgrad_workspace(d);
     if (dgrad_by_parity(d)) return 0;
-    return kc_split_bytes(plan_kc_split(d->N * d->H * d->W, d->C, d->R * d->S * d->K, d->K), d->N * d->H * d->W, d->C);
+    return kc_split_bytes(plan_kc_split(d->N * d->H * d->W, d->C, d->R * d->S * d->K, d->K, d->tuning), d->N * d->H * d->W, d->C);
 }
 
 // ---- fused normalisation statistics: layout of the `stats` buffer = [tiles_m * WM records][2][K][2] doubles, then the
@@ -842,21 +803,25 @@ static bool fwd_stats_plan(const sscg_conv_desc* d, int G, long L, StatPlan* sp)
     const long M = (long)d->N * d->P * d->Q;
     if (G <= 0 || L <= 0 || (long)G * L != M || d->act != SSCG_ACT_NONE || d->K <= 32) return false;   // (thin 1x1 shapes keep the matrix-core path when statistics are asked for)
     int splits;
-    if (sscg_conv16_fwd_applies(d)) {
+    if (sscg_conv16_fwd_applies(d) || sscg_convs_fwd_applies(d)) {
         int full_tiles, m_tail0, tiles_n;
-        if (!sscg_conv16_stats_geometry(d, L, &sp->bm, &sp->wm, &tiles_n, &splits, &full_tiles, &m_tail0)) return false;
+        if (sscg_conv16_fwd_applies(d)) {
+            if (!sscg_conv16_stats_geometry(d, L, &sp->bm, &sp->wm, &tiles_n, &splits, &full_tiles, &m_tail0)) return false;
+        } else if (!sscg_convs_stats_geometry(d, L, &sp->bm, &sp->wm, &tiles_n, &splits, &full_tiles, &m_tail0)) {
+            return false;
+        }
         sp->tiles_m = cdiv(M, sp->bm);
         sp->valid_tiles = splits > 1 ? full_tiles / tiles_n : sp->tiles_m;
         sp->m_tail0 = splits > 1 ? m_tail0 : M;
     } else {
         if (d->x_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return false;
         const int Ktot = d->R * d->S * d->C;
-        const int cfg = kc_choose_cfg((int)M, d->K, Ktot, d->C);
+        const int cfg = kc_choose_cfg((int)M, d->K, Ktot, d->C, d->tuning);
         if (cfg == 8) return false;
         sp->bm = KC_BM[cfg];
         sp->wm = (cfg == 4) ? 4 : 2;
         if (L < sp->bm) return false;
-        KcSplit ks = plan_kc_split((int)M, d->K, Ktot, d->C, L);
+        KcSplit ks = plan_kc_split((int)M, d->K, Ktot, d->C, d->tuning, L);
         sp->tiles_m = cdiv(M, sp->bm);
         const int tiles_n = cdiv(d->K, KC_BN[cfg]);
         splits = ks.splits;
@@ -889,17 +854,18 @@ static int conv_fwd_impl(const sscg_conv_desc* d, const void* x, const void* w, 
     if (!x || !w || !y) return SSCG_ERR_BAD_ARG;
     if (!stats && sscg_thin1x1_fwd_applies(d)) return sscg_thin1x1_fwd(d, x, w, bias, y, (hipStream_t)stream);
     if (sscg_conv16_fwd_applies(d)) return sscg_conv16_fwd(d, x, w, bias, y, stats, stat_L, xstats, ws, ws_bytes, (hipStream_t)stream);
+    if (sscg_convs_fwd_applies(d)) return sscg_convs_fwd(d, x, w, bias, y, stats, stat_L, xstats, ws, ws_bytes, (hipStream_t)stream);
     if (d->x_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return SSCG_ERR_UNSUPPORTED;
     KcParams p = {};
     p.src = reinterpret_cast<const float*>(x); p.wgt = reinterpret_cast<const float*>(w); p.bias = bias; p.dst = y;
-    p.out_bf16 = d->y_dtype == SSCG_BF16; p.precision = d->precision;
+    p.out_bf16 = d->y_dtype == SSCG_BF16; p.precision = d->precision; p.tuning = d->tuning;
     p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Cs = d->C; p.Ktot = d->R * d->S * d->C;
     p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope; p.tiles_n = 0; p.tiles = 0;
     p.stats = stats; p.stat_L = (int)stat_L; p.xstats = xstats;
     kc_dense_taps(p);
-    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs, stats ? stat_L : 0);
+    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs, p.tuning, stats ? stat_L : 0);
     if (sp.splits > 1 && (!ws || ws_bytes < kc_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
@@ -949,10 +915,11 @@ extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const void* dy, const 
     if (d->pad_mode != 0) return SSCG_ERR_UNSUPPORTED;
     if (sscg_thin1x1_dgrad_applies(d, bias, act)) return sscg_thin1x1_dgrad(d, dy, wt, dx, (hipStream_t)stream);
     if (sscg_conv16_dgrad_applies(d)) return sscg_conv16_dgrad(d, dy, wt, bias, dx, act, slope, ws, ws_bytes, (hipStream_t)stream);
+    if (sscg_convs_dgrad_applies(d)) return sscg_convs_dgrad(d, dy, wt, bias, dx, act, slope, ws, ws_bytes, (hipStream_t)stream);
     if (d->y_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return SSCG_ERR_UNSUPPORTED;
     KcParams p = {};
     p.src = reinterpret_cast<const float*>(dy); p.wgt = reinterpret_cast<const float*>(wt); p.bias = bias; p.dst = dx;
-    p.out_bf16 = d->x_dtype == SSCG_BF16; p.precision = d->precision;
+    p.out_bf16 = d->x_dtype == SSCG_BF16; p.precision = d->precision; p.tuning = d->tuning;
     p.M = d->N * d->H * d->W; p.Ng = d->C; p.Cs = d->K; p.Ktot = d->R * d->S * d->K;
     p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
@@ -987,7 +954,7 @@ extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const void* dy, const 
         }
         return SSCG_OK;
     }
-    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs);
+    KcSplit sp = plan_kc_split(p.M, p.Ng, p.Ktot, p.Cs, p.tuning);
     if (sp.splits > 1 && (!ws || ws_bytes < kc_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
@@ -1013,7 +980,11 @@ __global__ void krsc_to_crsk_kernel(const S* __restrict__ w, D* __restrict__ wt,
 }
 
 extern "C" int sscg_weight_krsc_to_crsk(const void* w, int w_dtype, void* wt, int wt_dtype, int K, int RS, int C, void* stream) {
-    if (!w || !wt || K <= 0 || RS <= 0 || C <= 0 || !dt_ok(w_dtype) || !dt_ok(wt_dtype)) return SSCG_ERR_BAD_ARG;
+    if (!w || !wt || K <= 0 || RS <= 0 || C <= 0 || !dt_ok(w_dtype) || !wdt_ok(wt_dtype)) return SSCG_ERR_BAD_ARG;
+    if (wt_dtype == SSCG_BF16X3) {      // three dense planes of [C][RS][K] bf16
+        if (w_dtype != SSCG_F32) return SSCG_ERR_UNSUPPORTED;
+        return sscg_krsc_to_crsk_split(reinterpret_cast<const float*>(w), wt, K, RS, C, (hipStream_t)stream);
+    }
     dim3 grid(cdiv(C, 32), cdiv(K, 32), RS);
     hipStream_t st = (hipStream_t)stream;
     if (w_dtype == SSCG_F32 && wt_dtype == SSCG_F32)

@@ -1,0 +1,751 @@
+// fp32 convolutions on the BF16 matrix cores with fp32 accuracy ("split" contraction; sscg_conv_desc.w_dtype == SSCG_BF16X3).
+//
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate.  Here every fp32 operand is written as three bfloat16
+// pieces x = h + m + l (round-to-nearest each time; the residuals x - h and x - h - m are exact in fp32, so the sum is x to
+// 2^-24) and a product a * b is the six piece products a0 b0 + a0 b1 + a1 b0 + a0 b2 + a1 b1 + a2 b0, each EXACT (8-bit x 8-bit
+// mantissas) and accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (smallest terms first); the three terms left out are below
+// 2^-23 |a b|.  Six MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 16 k: 2.67x fewer matrix-core cycles, at or
+// below the rounding error of the exact-fp32 kernel (conv_igemm.hip) against fp64 (tests/test_kernels_gpu.py).
+//
+// Same products as conv_igemm.hip (reference call sites: arch/ops.py:43,49,55-56,68; arch/generators.py:325-336,373,388,415;
+// arch/discriminators.py:45,58,70-75 and their autograd, model.py:472,539):
+//   forward / data gradient / ConvTranspose forward : D[m][n] = sum_k A[m][k] * B[n][k]
+// Operands:
+//   A = the activation (fp32 NHWC in HBM, gathered on the fly exactly like conv_igemm.hip's fast path): it goes to LDS as it
+//       is, by LDS-DMA (128-byte rows of 32 k), and is split in registers between LDS and the matrix cores;
+//   B = the weight, split ONCE per optimiser step (sscg_split3 / the Adam kernel's shadow / the transposing copy): three bf16
+//       planes in HBM, three 64-byte rows per output channel and k-tile in LDS - a lane's ds_read_b128 is a complete MFMA operand.
+// A wave owns the 32 x (TN * 32) or (TM * 32) x (TN * 32) corner of the block tile; each A fragment is split by the waves of
+// one tile row only (WN waves), ~5.5 VALU operations per element, hidden under the 6 * TN MFMAs it feeds.
+//
+// The k-loop is software-pipelined across k-tiles with ONE barrier per tile: while the MFMAs of half-tile (t, 0) run, the
+// fragments of (t, 1) are read and split; then tile t+1 must have landed (vmcnt + barrier), the copy of tile t+2 is requested
+// into the stage just drained, and the fragments of (t+1, 0) are read and split under the MFMAs of (t, 1).  LDS accesses and
+// waits inside the loop are hand-placed (the compiler would order every visible LDS read behind the copies' vmcnt(0)).
+#include "common.h"
+#include "sscg_internal.h"
+#include "reduce_common.h"
+
+namespace {
+
+#ifndef KS_ABLATE
+#define KS_ABLATE 0        // tools/: timing ablations of the k-loop (1 = no copies after the prologue, 2 = no operand split, 4 = no barrier / copy wait); WRONG results
+#endif
+constexpr int BKS = 32;                    // k per tile
+typedef __bf16 bf16;
+typedef uint32_t u32;
+
+// Zeros: the source of masked LDS-DMA lanes (padding taps, rows past M).  A masked row's pointer is chosen once per tap and then
+// advanced by the channel-chunk offset like any other (one 64-bit add per copy piece, no per-tile select): the page covers the
+// largest channel offset of a row (Cs <= 4096 fp32 = 16 KB).
+constexpr int KS_ZERO_FLOATS = 4096 + 64;
+__device__ float sscg_zero_page_s[KS_ZERO_FLOATS];
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+// eight fp32 (two LDS fragments) -> three bf16x8 pieces
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& h, bf16x8& m, bf16x8& l) {
+    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    sscg_split8(x, h, m, l);
+}
+
+struct KsParams {
+    const float* __restrict__ src;   // A source (input for fwd, dy for dgrad), fp32 NHWC
+    const bf16* __restrict__ wgt;    // plane 0 of the split weight: [3][Ng][wKtot] bf16, planes `wplane` elements apart
+    long wplane;
+    const float* __restrict__ bias;  // [Ng] or null
+    float* __restrict__ dst;         // [M][Ng] fp32
+    int M, Ng, Ktot, Cs;
+    int SH, SW, OH, OW;
+    int R, S;
+    int stride, pad, dil, pad_x;
+    int wKtot;
+    int wt_ky0, wt_kx0, wt_step, wt_S;
+    int o_step, o_a, o_b, o_W, o_HW;
+    int pad_mode, act;
+    float slope;
+    int tiles_n, tiles;
+    int splits, ksplit, full_tiles, m_tail0;
+    float* __restrict__ part;        // [splits][M - m_tail0][Ng] when splits > 1
+    double* __restrict__ stats;      // fused normalisation statistics: [tiles_m * WM][2][Ng][2] doubles, or null
+    int stat_L;
+    double* __restrict__ xstats;     // host side
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int NSTAGE = 2;
+    constexpr int RPA = NT / 8;               // A rows per loader pass (8 lanes x 16 B per 128-byte row)
+    constexpr int RPB = NT / 4;               // B rows per loader pass (4 lanes x 16 B per 64-byte row)
+    constexpr int PA = BM / RPA;
+    constexpr int HB = BN / RPB;              // passes per weight plane
+    constexpr int PB = 3 * HB;
+    static_assert(BM % RPA == 0 && BN % RPB == 0, "whole loader passes");
+    constexpr int A_STAGE = BM * 128;         // bytes
+    constexpr int B_PLANE = BN * 64;
+    constexpr int B_STAGE = 3 * B_PLANE;
+    constexpr int NPIECE = PA + PB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2] A images, then [2][3] B plane images
+
+    const int tid = threadIdx.x;
+    int split = 0, tile;
+    bool partial = false;
+    if ((int)blockIdx.x < p.full_tiles) {
+        tile = xcd_remap(blockIdx.x, p.full_tiles);
+    } else {
+        const int ntail = p.tiles - p.full_tiles;
+        const int t = xcd_remap(blockIdx.x - p.full_tiles, gridDim.x - p.full_tiles);
+        split = t / ntail;
+        tile = p.full_tiles + (t - split * ntail);
+        partial = p.splits > 1;
+    }
+    const int tile_n = tile % p.tiles_n;
+    const int tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int wave_id = tid >> 6;
+
+    // ---- copy side
+    const int r0 = tid >> 3;                                   // A row inside a pass
+    const int kqa = (tid & 7) ^ ((r0 >> 1) & 7);               // 16-byte k slot this lane fetches (lands at LDS slot tid & 7 of row r0)
+    const int rb0 = tid >> 2;                                  // B row inside a pass
+    const int kqb = (tid & 3) ^ ((rb0 >> 2) & 3);
+
+    const float* arow[PA];
+    int ay0[PA], ax0[PA];
+    bool aok[PA];
+#pragma unroll
+    for (int ps = 0; ps < PA; ++ps) {
+        const int m = m0 + r0 + ps * RPA;
+        aok[ps] = m < p.M;
+        const int mm = aok[ps] ? m : 0;
+        const int img = mm / (p.OH * p.OW);
+        const int rem = mm - img * (p.OH * p.OW);
+        const int oy = rem / p.OW;
+        const int ox = rem - oy * p.OW;
+        arow[ps] = p.src + (size_t)img * p.SH * p.SW * p.Cs;
+        if (MODE == MODE_FWD) {
+            ay0[ps] = oy * p.stride - p.pad;
+            ax0[ps] = ox * p.stride - p.pad_x;
+        } else {
+            ay0[ps] = oy + p.pad;
+            ax0[ps] = ox + p.pad_x;
+        }
+    }
+    // weight rows past Ng are clamped to the last row: their products land in output columns that are never stored
+    const bf16* brow[HB];
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) {
+        const int n = n0 + rb0 + hb * RPB;
+        brow[hb] = p.wgt + (size_t)(n < p.Ng ? n : p.Ng - 1) * p.wKtot + kqb * 8;
+    }
+
+    const bool reflect = p.pad_mode == 1;
+    auto locate = [&](int ps, int tdy, int tdx, int& pix) -> bool {
+        bool ok = aok[ps];
+        int sy, sx;
+        if (MODE == MODE_FWD) {
+            sy = ay0[ps] + tdy;
+            sx = ax0[ps] + tdx;
+            int ry = sy < 0 ? -sy : sy;
+            int rx = sx < 0 ? -sx : sx;
+            ry = ry >= p.SH ? 2 * (p.SH - 1) - ry : ry;
+            rx = rx >= p.SW ? 2 * (p.SW - 1) - rx : rx;
+            sy = reflect ? ry : sy;
+            sx = reflect ? rx : sx;
+        } else {
+            const int ty = ay0[ps] - tdy;
+            const int tx = ax0[ps] - tdx;
+            if (p.stride == 1) {
+                sy = ty; sx = tx;
+            } else if (p.stride == 2) {
+                sy = ty >> 1; sx = tx >> 1;
+                ok = ok && (((ty | tx) & 1) == 0);
+            } else {
+                sy = ty / p.stride; sx = tx / p.stride;
+                ok = ok && (ty >= 0) && (tx >= 0) && (sy * p.stride == ty) && (sx * p.stride == tx);
+            }
+        }
+        ok = ok && ((unsigned)sy < (unsigned)p.SH) && ((unsigned)sx < (unsigned)p.SW);
+        pix = ok ? sy * p.SW + sx : 0;
+        return ok;
+    };
+
+    const int nk_all = p.Ktot / BKS;                         // Cs % 32 == 0: a k-tile never straddles a tap
+    const int kt0 = partial ? split * p.ksplit : 0;
+    const int kt1 = partial ? min(nk_all, kt0 + p.ksplit) : nk_all;
+    const int f_nchunk = p.Cs / BKS;
+    int f_chunk, f_ky, f_kx;
+    {
+        const int tap0 = kt0 / f_nchunk;
+        f_chunk = kt0 - tap0 * f_nchunk;
+        f_ky = tap0 / (p.S > 0 ? p.S : 1);
+        f_kx = tap0 - f_ky * p.S;
+    }
+    int f_k = 0;
+    const float* aptr[PA];
+    int dma_stage = 0;
+    const float* const zero = sscg_zero_page_s;
+
+    auto set_tap = [&]() {
+        const int tdy = f_ky * p.dil, tdx = f_kx * p.dil;
+        f_k = ((p.wt_ky0 + f_ky * p.wt_step) * p.wt_S + p.wt_kx0 + f_kx * p.wt_step) * p.Cs;
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            int pix;
+            const bool ok = locate(ps, tdy, tdx, pix);
+            aptr[ps] = ok ? arow[ps] + (size_t)pix * p.Cs + kqa * 4 : zero + kqa * 4;
+        }
+    };
+    set_tap();
+    f_k += f_chunk * BKS;
+
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds0 = (lds_char*)smem_raw;
+    const int lds_wave = __builtin_amdgcn_readfirstlane(wave_id * 1024);      // this wave's 1 KB of every loader pass
+    auto request_tile = [&]() {
+        if (f_chunk == f_nchunk) {       // wave-uniform: next tap
+            f_chunk = 0;
+            ++f_kx;
+            if (f_kx == p.S) { f_kx = 0; ++f_ky; }
+            if (f_ky >= p.R) { f_ky = 0; f_kx = 0; }      // past the last tap (never requested)
+            set_tap();
+        }
+        if ((KS_ABLATE & 1) && f_k > 2 * BKS) { dma_stage ^= 1; ++f_chunk; f_k += BKS; return; }
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const float* g = aptr[q] + f_chunk * BKS;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lds0 + dma_stage * A_STAGE + lds_wave + q * (RPA * 128)), 16, 0, 0);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                const bf16* g = brow[hb] + (pl * p.wplane + f_k);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + dma_stage * B_STAGE + pl * B_PLANE +
+                                                                                            lds_wave + hb * (RPB * 64)), 16, 0, 0);
+            }
+        }
+        dma_stage ^= 1;
+        ++f_chunk;
+        f_k += BKS;
+    };
+
+    // ---- matrix-core side
+    const int lane = tid & 63;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int wm = wave_id / WN;
+    const int wn = wave_id % WN;
+    const int row_w = wm * TM * 32;
+    const int col_w = wn * TN * 32;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addresses.  MFMA step s (k = 16 s .. 16 s + 15 of the tile): lane half h supplies k = 16 s + 8 h + (0..7):
+    //   A (fp32): 16-byte slots 4 s + 2 h and 4 s + 2 h + 1 of the 128-byte row, stored at slot ^ ((row >> 1) & 7);
+    //   B (bf16): slot 2 s + h of the 64-byte row, stored at slot ^ ((row >> 2) & 3).
+    const int swa = (li >> 1) & 7, swb = (li >> 2) & 3;
+    int aoff[2][2], boff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        aoff[s][0] = (row_w + li) * 128 + (((4 * s + 2 * lh) ^ swa) << 4);
+        aoff[s][1] = (row_w + li) * 128 + (((4 * s + 2 * lh + 1) ^ swa) << 4);
+        boff[s] = NSTAGE * A_STAGE + (col_w + li) * 64 + (((2 * s + lh) ^ swb) << 4);
+    }
+
+    f32x4 ra[TM][2];            // raw fp32 fragments of the half-tile being split
+    bf16x8 pa[2][TM][3];        // split A fragments (two half-tiles in flight)
+    bf16x8 fb[2][TN][3];        // weight pieces
+
+    auto read_frags = [&](int stage, int s, int set) {
+        const lds_char* a = lds0 + stage * A_STAGE;
+        const lds_char* b = lds0 + stage * B_STAGE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra[i][0]) : "v"(a + aoff[s][0]), "n"(i * 32 * 128));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra[i][1]) : "v"(a + aoff[s][1]), "n"(i * 32 * 128));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][j][pl]) : "v"(b + boff[s]), "n"(pl * B_PLANE + j * 32 * 64));
+    };
+    auto landed = [&](int set) {      // after the lgkmcnt wait: order the consumers of this set behind it
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { pin(ra[i][0]); pin(ra[i][1]); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) pin(fb[set][j][pl]);
+    };
+    auto split_set = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (KS_ABLATE & 2) {
+                pa[set][i][0] = __builtin_bit_cast(bf16x8, ra[i][0]); pa[set][i][1] = __builtin_bit_cast(bf16x8, ra[i][1]);
+                pa[set][i][2] = __builtin_bit_cast(bf16x8, ra[i][0] + ra[i][1]);
+                continue;
+            }
+            split8(ra[i][0], ra[i][1], pa[set][i][0], pa[set][i][1], pa[set][i][2]);
+        }
+    };
+    // one piece product over the wave's accumulators (consecutive MFMAs write different accumulators)
+    auto product = [&](int set, int ap, int bp) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][i][ap], fb[set][j][bp], acc[i][j], 0, 0, 0);
+    };
+    constexpr int NM = TM * TN;                 // MFMAs per piece product
+    constexpr int NV = TM * 44;                 // VALU operations of one split_set
+    constexpr int VPM = (NV + 5 * NM - 1) / (5 * NM);
+    // the six piece products of half-tile `set` (smallest terms first); with `prep`, the fragments of the next half-tile - already
+    // requested - are waited for after the first product and split between the MFMAs of the other five
+    auto half_tile = [&](int set, bool prep) {
+        __builtin_amdgcn_sched_barrier(0);
+        product(set, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (prep) {
+            wait_lgkm<0>();
+            landed(set ^ 1);
+            split_set(set ^ 1);
+        }
+        product(set, 1, 1);
+        product(set, 0, 2);
+        product(set, 1, 0);
+        product(set, 0, 1);
+        product(set, 0, 0);
+        if (prep) {
+#pragma unroll
+            for (int n = 0; n < 5 * NM; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);      // VPM VALU
+            }
+            // the pieces are produced HERE, under this half-tile's MFMAs (left alone, the compiler sinks the split to their first use)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) pin(pa[set ^ 1][i][pl]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int nk = kt1 - kt0;
+    if (nk > 0) {
+        request_tile();                       // tile 0 -> stage 0
+        if (nk > 1) {
+            request_tile();                   // tile 1 -> stage 1
+            wait_vm<NPIECE>();
+        } else {
+            wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, 0, 0);
+        wait_lgkm<0>();
+        landed(0);
+        split_set(0);
+        int issued = nk > 1 ? 2 : 1;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int stage = kt & 1;
+            read_frags(stage, 1, 1);
+            half_tile(0, true);
+            // tile kt + 1 (the only copy in flight) has landed for every wave, and every wave has finished reading tile kt
+            if (!(KS_ABLATE & 4)) {
+                wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            if (issued < nk) { request_tile(); ++issued; }        // -> the stage of tile kt
+            read_frags(stage ^ 1, 0, 0);
+            half_tile(1, true);
+        }
+        {
+            const int stage = (nk - 1) & 1;
+            read_frags(stage, 1, 1);
+            half_tile(0, true);
+            half_tile(1, false);
+        }
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // Fused statistics of the normalisation layer that follows (conv_igemm.hip): fp64 column sums of y and y^2 over this tile's
+    // rows, four rows at a time in fp32 where the tile lies inside one group and inside the tensor.
+    const bool want_stats = p.stats != nullptr && !partial;
+    int gb = 0x7fffffff;
+    if (want_stats) gb = (m0 / p.stat_L + 1) * p.stat_L;
+    // Every element goes to fp64 (as in the exact-fp32 kernel): the 4-rows-in-fp32 shortcut of the bf16 path moves a BatchNorm
+    // statistic by 1e-7, which DeepLab's chained losses amplify to the edge of the parity bound.
+    const bool slow_stats = want_stats;
+    const bool fast_stats = false;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + col_w + j * 32 + li;
+        const bool nok = n < p.Ng;
+        const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+        double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+        if (fast_stats) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float pre = acc[i][j][g4 * 4 + t] + bv;
+                        a += pre;
+                        b = fmaf(pre, pre, b);
+                    }
+                    s0 += (double)a; q0 += (double)b;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.M && nok) {
+                    if (partial) {
+                        p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc[i][j][e];
+                    } else {
+                        const float pre = acc[i][j][e] + bv;
+                        if (slow_stats) {
+                            const double d = (double)pre;
+                            if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
+                        }
+                        size_t row = (size_t)m;
+                        if (p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
+                            const int img = m / (p.OH * p.OW);
+                            const int rem = m - img * (p.OH * p.OW);
+                            const int oi = rem / p.OW;
+                            const int oj = rem - oi * p.OW;
+                            row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+                        }
+                        p.dst[row * p.Ng + n] = sscg_act(pre, p.act, p.slope);
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);      // the lane halves hold different rows of a column
+            s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+            if (lh == 0 && nok) {
+                double* rec = p.stats + ((size_t)(tile_m * WM + wm) * 2) * p.Ng * 2;
+                rec[(size_t)n * 2] = s0; rec[(size_t)n * 2 + 1] = q0;
+                rec[((size_t)p.Ng + n) * 2] = s1; rec[((size_t)p.Ng + n) * 2 + 1] = q1;
+            }
+        }
+    }
+}
+
+// y[i] = act(sum_s part[s][i] + bias[i % Ng])   (fixed order => deterministic); 4 floats per thread (Ng % 4 == 0)
+__global__ __launch_bounds__(256) void ks_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
+                                                         size_t n, int Ng, int splits, int act, float slope) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * n + i);
+    const int c = (int)(i % Ng);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = sscg_act(s[e] + (bias ? bias[c + e] : 0.f), act, slope);
+    *reinterpret_cast<f32x4*>(y + i) = o;
+}
+
+// ---- host side: tile classes and the split-K plan of the tail (same policy as conv_igemm.hip)
+enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_NCFG = 5 };
+const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64};
+const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128};
+const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2};        // wave rows of a tile = statistics records per tile row
+
+int ks_choose(long M, int Ng, int Ktot, int tuning) {
+    const int forced = (tuning & 0xff) - 1;
+    if (forced >= 0 && forced < KS_NCFG && Ng >= KS_BN[forced] / 2) return forced;
+    (void)Ktot;
+    if (Ng <= 64) return cdiv(M, 128) >= 384 ? KS_128x64 : KS_64x64;
+    if ((long)cdiv(M, 128) * cdiv(Ng, 128) >= 384) return KS_128x128;
+    return KS_64x64;
+}
+
+struct KsSplit { int splits, ksplit, full_tiles, m_tail0; };
+
+KsSplit ks_plan_raw(long M, int Ng, int Ktot, int tuning) {
+    const int nk = Ktot / BKS;
+    const int cfg = ks_choose(M, Ng, Ktot, tuning);
+    const int bm = KS_BM[cfg], bn = KS_BN[cfg];
+    const int tiles_m = cdiv(M, bm), tiles_n = cdiv(Ng, bn);
+    const int tiles = tiles_m * tiles_n;
+    KsSplit r = {1, nk, tiles, (int)M};
+    const int force = (tuning >> 8) & 0xff;         // 1 = never split, n > 1 = every tile cut in n
+    if (force == 1) return r;
+    if (force > 1) {
+        r.ksplit = cdiv(nk, force);
+        r.splits = cdiv(nk, r.ksplit);
+        r.full_tiles = 0; r.m_tail0 = 0;
+        return r;
+    }
+    if (nk < 8 || tiles > 2300) return r;
+    const int q = tiles / 256;
+    const int full_m = (q * 256) / tiles_n;
+    const int tail = tiles - full_m * tiles_n;
+    if (tail <= 0 || tail > 208) return r;
+    int s = 256 / tail;
+    if (s > 8) s = 8;
+    if (s > nk / 4) s = nk / 4;
+    if (s < 2) return r;
+    r.ksplit = cdiv(nk, s);
+    r.splits = cdiv(nk, r.ksplit);
+    r.full_tiles = full_m * tiles_n;
+    r.m_tail0 = full_m * bm;
+    return r;
+}
+
+// stat_L > 0: the launch also produces normalisation statistics; the rows of split tiles are summed separately as ONE extra group of
+// records, so they must lie in one normalisation group (else the launch is not split).
+KsSplit ks_plan(long M, int Ng, int Ktot, int tuning, long stat_L = 0) {
+    KsSplit r = ks_plan_raw(M, Ng, Ktot, tuning);
+    if (stat_L > 0 && r.splits > 1 && (r.full_tiles == 0 || r.m_tail0 / stat_L != (M - 1) / stat_L)) {
+        const int cfg = ks_choose(M, Ng, Ktot, tuning);
+        r.splits = 1; r.ksplit = Ktot / BKS;
+        r.full_tiles = cdiv(M, KS_BM[cfg]) * cdiv(Ng, KS_BN[cfg]); r.m_tail0 = (int)M;
+    }
+    return r;
+}
+
+size_t ks_split_bytes(const KsSplit& sp, long M, int Ng) {
+    return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+int launch_ks(const KsParams& p0, hipStream_t st) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int NT = WM * WN * 64;
+    KsParams p = p0;
+    p.tiles_n = cdiv(p.Ng, BN);
+    p.tiles = cdiv(p.M, BM) * p.tiles_n;
+    const size_t smem = (size_t)2 * (BM * 128 + 3 * BN * 64);
+    auto kern = convs_kernel<MODE, WM, WN, TM, TN>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
+    const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);
+    SSCG_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        const size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
+        float* yt = p.dst + (size_t)p.m_tail0 * p.Ng;
+        if (p.xstats)
+            return launch_split_reduce_stats(p.part, p.bias, yt, 0, p.M - p.m_tail0, p.Ng, p.splits, p.act, p.slope, p.xstats, st);
+        hipLaunchKernelGGL(ks_reduce_kernel, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st, p.part, p.bias, yt, n, p.Ng, p.splits, p.act,
+                           p.slope);
+        SSCG_LAUNCH_CHECK();
+    }
+    return SSCG_OK;
+}
+
+template <int MODE>
+int dispatch_ks(const KsParams& p, int tuning, hipStream_t st) {
+    switch (ks_choose(p.M, p.Ng, p.Ktot, tuning)) {
+        case KS_128x128: return launch_ks<MODE, 2, 2, 2, 2>(p, st);       // 4 waves of 64x64
+        case KS_128x128_R: return launch_ks<MODE, 4, 1, 1, 4>(p, st);     // 4 waves of 32x128: every A fragment split by one wave only
+        case KS_64x64: return launch_ks<MODE, 2, 2, 1, 1>(p, st);
+        case KS_128x64: return launch_ks<MODE, 4, 1, 1, 2>(p, st);
+        case KS_64x128: return launch_ks<MODE, 2, 2, 1, 2>(p, st);
+        default: return SSCG_ERR_BAD_ARG;
+    }
+}
+
+void ks_dense_taps(KsParams& p) {
+    p.pad_x = p.pad; p.wKtot = p.Ktot;
+    p.wt_ky0 = 0; p.wt_kx0 = 0; p.wt_step = 1; p.wt_S = p.S;
+    p.o_step = 1; p.o_a = 0; p.o_b = 0; p.o_W = 0; p.o_HW = 0;
+}
+
+bool ks_dgrad_by_parity(const sscg_conv_desc* d) { return d->stride == 2 && d->dil == 1 && d->pad_mode == 0; }
+
+long ks_plane(const sscg_conv_desc* d) { return d->w_plane > 0 ? (long)d->w_plane : (long)d->K * d->R * d->S * d->C; }
+
+// ---- fp32 -> three bf16 planes
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t n, size_t plane) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    if (i + 8 <= n) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + i), b = *reinterpret_cast<const f32x4*>(x + i + 4);
+        bf16x8 h, m, l;
+        split8(a, b, h, m, l);
+        *reinterpret_cast<bf16x8*>(y + i) = h;
+        *reinterpret_cast<bf16x8*>(y + plane + i) = m;
+        *reinterpret_cast<bf16x8*>(y + 2 * plane + i) = l;
+    } else {
+        for (size_t e = i; e < n; ++e) {
+            const sscg_bf3 t = sscg_split3(x[e]);
+            y[e] = t.h; y[plane + e] = t.m; y[2 * plane + e] = t.l;
+        }
+    }
+}
+
+// [K][RS][C] fp32 -> three planes of [C][RS][K] bf16 (the data-gradient operand of a split weight)
+__global__ void krsc_to_crsk_split_kernel(const float* __restrict__ w, bf16* __restrict__ wt, int K, int RS, int C, size_t plane) {
+    __shared__ float t[32][33];
+    const int rs = blockIdx.z;
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, c = c0 + tx;
+        t[r][tx] = (k < K && c < C) ? w[((size_t)k * RS + rs) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, k = k0 + tx;
+        if (k < K && c < C) {
+            const sscg_bf3 s = sscg_split3(t[tx][r]);
+            const size_t o = ((size_t)c * RS + rs) * K + k;
+            wt[o] = s.h; wt[plane + o] = s.m; wt[2 * plane + o] = s.l;
+        }
+    }
+}
+
+}  // namespace
+
+// ---- entry points used by conv_igemm.hip's dispatch
+bool sscg_convs_fwd_applies(const sscg_conv_desc* d) {
+    return d->x_dtype == SSCG_F32 && d->w_dtype == SSCG_BF16X3 && d->y_dtype == SSCG_F32 && d->C % BKS == 0 && d->C <= 4096 &&
+           d->K >= 32 && d->K % 4 == 0;
+}
+
+bool sscg_convs_dgrad_applies(const sscg_conv_desc* d) {
+    return d->y_dtype == SSCG_F32 && d->w_dtype == SSCG_BF16X3 && d->x_dtype == SSCG_F32 && d->K % BKS == 0 && d->K <= 4096 && d->C >= 32 && d->C % 4 == 0 &&
+           d->pad_mode == 0;
+}
+
+bool sscg_convs_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* wm, int* tiles_n, int* splits, int* full_tiles, int* m_tail0) {
+    const long M = (long)d->N * d->P * d->Q;
+    const int cfg = ks_choose(M, d->K, d->R * d->S * d->C, d->tuning);
+    if (L < KS_BM[cfg]) return false;
+    *bm = KS_BM[cfg];
+    *wm = KS_WM[cfg];
+    *tiles_n = cdiv(d->K, KS_BN[cfg]);
+    KsSplit sp = ks_plan(M, d->K, d->R * d->S * d->C, d->tuning, L);
+    *splits = sp.splits; *full_tiles = sp.full_tiles; *m_tail0 = sp.m_tail0;
+    return true;
+}
+
+size_t sscg_convs_fwd_workspace(const sscg_conv_desc* d, long stat_L) {
+    const long M = (long)d->N * d->P * d->Q;
+    return ks_split_bytes(ks_plan(M, d->K, d->R * d->S * d->C, d->tuning, stat_L), M, d->K);
+}
+
+size_t sscg_convs_dgrad_workspace(const sscg_conv_desc* d) {
+    if (ks_dgrad_by_parity(d)) return 0;
+    const long M = (long)d->N * d->H * d->W;
+    return ks_split_bytes(ks_plan(M, d->C, d->R * d->S * d->K, d->tuning), M, d->C);
+}
+
+int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
+                   double* xstats, void* ws, size_t ws_bytes, hipStream_t st) {
+    KsParams p = {};
+    p.src = reinterpret_cast<const float*>(x); p.wgt = reinterpret_cast<const bf16*>(w); p.wplane = ks_plane(d);
+    p.bias = bias; p.dst = reinterpret_cast<float*>(y);
+    p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Cs = d->C; p.Ktot = d->R * d->S * d->C;
+    p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope;
+    p.stats = stats; p.stat_L = (int)stat_L; p.xstats = xstats;
+    ks_dense_taps(p);
+    KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, d->tuning, stats ? stat_L : 0);
+    if (sp.splits > 1 && (!ws || ws_bytes < ks_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
+    p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
+    p.part = reinterpret_cast<float*>(ws);
+    return dispatch_ks<MODE_FWD>(p, d->tuning, st);
+}
+
+int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
+                     void* ws, size_t ws_bytes, hipStream_t st) {
+    KsParams p = {};
+    p.src = reinterpret_cast<const float*>(dy); p.wgt = reinterpret_cast<const bf16*>(wt); p.wplane = ks_plane(d);
+    p.bias = bias; p.dst = reinterpret_cast<float*>(dx);
+    p.M = d->N * d->H * d->W; p.Ng = d->C; p.Cs = d->K; p.Ktot = d->R * d->S * d->K;
+    p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.pad_mode = 0; p.act = act; p.slope = slope;
+    ks_dense_taps(p);
+    if (ks_dgrad_by_parity(d)) {
+        // stride 2: four parity classes, each a stride-1 data gradient over its sub-lattice of taps (conv_igemm.hip)
+        p.splits = 1; p.ksplit = 0; p.part = nullptr;
+        p.stride = 1; p.wt_step = 2; p.wt_S = d->S;
+        p.o_step = 2; p.o_W = d->W; p.o_HW = d->H * d->W;
+        for (int a = 0; a < 2; ++a) {
+            for (int b = 0; b < 2; ++b) {
+                const int Ha = (d->H - a + 1) / 2, Wb = (d->W - b + 1) / 2;
+                if (Ha <= 0 || Wb <= 0) continue;
+                const int ky0 = (a + d->pad) & 1, kx0 = (b + d->pad) & 1;
+                KsParams q = p;
+                q.R = ky0 < d->R ? (d->R - ky0 + 1) / 2 : 0;
+                q.S = kx0 < d->S ? (d->S - kx0 + 1) / 2 : 0;
+                if (q.R == 0 || q.S == 0) { q.R = 0; q.S = 0; }
+                q.pad = (a + d->pad - ky0) / 2;
+                q.pad_x = (b + d->pad - kx0) / 2;
+                q.wt_ky0 = ky0; q.wt_kx0 = kx0;
+                q.o_a = a; q.o_b = b;
+                q.OH = Ha; q.OW = Wb;
+                q.M = d->N * Ha * Wb;
+                q.Ktot = q.R * q.S * q.Cs;
+                int rc = dispatch_ks<MODE_DGRAD>(q, d->tuning & ~0xff00, st);
+                if (rc) return rc;
+            }
+        }
+        return SSCG_OK;
+    }
+    KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, d->tuning);
+    if (sp.splits > 1 && (!ws || ws_bytes < ks_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
+    p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
+    p.part = reinterpret_cast<float*>(ws);
+    return dispatch_ks<MODE_DGRAD>(p, d->tuning, st);
+}
+
+extern "C" int sscg_conv2d_split_applies(const sscg_conv_desc* d, int kind) {
+    if (!d) return 0;
+    sscg_conv_desc t = *d;
+    t.x_dtype = SSCG_F32; t.y_dtype = SSCG_F32; t.w_dtype = SSCG_BF16X3;
+    if (kind == 0) return sscg_convs_fwd_applies(&t) ? 1 : 0;
+    if (kind == 1) return sscg_convs_dgrad_applies(&t) ? 1 : 0;
+    return 0;
+}
+
+extern "C" int sscg_split3(const float* src, void* dst, int64_t n, int64_t plane_stride, void* stream) {
+    if (!src || !dst || n <= 0 || plane_stride < n) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(split3_kernel, dim3(cdiv((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, reinterpret_cast<bf16*>(dst),
+                       (size_t)n, (size_t)plane_stride);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+int sscg_krsc_to_crsk_split(const float* w, void* wt, int K, int RS, int C, hipStream_t st) {
+    dim3 grid(cdiv(C, 32), cdiv(K, 32), RS);
+    hipLaunchKernelGGL(krsc_to_crsk_split_kernel, grid, dim3(256), 0, st, w, reinterpret_cast<bf16*>(wt), K, RS, C, (size_t)K * RS * C);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}

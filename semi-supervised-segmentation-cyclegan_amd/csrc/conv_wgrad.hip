@@ -244,29 +244,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
             // the lane half h keeps the pixel parity it has in the fp32 walk, A and B alike
 #pragma unroll
             for (int g2 = 0; g2 < BKP / 16; ++g2) {
-                if constexpr (BF16 == 2) {      // split mode (common.h sscg_split3): fp32-accurate on the bf16 matrix cores
-                    bf16x8 a0[TM], a1[TM], a2[TM], b0[TN], b1[TN], b2[TN];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int kp = g2 * 8 + e;
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) { const sscg_bf3 t3 = sscg_split3((float)a[kp * 2 * LDA + i * 32]); a0[i][e] = t3.h; a1[i][e] = t3.m; a2[i][e] = t3.l; }
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) { const sscg_bf3 t3 = sscg_split3((float)b[kp * 2 * LDB + j * 32]); b0[j][e] = t3.h; b1[j][e] = t3.m; b2[j][e] = t3.l; }
-                    }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b0[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b2[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
-                        }
-                    continue;
-                }
                 bf16x8 pa[TM], pb[TN];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -345,7 +322,6 @@ struct WgPlan {
     int chunk;
 };
 
-int sscg_wgrad_force_cfg = -1, sscg_wgrad_force_splits = 0;   // sweep hook (tools/wgrad_sweep.py)
 
 // Cost model of one (tile class, pixel splits) choice, fitted to tools/wgrad_sweep.py on the MI355X:
 //   workgroups spread over 256 CUs => a CU runs r = ceil(tiles*splits / 256) of them (co-resident or back to back, the
@@ -398,10 +374,13 @@ WgPlan plan_wgrad(const sscg_conv_desc* d) {
         }
     }
     long splits = best_s;
-    if (sscg_wgrad_force_cfg >= 0 && pl.cfg <= 1) {
-        pl.cfg = sscg_wgrad_force_cfg;
+    // sscg_conv_desc.wgrad_tuning (tools/wgrad_sweep.py, tile-class tests): bits 0..7 = 1 + forced class (0 = 128x128, 1 = 64x64),
+    // bits 8..23 = forced pixel splits
+    const int force_cfg = (d->wgrad_tuning & 0xff) - 1, force_splits = (d->wgrad_tuning >> 8) & 0xffff;
+    if (force_cfg >= 0 && force_cfg <= 1 && force_splits > 0 && pl.cfg <= 1) {
+        pl.cfg = force_cfg;
         pl.bm = pl.bn = pl.cfg == 0 ? 128 : 64;
-        splits = sscg_wgrad_force_splits;
+        splits = force_splits;
         if (splits > steps) splits = steps;
     }
     long steps_per = cdiv(steps, splits);
@@ -433,10 +412,8 @@ template <int VA, int VB>
 int dispatch_wg(const WgParams& p, const WgPlan& pl, int precision, hipStream_t st) {
     switch (pl.cfg) {
         case 0: if (precision == 1) return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4), 1>(p, pl.splits, st);
-                if constexpr (VA == 4 && VB == 4) { if (precision == 2) return launch_wg<2, 2, 2, 2, VA, VB, true, 2>(p, pl.splits, st); }
                 return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);   // LDS-DMA staging when vectorisable
         case 1: if (precision == 1) return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4), 1>(p, pl.splits, st);
-                if constexpr (VA == 4 && VB == 4) { if (precision == 2) return launch_wg<2, 2, 1, 1, VA, VB, true, 2>(p, pl.splits, st); }
                 return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);
         case 2: if (precision == 1) return launch_wg<1, 4, 1, 1, VA, VB, false, true>(p, pl.splits, st);
                 return launch_wg<1, 4, 1, 1, VA, VB>(p, pl.splits, st);
@@ -465,16 +442,6 @@ int dispatch_wg_types(const WgParams& p, const WgPlan& pl, bool va4, bool vb4, h
 }
 
 }  // namespace
-
-extern "C" int sscg_debug_set_wgrad_plan(int target_wgs, int min_iters) {
-    if (min_iters < 0) {   // forced (cfg, splits) for the 128x128 / 64x64 classes
-        sscg_wgrad_force_cfg = target_wgs;
-        sscg_wgrad_force_splits = -min_iters;
-        return SSCG_OK;
-    }
-    sscg_wgrad_force_cfg = -1;   // anything else: back to the cost model
-    return SSCG_OK;
-}
 
 // ---- "thin" weight gradients: 1x1 convolutions with a handful of channels on one side (PixelDiscriminator:
 // 3 -> 64, 21 -> 64, 128 -> 1 at 256x256).  dw[k][c] = sum_p dy[p][k] * x[p][c] over 524288 pixels is a pure stream of

@@ -223,7 +223,7 @@ __global__ void weighted_sum_kernel(WsumArgs a, float* __restrict__ out) {
 
 // ---------------------------------------------------------------- Adam (torch.optim.Adam single-tensor arithmetic)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            __bf16* __restrict__ p16, size_t n, float step_size, float omb1, float beta2, float omb2, float eps,
+                            __bf16* __restrict__ p16, int split, size_t n, float step_size, float omb1, float beta2, float omb2, float eps,
                             float inv_bc2_sqrt, float grad_scale) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float gi = g[i] * grad_scale;
@@ -233,7 +233,14 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
         const float pn = p[i] - step_size * (mi / denom);
         p[i] = pn;
-        if (p16) p16[i] = (__bf16)pn;       // bf16 operand copy of the fp32 master weight (RNE)
+        if (p16) {
+            if (split) {      // the three bf16 planes of the split contraction (conv_split.hip), n elements apart
+                const sscg_bf3 t = sscg_split3(pn);
+                p16[i] = t.h; p16[n + i] = t.m; p16[2 * n + i] = t.l;
+            } else {
+                p16[i] = (__bf16)pn;       // bf16 operand copy of the fp32 master weight (RNE)
+            }
+        }
         m[i] = mi;
         v[i] = vi;
     }
@@ -400,16 +407,17 @@ extern "C" int sscg_weighted_sum(const float* const* terms, const float* w, int 
     return SSCG_OK;
 }
 
-extern "C" int sscg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, int64_t n,
+extern "C" int sscg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow, int shadow_dtype, int64_t n,
                               double lr, double beta1, double beta2, double eps, int step, float grad_scale, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return SSCG_ERR_BAD_ARG;
+    if (shadow && shadow_dtype != SSCG_BF16 && shadow_dtype != SSCG_BF16X3) return SSCG_ERR_BAD_ARG;
     // hyper-parameters arrive as doubles (python floats): 1 - beta must not be formed in fp32
     double bc1 = 1.0 - pow(beta1, (double)step);
     double bc2 = 1.0 - pow(beta2, (double)step);
     float step_size = (float)(lr / bc1);
     float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n, 16384)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, reinterpret_cast<__bf16*>(param_bf16), (size_t)n, step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       exp_avg_sq, reinterpret_cast<__bf16*>(shadow), shadow_dtype == SSCG_BF16X3 ? 1 : 0, (size_t)n, step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
                        inv_bc2_sqrt, grad_scale);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;

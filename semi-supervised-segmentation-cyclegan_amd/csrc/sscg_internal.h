@@ -17,6 +17,17 @@ int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, c
 bool sscg_wgrad16_applies(const sscg_conv_desc* d);
 size_t sscg_wgrad16_workspace(const sscg_conv_desc* d);
 int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_split.hip: fp32-accurate "split" contraction on the bf16 matrix cores (fp32 activations, w_dtype == SSCG_BF16X3)
+bool sscg_convs_fwd_applies(const sscg_conv_desc* d);
+bool sscg_convs_dgrad_applies(const sscg_conv_desc* d);
+bool sscg_convs_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* wm, int* tiles_n, int* splits, int* full_tiles, int* m_tail0);
+size_t sscg_convs_fwd_workspace(const sscg_conv_desc* d, long stat_L);
+size_t sscg_convs_dgrad_workspace(const sscg_conv_desc* d);
+int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
+                   double* xstats, void* ws, size_t ws_bytes, hipStream_t st);
+int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
+                     void* ws, size_t ws_bytes, hipStream_t st);
+int sscg_krsc_to_crsk_split(const float* w, void* wt, int K, int RS, int C, hipStream_t st);
 // conv_thin.hip: HBM-streaming kernels for 1x1 convolutions with a handful of channels on one side (PixelDiscriminator ends)
 bool sscg_thin1x1_fwd_applies(const sscg_conv_desc* d);
 int sscg_thin1x1_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, hipStream_t st);

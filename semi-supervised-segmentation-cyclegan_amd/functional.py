@@ -35,7 +35,7 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-F32, BF16 = _lib.F32, _lib.BF16
+F32, BF16, BF16X3 = _lib.F32, _lib.BF16, _lib.BF16X3
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
@@ -244,23 +244,40 @@ def to_nchw(x):
     return y
 
 
-_MODE = ["f32"]
+# What `--dtype f32` computes its contractions with: False = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), True = the fp32-accurate split
+# contraction on the bf16 matrix cores (conv_split.hip) wherever the library offers it.
+F32_SPLIT = [os.environ.get("SSCG_F32_SPLIT", "1") == "1"]
+_MODE = ["f32s" if F32_SPLIT[0] else "f32"]
 FUSE_STATS = [os.environ.get("SSCG_FUSE_STATS", "1") != "0"]    # norm statistics from the producing conv's epilogue (K3/K4)
 
 
 def set_conv_precision(mode):
     """Arithmetic of the networks (host-side policy; the library itself keeps no mode - every call carries its dtypes):
-      "f32"   (default, the reference's dtype, BASELINE config 2): fp32 tensors, exact fp32 MFMA contractions;
+      "f32"   (default, the reference's dtype, BASELINE config 2): fp32 tensors.  Which contraction that means is the build-wide
+              policy F32_SPLIT (env SSCG_F32_SPLIT, default on): "f32s" below, or "f32x";
+      "f32s"  fp32 tensors; forward / data-gradient contractions of every conv with >= 32 source channels (a multiple of 32) run as
+              the fp32-accurate split contraction on the BF16 matrix cores (conv_split.hip: each operand as three bfloat16 pieces,
+              six exact piece products accumulated in fp32; the weights' pieces are kept by the Adam kernel / the operand-copy
+              cache, the activations are split between LDS and the matrix cores); weight gradients, few-channel stems and heads
+              run the exact fp32 MFMA kernels;
+      "f32x"  fp32 tensors, exact fp32 MFMA contractions everywhere (v_mfma_f32_32x32x2_f32);
       "bf16"  (BASELINE configs 3/5): activations and conv-weight operand copies are bfloat16 in HBM, bf16 LDS tiles,
               v_mfma_f32_32x32x16_bf16 with fp32 accumulation; network inputs/outputs, norm statistics, losses, weight
               gradients, master weights and Adam moments stay fp32;
-      "bf16c" (round-1 mode): fp32 tensors, operands rounded to bf16 between LDS and the matrix cores;
-      "f32s"  (experimental): fp32 tensors and fp32-accurate contractions on the BF16 matrix cores - every operand is split into
-              three bfloat16 pieces between LDS and the matrix cores and six piece products (exact) are accumulated in fp32
-              (sscg_conv_desc.precision = 2; the heavy LDS-DMA tile classes only, everything else stays exact fp32)."""
-    m = {"f32": "f32", "fp32": "f32", "float32": "f32", "bf16": "bf16", "bfloat16": "bf16", "bf16c": "bf16c", "f32s": "f32s"}.get(str(mode).lower())
+      "bf16c" (round-1 mode): fp32 tensors, operands rounded to bf16 between LDS and the matrix cores."""
+    m = {"f32": "f32", "fp32": "f32", "float32": "f32", "bf16": "bf16", "bfloat16": "bf16", "bf16c": "bf16c", "f32s": "f32s",
+         "f32x": "f32x"}.get(str(mode).lower())
     if m is None:
-        raise _lib.SscgError("conv precision must be 'f32', 'f32s', 'bf16' or 'bf16c', got %r" % (mode,))
+        raise _lib.SscgError("conv precision must be 'f32', 'f32x', 'f32s', 'bf16' or 'bf16c', got %r" % (mode,))
+    if m == "f32":          # fp32 tensors: which contraction "f32" means is a build-wide policy (F32_SPLIT); "f32x" / "f32s" name one
+        m = "f32s" if F32_SPLIT[0] else "f32"
+    elif m == "f32x":
+        m = "f32"
+    if m != _MODE[0]:
+        # which operand copies (transposed fp32 / bf16 / split planes) a weight needs depends on the mode: forget the old mode's
+        # registrations, or every later step keeps rebuilding copies nothing reads
+        for _, kinds in globals().get("_WT_USERS", {}).values():
+            kinds.clear()
     _MODE[0] = m
 
 
@@ -291,35 +308,61 @@ def conv_out_size(h, k, stride, pad, dil):
 _DESC_CACHE = {}
 
 
-def make_desc(xshape, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0, xdt=F32, wdt=F32, ydt=F32, prec=0):
+TUNING = [0]        # sscg_conv_desc.tuning of every descriptor built from here on (tools/ and tile-class tests; 0 = the library's plan)
+WGRAD_TUNING = [0]  # sscg_conv_desc.wgrad_tuning, likewise
+
+
+def tuning(tile_class=None, split=0, wgrad_class=None, wgrad_splits=0, wgrad_flags=0):
+    """Set the per-call tuning fields of the descriptors built from here on (None / 0 = the library's own plans).  Returns the
+    previous pair: `old = F.tuning(tile_class=1); ...; F.TUNING[0], F.WGRAD_TUNING[0] = old`."""
+    old = (TUNING[0], WGRAD_TUNING[0])
+    TUNING[0] = (0 if tile_class is None else tile_class + 1) | (split << 8)
+    WGRAD_TUNING[0] = (0 if wgrad_class is None else wgrad_class + 1) | (wgrad_splits << 8) | (wgrad_flags << 24)
+    return old
+
+
+def make_desc(xshape, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0, xdt=F32, wdt=F32, ydt=F32, prec=0, wplane=0):
     """ConvDesc of a call, memoised (a step re-issues the same few dozen geometries thousands of times, and the host side
     of a launch is what bounds the 4-stream schedule)."""
-    key = (tuple(xshape), tuple(wshape), stride, pad, dil, pad_mode, act, slope, xdt, wdt, ydt, prec)
+    key = (tuple(xshape), tuple(wshape), stride, pad, dil, pad_mode, act, slope, xdt, wdt, ydt, prec, TUNING[0], WGRAD_TUNING[0], wplane)
     d = _DESC_CACHE.get(key)
     if d is None:
         d = _DESC_CACHE[key] = _build_desc(xshape, wshape, stride, pad, dil, pad_mode, act, slope)
         d.x_dtype, d.w_dtype, d.y_dtype, d.precision = xdt, wdt, ydt, prec
+        d.tuning, d.w_plane, d.wgrad_tuning = TUNING[0], wplane, WGRAD_TUNING[0]
     return d
 
 
-SPLIT_KINDS = {"fwd", "dgrad", "wgrad"}      # which products the experimental split mode covers (bisection aid)
+_SPLIT_OK = {}
+
+
+def split_applies(xshape, wshape, stride, pad, dil, pad_mode, kind):
+    """Does the library's split contraction (fp32 accuracy on the bf16 matrix cores) serve this product?  kind: 0 forward,
+    1 data gradient, 2 weight gradient.  The library decides (sscg_conv2d_split_applies); the answer is cached per geometry."""
+    key = (tuple(xshape), tuple(wshape), stride, pad, dil, pad_mode, kind)
+    v = _SPLIT_OK.get(key)
+    if v is None:
+        d = _build_desc(xshape, wshape, stride, pad, dil, pad_mode, ACT_NONE, 0.0)
+        v = _SPLIT_OK[key] = bool(lib.sscg_conv2d_split_applies(C.byref(d), kind))
+    return v
+
+
+SPLIT_KINDS = {"fwd", "dgrad"}      # which products the split mode covers (bisection aid; weight gradients always run exact fp32)
 
 
 def _prec(kind="fwd"):
-    """`precision` field for fp32-tensor contractions: bf16 rounding between LDS and the matrix cores in both bf16 modes; 2 = the
-    split-bf16 mode (fp32-accurate)."""
-    if _MODE[0] == "f32s":
-        return 2 if kind in SPLIT_KINDS else 0
-    return 0 if _MODE[0] == "f32" else 1
+    """`precision` field for fp32-tensor contractions: 1 = bf16 rounding between LDS and the matrix cores (both bf16 modes); the
+    split mode selects its kernels through the weight operand's dtype (SSCG_BF16X3), not through this field."""
+    return 0 if _MODE[0] in ("f32", "f32s") else 1
 
 
 _PLAN_SIZES = {}
 
 
 def _ws_bytes(d, which):
-    """Workspace size of a conv entry point.  The split plans depend on the geometry and on the tuning hooks: cached per
-    (descriptor object - one per geometry / dtype, make_desc - , entry point, hook generation)."""
-    key = (id(d), which, _lib.HOOK_GEN[0])
+    """Workspace size of a conv entry point.  The split plans depend on the geometry and on the descriptor's tuning fields: cached
+    per (descriptor object - one per geometry / dtype / tuning, make_desc - , entry point)."""
+    key = (id(d), which)
     v = _PLAN_SIZES.get(key)
     if v is None:
         v = _PLAN_SIZES[key] = getattr(lib, "sscg_conv2d_%s_workspace" % which)(C.byref(d))
@@ -327,7 +370,7 @@ def _ws_bytes(d, which):
 
 
 def _stats_bytes(d, g, l):
-    key = (id(d), "stats", g, l, _lib.HOOK_GEN[0])
+    key = (id(d), "stats", g, l)
     v = _PLAN_SIZES.get(key)
     if v is None:
         v = _PLAN_SIZES[key] = lib.sscg_conv2d_fwd_stats_bytes(C.byref(d), g, l)
@@ -400,22 +443,26 @@ def _timed(kind, d, fn):
     else:
         b16 = d.x_dtype == BF16 and d.y_dtype == BF16 and d.K >= 32 and d.R * d.S * d.C >= 32
     # algorithmic HBM bytes of the launch: every operand read once, the result written once
-    esz = {F32: 4, BF16: 2}
+    esz = {F32: 4, BF16: 2, BF16X3: 6}
     nbytes = (d.N * d.H * d.W * d.C * esz[d.x_dtype] + d.N * d.P * d.Q * d.K * esz[d.y_dtype]
               + d.K * d.R * d.S * d.C * (4 if kind == "wgrad" else esz[d.w_dtype]))
-    prof.records.append(((kind, "bf16" if b16 else "f32"), flops, key, e0, e1, float(nbytes)))
+    prof.records.append(((kind, "split" if d.w_dtype == BF16X3 else ("bf16" if b16 else "f32")), flops, key, e0, e1, float(nbytes)))
     return r
 
 
 # ----------------------------------------------------------------------------- raw ops
-def _fwd_operands(x, w):
-    """(weight operand, its dtype code) for a forward whose input is x: bf16 tiles when x is a bf16 activation with a
-    multiple of 64 channels, else the fp32 kernel on the fp32 master weight (stems, few-channel inputs)."""
+def _fwd_operands(x, w, geom=None):
+    """(weight operand, its dtype code, plane stride) for a forward whose input is x: bf16 tiles when x is a bf16 activation
+    with a multiple of 64 channels; the three-plane split copy in the split mode where the library's split kernels serve the
+    geometry `geom` = (stride, pad, dil, pad_mode); else the fp32 kernel on the fp32 master weight (stems, few-channel inputs)."""
     if x.dtype == torch.bfloat16:
         if x.shape[1] % 64:
             raise _lib.SscgError("bf16 activations with %d channels: the bf16 conv kernels need a multiple of 64" % x.shape[1])
-        return weight_bf16(w), BF16
-    return w, F32
+        return weight_bf16(w), BF16, 0
+    if _MODE[0] == "f32s" and "fwd" in SPLIT_KINDS and geom is not None and split_applies(x.shape, w.shape, *geom, 0):
+        ws, plane = weight_split(w)
+        return ws, BF16X3, plane
+    return w, F32, 0
 
 
 def _out_dtype(out_f32):
@@ -425,9 +472,9 @@ def _out_dtype(out_f32):
 def conv2d_fwd(x, w, bias, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0, out_f32=True, stats=None):
     """y = act(conv(x, w) + bias).  out_f32: keep the output fp32 in bf16 mode (network heads).
     stats = (G, L): also return the epilogue's column statistics buffer (None when the fusion does not apply)."""
-    wop, wdt = _fwd_operands(x, w)
+    wop, wdt, wplane = _fwd_operands(x, w, (stride, pad, dil, pad_mode))
     ydt = _out_dtype(out_f32)
-    d = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, act, slope, _dt(x), wdt, _DT[ydt], _prec())
+    d = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, act, slope, _dt(x), wdt, _DT[ydt], _prec(), wplane)
     y = empty_nhwc(d.N, d.K, d.P, d.Q, x.device, ydt)
     ws = _WS.get(_ws_bytes(d, "fwd"), x.device)
     if stats is not None:
@@ -455,8 +502,13 @@ def norm_stats_from_conv(cs, per_sample_glc, eps, running_mean=None, running_var
 
 
 def weight_transposed(w, dtype=torch.float32):
-    """[K][R][S][C] -> [C][R][S][K] (the operand layout of sscg_conv2d_dgrad), as fp32 or bf16."""
+    """[K][R][S][C] -> [C][R][S][K] (the operand layout of sscg_conv2d_dgrad), as fp32 or bf16; dtype "x3" = the three bf16
+    planes of the split contraction (a flat bf16 tensor of 3 * numel elements)."""
     k, c, r, s = w.shape
+    if dtype == "x3":
+        wt = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=w.device)
+        check(lib.sscg_weight_krsc_to_crsk(w.data_ptr(), F32, wt.data_ptr(), BF16X3, k, r * s, c, _stream()), "sscg_weight_krsc_to_crsk")
+        return wt
     src = w
     if dtype == torch.bfloat16:
         src = weight_bf16(w)            # transposing the bf16 shadow reads half the bytes
@@ -466,10 +518,21 @@ def weight_transposed(w, dtype=torch.float32):
     return wt
 
 
+def dgrad_operand(w, xshape, stride, pad, dil, dy_dtype=torch.float32):
+    """The transposed operand copy [C][R][S][K] of weight `w` in the form the data gradient of this geometry reads in the current
+    mode (uncached: tools and kernel tests; the networks use the per-parameter cache of conv2d_dgrad_param)."""
+    if dy_dtype == torch.bfloat16:
+        return weight_transposed(w, torch.bfloat16)
+    if _MODE[0] == "f32s" and "dgrad" in SPLIT_KINDS and split_applies(xshape, w.shape, stride, pad, dil, PAD_ZEROS, 1):
+        return weight_transposed(w, "x3")
+    return weight_transposed(w, torch.float32)
+
+
 def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0, out_dtype=torch.float32):
     """dx = act(dgrad(dy, wt) + bias); `wt` is the transposed operand copy [C][R][S][K] (weight_transposed), fp32 for an
     fp32 dy, bf16 for a bf16 dy."""
-    d = make_desc(xshape, wshape, stride, pad, dil, xdt=_DT[out_dtype], wdt=_dt(wt), ydt=_dt(dy), prec=_prec("dgrad"))
+    wdt = BF16X3 if (wt.dim() == 1 and wt.dtype == torch.bfloat16) else _dt(wt)      # the split copy is a flat tensor of three planes
+    d = make_desc(xshape, wshape, stride, pad, dil, xdt=_DT[out_dtype], wdt=wdt, ydt=_dt(dy), prec=_prec("dgrad"))
     dx = empty_nhwc(d.N, d.C, d.H, d.W, dy.device, out_dtype)
     ws = _WS.get(_ws_bytes(d, "dgrad"), dy.device)
     _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wt.data_ptr(), _ptr(bias), dx.data_ptr(),
@@ -484,6 +547,9 @@ def conv2d_dgrad_param(dy, w, xshape, wshape, stride, pad, dil, bias=None, act=A
         if wshape[0] % 64:
             raise _lib.SscgError("bf16 output gradients with %d channels: the bf16 conv kernels need a multiple of 64" % wshape[0])
         wt = _cached_wt(w, torch.bfloat16)
+    elif (_MODE[0] == "f32s" and "dgrad" in SPLIT_KINDS and out_dtype == torch.float32
+          and split_applies(xshape, wshape, stride, pad, dil, PAD_ZEROS, 1)):
+        wt = _cached_wt(w, "x3")
     else:
         wt = _cached_wt(w, torch.float32)
     return conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias, act, slope, out_dtype)
@@ -772,8 +838,10 @@ def _loss_ws(device):
     return _WS.get(lib.sscg_loss_workspace(0), device)
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, shadow_bf16=None):
-    check(lib.sscg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow_bf16), p.numel(), lr, beta1, beta2,
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, shadow_bf16=None, shadow_split=None):
+    """shadow_bf16: bf16 arena rewritten with the parameters; shadow_split: the 3-plane split arena (3 * numel bf16) instead."""
+    sh, sdt = (shadow_split, BF16X3) if shadow_split is not None else (shadow_bf16, BF16)
+    check(lib.sscg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(sh), sdt, p.numel(), lr, beta1, beta2,
                              eps, step, grad_scale, _stream()), "sscg_adam_step")
 
 
@@ -808,20 +876,34 @@ def refresh_transposed_weights(weights=(), all_users=True):
     `all_users` is only safe on a stream that is ordered behind EVERY optimiser's last update and every reader of the
     stale copies (a rebuild frees the old copy: the allocator may hand its block to the next allocation at once)."""
     bf16 = _MODE[0] == "bf16"
-    for w in weights:
-        _cached_wt(w, torch.bfloat16 if (bf16 and w.shape[0] % 64 == 0) else torch.float32)
+    if _MODE[0] != "f32s":       # (split mode: which copy a weight needs depends on its geometry - the registry below knows)
+        for w in weights:
+            _cached_wt(w, torch.bfloat16 if (bf16 and w.shape[0] % 64 == 0) else torch.float32)
     if not all_users:
+        if _MODE[0] == "f32s":
+            for w in weights:
+                ent = _WT_USERS.get(id(w))
+                if ent is not None:
+                    _refresh_kinds(w, ent[1])
         return
     for r, kinds in list(_WT_USERS.values()):
         w = r()
         if w is None:
             continue
-        if "t32" in kinds:
-            _cached_wt(w, torch.float32)
-        if "t16" in kinds:
-            _cached_wt(w, torch.bfloat16)
-        if "w16" in kinds:
-            weight_bf16(w)
+        _refresh_kinds(w, kinds)
+
+
+def _refresh_kinds(w, kinds):
+    if "t32" in kinds:
+        _cached_wt(w, torch.float32)
+    if "t16" in kinds:
+        _cached_wt(w, torch.bfloat16)
+    if "tx3" in kinds:
+        _cached_wt(w, "x3")
+    if "w16" in kinds:
+        weight_bf16(w)
+    if "wx3" in kinds:
+        weight_split(w)
 
 
 def _wtag(w):
@@ -831,9 +913,9 @@ def _wtag(w):
 def _cached_wt(w, dtype=torch.float32):
     """Transposed copy of a weight, cached ON the tensor object (dies with it; a recycled address can never
     alias).  Valid while neither torch (`_version`) nor our optimiser (`_WEIGHT_EPOCH`) has rewritten it."""
-    b16 = dtype == torch.bfloat16
-    _note_user(w, "t16" if b16 else "t32")
-    attr = "_sscg_wt16" if b16 else "_sscg_wt"
+    kind = "tx3" if dtype == "x3" else ("t16" if dtype == torch.bfloat16 else "t32")
+    _note_user(w, kind)
+    attr = {"tx3": "_sscg_wtx3", "t16": "_sscg_wt16", "t32": "_sscg_wt"}[kind]
     tag = _wtag(w)
     ent = getattr(w, attr, None)
     if ent is None or ent[0] != tag:
@@ -863,6 +945,30 @@ def weight_bf16(w):
         except AttributeError:
             pass
     return ent[1]
+
+
+def weight_split(w):
+    """(three-plane bf16 split copy of a conv weight in its own [K][R][S][C] layout, plane stride in elements): the operand of
+    the split contraction.  A parameter owned by optim.FusedAdam reads the optimiser's split shadow arena (rewritten by the
+    Adam kernel itself); any other weight (the frozen nets) gets a cached copy."""
+    _note_user(w, "wx3")
+    opt = getattr(w, "_sscg_opt", None)
+    opt = opt() if opt is not None else None
+    if opt is not None and hasattr(opt, "split_view"):
+        return opt.split_view(w)
+    tag = _wtag(w)
+    ent = getattr(w, "_sscg_wx3", None)
+    if ent is None or ent[0] != tag:
+        n = w.numel()
+        t = torch.empty(3 * n, dtype=torch.bfloat16, device=w.device)
+        src = w if w.is_contiguous(memory_format=CL) else w.contiguous(memory_format=CL)
+        check(lib.sscg_split3(src.data_ptr(), t.data_ptr(), n, n, _stream()), "sscg_split3")
+        ent = (tag, t)
+        try:
+            w._sscg_wx3 = ent
+        except AttributeError:
+            pass
+    return ent[1], w.numel()
 
 
 def _acc_target(param):

@@ -258,16 +258,28 @@ class semisuper_cycleGAN(object):
             if self.dp is not None:
                 self.dp.wait(g_works)
                 self.g_optimizer.step()                                              # :474 (deferred past the all-reduce)
+                self._refresh_generator_copies(dev)
         else:
             self._wait_operand_copies(torch.cuda.current_stream(dev))
             d_vals = self._d_step(a, recon_img, fake_img, fake_gt, unl_img, onehot_gt, resnet_recon_img)
             if self.dp is not None:
                 self.dp.wait(g_works)
                 self.g_optimizer.step()                                              # :474 (deferred: no D-step op reads G weights)
+                self._refresh_generator_copies(dev)
         vals = d_vals + (img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss, lab_loss_CE, lab_loss_MSE)
         out = {k: v.detach() for k, v in zip(LOSS_KEYS, vals)}
         out.update({k: v.detach() for k, v in extras.items()})
         return out
+
+    def _refresh_generator_copies(self, dev):
+        """Data parallel: the generator update lands AFTER the discriminator step was queued, so the operand copies of the
+        GENERATORS' weights are rebuilt here, on side lane 0, off the next step's critical path (the discriminators' copies are
+        rebuilt lazily by their own step: its stream may still be reading the old ones)."""
+        gen_w = [p for net in (self.Gis, self.Gsi) for p in net.parameters() if p.dim() == 4]
+        F.run_on_side_stream(dev, (), lambda: F.refresh_transposed_weights(gen_w, all_users=False))
+        if F.SideStream.enabled:
+            self._copies_ready = torch.cuda.Event()
+            self._copies_ready.record(F.SideStream.get(dev, 0))
 
     def _wait_operand_copies(self, stream):
         """Order `stream` behind the side lane that rebuilt the transposed / bf16 operand copies of the weights."""

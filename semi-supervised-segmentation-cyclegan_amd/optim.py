@@ -45,6 +45,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.trainable = ps
         self.arena16 = None    # bf16 shadow of `arena` (bf16 mode): the conv operand copies, rewritten by the Adam kernel itself
         self._shadow_ver = {}
+        self.arena_x3 = None   # three-plane bf16 split of `arena` (split mode, conv_split.hip): planes `arena.numel()` elements apart
+        self._split_ver = {}
         self._epoch = [0]      # bumped by step(): the cached transposed copies of these weights are stale
         self.slices = {}
         off = 0
@@ -91,6 +93,26 @@ class FusedAdam(torch.optim.Optimizer):
             self._shadow_ver[p] = p._version
         return self._view(self.arena16, p, self.slices[p][0])
 
+    # ---- split shadow (fp32-accurate contractions on the bf16 matrix cores): h + m + l planes of every parameter
+    def refresh_split(self):
+        n = self.arena.numel()
+        if self.arena_x3 is None:
+            self.arena_x3 = torch.empty(3 * n, dtype=torch.bfloat16, device=self.arena.device)
+        F.check(F.lib.sscg_split3(self.arena.data_ptr(), self.arena_x3.data_ptr(), n, n, F._stream()), "sscg_split3")
+        self._split_ver = {p: p._version for p in self.trainable}
+
+    def split_view(self, p):
+        """(plane 0 of parameter p inside the split arena - a flat bf16 view -, plane stride in elements)."""
+        if self.arena_x3 is None:
+            self.refresh_split()
+        elif self._split_ver.get(p) != p._version:      # torch wrote p (load_state_dict, init): re-split that slice
+            off, n = self.slices[p]
+            F.check(F.lib.sscg_split3(self.arena[off:off + n].data_ptr(), self.arena_x3[off:off + n].data_ptr(), n, self.arena.numel(),
+                                      F._stream()), "sscg_split3")
+            self._split_ver[p] = p._version
+        off, n = self.slices[p]
+        return self.arena_x3[off:off + n], self.arena.numel()
+
     def zero_grad(self, set_to_none=False):
         F.fill_(self.grad, 0.0)
 
@@ -99,8 +121,15 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._steps += 1
         F.SideStream.join(self.arena.device)     # weight gradients are accumulated on the side stream
+        # the operand copy the current arithmetic mode reads is rewritten by the Adam kernel; a copy left over from another mode is
+        # dropped (it would go stale silently; it is rebuilt from the arena on its next use)
+        mode = F.get_conv_precision()
+        if mode != "bf16" and self.arena16 is not None:
+            self.arena16, self._shadow_ver = None, {}
+        if mode != "f32s" and self.arena_x3 is not None:
+            self.arena_x3, self._split_ver = None, {}
         F.adam_step(self.arena, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                    self._steps, 1.0 / self.world_size, shadow_bf16=self.arena16)
+                    self._steps, 1.0 / self.world_size, shadow_bf16=self.arena16, shadow_split=self.arena_x3)
         F.bump_weight_epoch(self._epoch)
 
     def mark_touched(self):

@@ -37,8 +37,7 @@ class DataParallel:
         for opt in (g_opt, d_opt):
             opt.world_size = self.world_size
             broadcast_flat(opt.arena)
-            if opt.arena16 is not None:
-                opt.refresh_shadow()
+            _refresh_operand_copies(opt)
         for net in nets:
             for t in list(net.parameters()) + list(net.buffers()):
                 if getattr(t, "_sscg_grad", None) is None:   # arena-resident parameters were broadcast above
@@ -48,6 +47,7 @@ class DataParallel:
         """Single-optimiser drivers (supervised_model)."""
         opt.world_size = self.world_size
         broadcast_flat(opt.arena)
+        _refresh_operand_copies(opt)
         for net in nets:
             for t in list(net.parameters()) + list(net.buffers()):
                 if getattr(t, "_sscg_grad", None) is None:
@@ -71,6 +71,14 @@ class DataParallel:
         dist.barrier()
 
 
+def _refresh_operand_copies(opt):
+    """The optimiser's operand copies of its parameters (bf16 shadow / split planes) follow a broadcast of the arena."""
+    if opt.arena16 is not None:
+        opt.refresh_shadow()
+    if getattr(opt, "arena_x3", None) is not None:
+        opt.refresh_split()
+
+
 def allreduce_flat(flat, chunk=CHUNK_ELEMS, wait=True):
     """In-place sum all-reduce of a 1-D buffer in large chunks (async; `wait=False` returns the work handles)."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and dist.get_backend() != "nccl"):
@@ -87,7 +95,8 @@ def allreduce_flat(flat, chunk=CHUNK_ELEMS, wait=True):
 
 
 def broadcast_flat(flat, src=0, chunk=CHUNK_ELEMS):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    # (a one-rank RCCL group still runs the collective: `SSCG_FORCE_DP=1` / tests/test_rccl_gpu.py exercise the real code path)
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and dist.get_backend() != "nccl"):
         return flat
     n = flat.numel()
     for off in range(0, n, chunk):

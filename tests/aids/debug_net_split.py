@@ -35,7 +35,7 @@ for k in orig:
 
 
 def run(flag):
-    F.lib.sscg_debug_set_conv_cfg(flag)
+    F.tuning(tile_class=None if flag < 0 else flag & 0xff, split=(flag >> 8) & 0xff if flag >= 0 else 0)
     log.clear()
     torch.manual_seed(0)
     m = arch.define_Gen(args[0], args[1], 64, kind, norm="instance", use_dropout=False, gpu_ids=[0])

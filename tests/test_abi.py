@@ -28,15 +28,16 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_conv_desc_layout_matches_header():
     import ctypes
     lib = load_sub("_lib")
-    assert ctypes.sizeof(lib.ConvDesc) == 19 * 4
+    assert ctypes.sizeof(lib.ConvDesc) == 96          # 20 four-byte members, the 8-byte plane stride at offset 80, wgrad_tuning, padding
+    assert lib.ConvDesc.w_plane.offset == 80 and lib.ConvDesc.wgrad_tuning.offset == 88
     names = [f[0] for f in lib.ConvDesc._fields_]
     assert names == ["N", "H", "W", "C", "K", "R", "S", "P", "Q", "stride", "pad", "dil", "pad_mode", "act", "slope",
-                     "x_dtype", "w_dtype", "y_dtype", "precision"]
+                     "x_dtype", "w_dtype", "y_dtype", "precision", "tuning", "w_plane", "wgrad_tuning"]
     # the header declares the same members in the same order
     src = open(os.path.join(ROOT, "include", "sscg.h")).read()
     body = src[src.index("typedef struct sscg_conv_desc {"):src.index("} sscg_conv_desc;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    members = [m.strip() for decl in re.findall(r"(?:int32_t|float)\s+([^;]+);", body) for m in decl.split(",")]
+    members = [m.strip() for decl in re.findall(r"(?:int32_t|int64_t|float)\s+([^;]+);", body) for m in decl.split(",")]
     assert members == names
 
 

@@ -102,14 +102,14 @@ def test_conv_bf16_tensors(case, dev, bf16_mode):
     assert rel(acc - 1.0, wr.grad) < 2e-4
 
 
-TILE_CLASSES = [(100, "128x128/4 waves"), (101, "64x64"), (103, "128x64"), (104, "128x128/8 waves"), (105, "256x128/8 waves")]
+TILE_CLASSES = [(0, "128x128/4 waves"), (1, "64x64"), (3, "128x64"), (4, "128x128/8 waves"), (5, "256x128/8 waves")]
 
 
 @pytest.mark.parametrize("cfg", TILE_CLASSES, ids=[c[1].replace(" ", "") for c in TILE_CLASSES])
 @pytest.mark.parametrize("case", [(8, 256, 33, 33, 256, 3, 1, 2, 2, 2), (4, 128, 40, 48, 192, 3, 1, 1, 1, 1), (2, 64, 31, 37, 320, 1, 1, 0, 1, 2)],
                          ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_s%d_p%d_d%d_g%d" % c)
 def test_conv_bf16_every_tile_class(case, cfg, dev, bf16_mode):
-    """The planner picks one tile class per shape; here every class (forced through the tuning hook) runs the same
+    """The planner picks one tile class per shape; here every class (forced through sscg_conv_desc.tuning) runs the same
     convolutions: forward (+ fused BatchNorm statistics over `g` groups), data gradient - against fp64 on the bf16-rounded operands."""
     F = bf16_mode
     n, c, h, w, k, r, s, p, d, groups = case
@@ -126,7 +126,7 @@ def test_conv_bf16_every_tile_class(case, cfg, dev, bf16_mode):
     yv = yr.detach().view(groups, n // groups, k, yr.shape[2], yr.shape[3])
     mu = yv.mean((1, 3, 4))
     var = ((yv - mu.view(groups, 1, k, 1, 1)) ** 2).mean((1, 3, 4))
-    F.lib.sscg_debug_set_conv_cfg(cfg[0])
+    old = F.tuning(tile_class=cfg[0])
     try:
         y = F.conv2d_fwd(xg, wg, b.to(dev), s, p, d, out_f32=True)
         assert rel(y, yr) < 2e-5
@@ -141,7 +141,7 @@ def test_conv_bf16_every_tile_class(case, cfg, dev, bf16_mode):
             assert float((mean.double().cpu() - mu).abs().max()) < 1e-4 * scale
             assert rel(rstd, 1.0 / torch.sqrt(var + 1e-5)) < 1e-4
     finally:
-        F.lib.sscg_debug_set_conv_cfg(-1)
+        F.TUNING[0], F.WGRAD_TUNING[0] = old
 
 
 @pytest.mark.parametrize("flags", [(0, "transpose-read"), (1, "register-transposing"), (2, "transpose-read/8 waves")], ids=lambda f: f[1].replace(" ", ""))
@@ -159,12 +159,12 @@ def test_wgrad_bf16_every_kernel(case, flags, dev, bf16_mode):
     gy = torch.randn(yr.shape, generator=g)
     yr.backward(r16(gy))
     xg, gyg = dev16(x, dev), dev16(gy, dev)
-    F.lib.sscg_debug_set_conv_cfg(0xff | (flags[0] << 16))
+    old = F.tuning(wgrad_flags=flags[0])
     try:
         dw = F.conv2d_wgrad(xg, gyg, (k, c, r, r), s, p, d)
         assert rel(dw, wr.grad) < 2e-5
     finally:
-        F.lib.sscg_debug_set_conv_cfg(-1)
+        F.TUNING[0], F.WGRAD_TUNING[0] = old
 
 
 # layers at a network's fp32 boundary: (N, C, H, W, K, R, stride, pad, dil, x_is_f32)

@@ -191,29 +191,49 @@ def test_bench_cpu_baseline_leg_runs_and_reports(monkeypatch):
     finally:
         torch.set_num_threads(threads)
     assert r["kind"] == "port" and r["unit"] == "img/s" and r["value"] > 0 and r["cores"] >= 1
-    assert "32x32" in r["sample"] and "1 warm-up + 3 timed" in r["sample"] and r["cpu_model"] in r["sample"]
-    assert r["elided_dead_work"]["value"] > 0
+    assert "32x32" in r["sample"] and "2 timed steps at the fastest setting" in r["sample"] and r["cpu_model"] in r["sample"]
+    assert r["elided_dead_work"]["value"] > 0 and str(r["cores"]) in r["probe_seconds_per_step"]
     json.dumps(r)
+    # the thread-count search on a stub clock: 32 -> 64 pays (10 s -> 6 s), so all physical cores are tried too (9 s: over-subscribed);
+    # the fastest setting (64) is the one reported, from its two timed steps
+    cost = {32: 10.0, 64: 6.0, 128: 9.0}
+    clock = [0.0]
+    calls = []
+
+    def step(threads, as_written=True):
+        calls.append(threads)
+        clock[0] += cost[threads] * (1.0 if as_written else 0.9)
+    monkeypatch.setattr(bench, "cpu_thread_candidates", lambda physical: [32, 64, 128])
+    r = bench.cpu_baseline({"dataset": "voc2012", "C": 21, "H": 256, "W": 256}, step_fn=step, now=lambda: clock[0])
+    assert calls == [32, 64, 128, 64, 64, 64] and r["cores"] == 64 and abs(r["seconds_per_step"] - 6.0) < 1e-9
+    assert abs(r["value"] - 2 / 6.0) < 1e-4
+    # 32 -> 64 does not pay: the physical-core probe is skipped
+    cost[64] = 9.5
+    calls.clear()
+    r = bench.cpu_baseline({"dataset": "voc2012", "C": 21, "H": 256, "W": 256}, step_fn=step, now=lambda: clock[0])
+    assert calls == [32, 64, 64, 64, 64] and r["cores"] == 64
 
 
-def test_plan_size_cache_follows_the_tuning_hooks():
-    """functional caches the plan-dependent workspace sizes per (descriptor, entry point, tuning-hook generation): a tuning hook
-    call (tests, tools/) must invalidate them - the planners answer differently under a forced tile class."""
+def test_plan_sizes_follow_the_descriptor_tuning():
+    """Tile-class / split overrides travel in sscg_conv_desc.tuning (no process-wide hook): a descriptor built under a forced
+    tile class is a different descriptor with its own cached workspace size, and the library answers per descriptor."""
     import ctypes as C
     F = load_sub("functional")
     L = load_sub("_lib")
-    d = F.make_desc((16, 256, 33, 65), (256, 256, 3, 3), 1, 2, 2, xdt=L.BF16, wdt=L.BF16, ydt=L.BF16)
+    mk = lambda: F.make_desc((16, 256, 33, 65), (256, 256, 3, 3), 1, 2, 2, xdt=L.BF16, wdt=L.BF16, ydt=L.BF16)
+    d = mk()
+    a = F._ws_bytes(d, "fwd")
+    assert a == L.lib.sscg_conv2d_fwd_workspace(C.byref(d)) and F._ws_bytes(d, "fwd") == a
+    old = F.tuning(tile_class=1)                    # 64x64 tiles: a different tail split, a different workspace
     try:
-        a = F._ws_bytes(d, "fwd")
-        assert a == L.lib.sscg_conv2d_fwd_workspace(C.byref(d)) and F._ws_bytes(d, "fwd") == a
-        g0 = L.HOOK_GEN[0]
-        L.lib.sscg_debug_set_conv_cfg(101)          # 64x64 tiles: a different tail split, a different workspace
-        assert L.HOOK_GEN[0] == g0 + 1
-        b = F._ws_bytes(d, "fwd")
-        assert b == L.lib.sscg_conv2d_fwd_workspace(C.byref(d)) and b != a
+        d2 = mk()
+        assert d2 is not d and d2.tuning == 2 and d.tuning == 0
+        b = F._ws_bytes(d2, "fwd")
+        assert b == L.lib.sscg_conv2d_fwd_workspace(C.byref(d2)) and b != a
     finally:
-        L.lib.sscg_debug_set_conv_cfg(-1)
-    assert F._ws_bytes(d, "fwd") == a
+        F.TUNING[0], F.WGRAD_TUNING[0] = old
+    assert mk() is d and F._ws_bytes(d, "fwd") == a
+    assert not hasattr(L.lib, "sscg_debug_set_conv_cfg")
 
 
 def test_bench_spawns_its_own_ranks_when_no_launcher_is_present(monkeypatch):

@@ -21,7 +21,7 @@ SHAPES = [(32, 256, 64, 128, 256, 3, 1, 1, 1), (16, 256, 33, 65, 256, 3, 1, 2, 2
           (32, 64, 128, 256, 128, 3, 2, 1, 1), (32, 128, 64, 128, 256, 3, 2, 1, 1), (16, 64, 128, 256, 128, 4, 2, 1, 1),
           (16, 128, 64, 128, 256, 4, 2, 1, 1), (16, 256, 32, 64, 512, 4, 1, 1, 1)]
 # name, forced tile class (100 + cfg; 0xff = planner), tune flags (1 = LDS-DMA pieces spread over the MFMA groups)
-VARIANTS = [("plan", 0xff, 0), ("128x128w8", 104, 0), ("64x64", 101, 0)]
+VARIANTS = [("plan", None, 0), ("128x128w8", 4, 0), ("64x64", 1, 0)]      # (name, forced tile class or None, -)
 
 
 def timeit(fn, n=20):
@@ -51,7 +51,7 @@ for (n, c, h, w, k, r, s, p, d) in SHAPES:
     y_ref = y.float()
     dx_ref = F.conv2d_dgrad(gy, wtt, x.shape, wt.shape, s, p, d, out_dtype=torch.bfloat16).float()
     for name, cfg, tune in VARIANTS:
-        F.lib.sscg_debug_set_conv_cfg(cfg | (tune << 16))
+        old = F.tuning(tile_class=cfg)
         try:
             ey = float((F.conv2d_fwd(x, wt, None, s, p, d, out_f32=False).float() - y_ref).abs().max())
             ed = float((F.conv2d_dgrad(gy, wtt, x.shape, wt.shape, s, p, d, out_dtype=torch.bfloat16).float() - dx_ref).abs().max())
@@ -61,11 +61,11 @@ for (n, c, h, w, k, r, s, p, d) in SHAPES:
             td = timeit(lambda: F.conv2d_dgrad(gy, wtt, x.shape, wt.shape, s, p, d, out_dtype=torch.bfloat16))
             row += " | %-9s f %6.1f d %6.1f" % (name, flops / tf / 1e9, flops / td / 1e9)
         finally:
-            F.lib.sscg_debug_set_conv_cfg(-1)
+            F.TUNING[0], F.WGRAD_TUNING[0] = old
     # weight gradient: register-transposing kernel (flag 1) vs LDS-DMA + transpose-read kernel with 2 (default) / 3-4 copy stages
     dw_ref = None
     for name, tune in (("wg-old", 1), ("wg8-768", 0), ("wg4", 2), ("wg8-512", 4 << 4), ("wg8-1024", 8 << 4), ("wg8-1536", 12 << 4), ("wg8-384", 3 << 4)):
-        F.lib.sscg_debug_set_conv_cfg(0xff | (tune << 16))
+        old = F.tuning(wgrad_flags=tune)
         try:
             dw = F.conv2d_wgrad(x, gy, wt.shape, s, p, d)
             if dw_ref is None:
@@ -77,6 +77,6 @@ for (n, c, h, w, k, r, s, p, d) in SHAPES:
             tw = timeit(lambda: F.conv2d_wgrad(x, gy, wt.shape, s, p, d))
             row += " | %s %6.1f" % (name, flops / tw / 1e9)
         finally:
-            F.lib.sscg_debug_set_conv_cfg(-1)
+            F.TUNING[0], F.WGRAD_TUNING[0] = old
     out.write(row + "\n")
     out.flush()

@@ -47,7 +47,8 @@ def timeit(fn, iters=20):
 
 
 def main():
-    cfgs = [int(a, 0) for a in sys.argv[1:]] or [-1, 0, 1, 2, 3, 4]
+    cfgs = [int(a, 0) for a in sys.argv[1:]] or [-1, 0, 1, 2, 3, 4]      # forced tile classes of the exact-fp32 family (-1 = the planner)
+    F.set_conv_precision("f32x")
     for (N, C, H, W, K, R, s, p, d) in SHAPES:
         x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=CL)
         w = (torch.randn(K, C, R, R, device=dev) * 0.05).contiguous(memory_format=CL)
@@ -57,19 +58,16 @@ def main():
         flops = 2.0 * y.numel() * C * R * R
         line = "%-44s" % ("%dx%dx%d c%d k%d r%d s%d d%d" % (N, H, W, C, K, R, s, d))
         for cfg in cfgs:
-            F.lib.sscg_debug_set_conv_cfg(cfg)
+            F.tuning(tile_class=None if cfg < 0 else cfg & 0xff, split=(cfg >> 8) & 0xff if cfg >= 0 else 0)
             try:
                 tf = timeit(lambda: F.conv2d_fwd(x, w, None, s, p, d))
                 td = timeit(lambda: F.conv2d_dgrad(gy, wt, x.shape, w.shape, s, p, d))
                 line += " | %5s f %5.1f d %5.1f" % (hex(cfg) if cfg > 255 else cfg, flops / tf / 1e12, flops / td / 1e12)
             except Exception as e:
                 line += " | cfg%2d ERR" % cfg
-        F.lib.sscg_debug_set_conv_cfg(-1)
-        for (tw_, mi_) in ((0, 0),):
-            F.lib.sscg_debug_set_wgrad_plan(tw_, mi_)
-            tw = timeit(lambda: F.conv2d_wgrad(x, gy, w.shape, s, p, d))
-            line += " | wg(%d,%d) %5.1f" % (tw_, mi_, flops / tw / 1e12)
-        F.lib.sscg_debug_set_wgrad_plan(768, 12)
+        F.tuning()
+        tw = timeit(lambda: F.conv2d_wgrad(x, gy, w.shape, s, p, d))
+        line += " | wg %5.1f" % (flops / tw / 1e12)
         print(line)
         sys.stdout.flush()
 

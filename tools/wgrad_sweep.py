@@ -53,7 +53,7 @@ def main():
         gy = torch.randn_like(y)
         flops = 2.0 * y.numel() * C * R * R
         steps = (y.numel() // K + 31) // 32
-        F.lib.sscg_debug_set_wgrad_plan(0, 0)
+        F.tuning()
         t0 = timeit(lambda: F.conv2d_wgrad(x, gy, w.shape, s, p, d))
         print("%dx%dx%d c%d k%d r%d: steps %d default %.1f TF/s" % (N, H, W, C, K, R, steps, flops / t0 / 1e12))
         for cfg, b in ((0, 128), (1, 64)):
@@ -64,7 +64,7 @@ def main():
             for sp in cand:
                 if sp > 256:
                     continue
-                F.lib.sscg_debug_set_wgrad_plan(cfg, -sp)
+                F.tuning(wgrad_class=cfg, wgrad_splits=sp)
                 try:
                     t = timeit(lambda: F.conv2d_wgrad(x, gy, w.shape, s, p, d))
                 except Exception as e:
@@ -73,11 +73,11 @@ def main():
                 res.append((flops / t / 1e12, sp, sp * tiles))
             print("   cfg%d tiles %4d: " % (cfg, tiles) + " ".join("%d/%d:%.0f" % (sp, wg, tf) for tf, sp, wg in res)
                   + "   best %s" % (max(res)[1:],))
-        F.lib.sscg_debug_set_wgrad_plan(0, 0)
+        F.tuning()
         t0 = timeit(lambda: F.conv2d_wgrad(x, gy, w.shape, s, p, d))
         print("   cost model again: %.1f TF/s" % (flops / t0 / 1e12))
         sys.stdout.flush()
-    F.lib.sscg_debug_set_wgrad_plan(0, 0)
+    F.tuning()
 
 
 if __name__ == "__main__":
