@@ -22,6 +22,15 @@ NETS = [
     ("unet128_3_2", "unet_128", (3, 2), (1, 3, 256, 256)),      # 7 downs: 256 -> 2x2 at the bottleneck (InstanceNorm needs > 1 pixel)
 ]
 
+# Floor of the parity bound of the three CHAINED first-step losses (img_cycle_loss, gt_cycle_loss, cycle_img_dis_loss: two DeepLab
+# passes with argmax / ReLU-mask flips in between).  The bound is k = 4 times the reference's own fp32-vs-fp64 distance on the
+# loss, but that distance is ONE sample of a heavy-tailed noise (1e-4 .. 1.2e-3 on the goldens), so it needs a floor, and the floor
+# must not sit below the noise itself: SURVEY App. D measured the reference moving by up to 2.4e-3 (img_cycle_loss) between
+# OMP_NUM_THREADS=1 and 8, and every arithmetic variant of this build - exact fp32 MFMA or split contraction, any tile class -
+# lands 0.2e-3 .. 2.4e-3 from the fp64 oracle on these three (profiles/r03_chained_loss_spread.txt).  Losses one pass deep keep 1e-3.
+CHAINED_LOSS_FLOOR = 2.5e-3
+CHAINED_LOSSES = ("img_cycle_loss", "gt_cycle_loss", "cycle_img_dis_loss")
+
 STEP_CONFIGS = {  # tag -> (classes, dataset, H, W, batch, steps)
     "s64": (21, "voc2012", 64, 64, 2, 3),
     "s128": (21, "voc2012", 128, 128, 2, 1),

@@ -77,8 +77,11 @@ class SemiSupOracle:
     """State + one step of the semi-supervised CycleGAN (model.py:203-311 ctor, :370-552 loop body)."""
 
     def __init__(self, n_classes, state_dicts, lr=2e-4, lab_CE_weight=1.0, lab_MSE_weight=1.0, adversarial_weight=1.0,
-                 discriminator_weight=1.0, lamda_gt=0.1, norm="instance", use_dropout=False, crop=(64, 64), as_written=False):
+                 discriminator_weight=1.0, lamda_gt=0.1, norm="instance", use_dropout=False, crop=(64, 64), as_written=False, q=None):
         self.C = n_classes
+        # q = nets.Bf16Emulation: the same step in the caller's dtype (fp64) with every tensor the bf16 build keeps in bf16 rounded
+        # to bf16 at the same place - the yardstick of the bf16 parity tests (not the reference's arithmetic; None = exact)
+        self.q = nets._NOQ if q is None else q
         self.as_written = as_written   # also run the reference's forwards whose outputs nothing reads (timing baseline only)
         self.sd = state_dicts  # dict: Gis, Gsi, Di, Ds, old_Gis, old_Gsi, old_Di -> flat state dicts (modified in place)
         self.w = dict(ce=lab_CE_weight, l1=lab_MSE_weight, adv=adversarial_weight, dis=discriminator_weight, gt=lamda_gt)
@@ -98,29 +101,29 @@ class SemiSupOracle:
         return TF.interpolate(x, size=self.crop, mode="bilinear", align_corners=True)
 
     def _old_g(self, name, x, tanh):
-        return nets.resnet_generator(self.sd[name], x, 9, tanh, self.norm, self.use_dropout)
+        return nets.resnet_generator(self.sd[name], x, 9, tanh, self.norm, self.use_dropout, q=self.q)
 
     def _dis(self, name, x):
-        return nets.pixel_discriminator(self.sd[name], x, self.norm)
+        return nets.pixel_discriminator(self.sd[name], x, self.norm, q=self.q)
 
     def step(self, l_img, l_gt, unl_img, collect=None):
-        C, sd, w = self.C, self.sd, self.w
+        C, sd, w, q = self.C, self.sd, self.w, self.q
         mse = lambda x, t: ((x - t) ** 2).mean()  # nn.MSELoss against ones/zeros (model.py:441-446,514-528)
         # ---------------- generator step (model.py:376-474)
         self.g_opt.zero_grad()
         for p in self.d_params:
             p.requires_grad_(False)                                        # set_grad(..., False) :379
         lab = l_gt.squeeze(1)
-        fake_img = self.interp(nets.deeplab(sd["Gis"], one_hot(l_gt, C, l_img.dtype), True))   # :385,390
-        fake_gt = self.interp(nets.deeplab(sd["Gsi"], unl_img, True))                            # :386,391
-        lab_gt = self.interp(nets.deeplab(sd["Gsi"], l_img, True))                               # :387,392
+        fake_img = self.interp(nets.deeplab(sd["Gis"], one_hot(l_gt, C, l_img.dtype), True, q=q))   # :385,390
+        fake_gt = self.interp(nets.deeplab(sd["Gsi"], unl_img, True, q=q))                            # :386,391
+        lab_gt = self.interp(nets.deeplab(sd["Gsi"], l_img, True, q=q))                               # :387,392
         lab_loss_CE = TF.cross_entropy(lab_gt, lab)                                              # :398
         lab_gt = torch.softmax(lab_gt, 1)                                                        # :401
         fake_gt = torch.softmax(fake_gt, 1)                                                      # :402
-        recon_img = self.interp(nets.deeplab(sd["Gis"], fake_gt, True))                          # :408,413
+        recon_img = self.interp(nets.deeplab(sd["Gis"], fake_gt, True, q=q))                          # :408,413
         with torch.no_grad():
-            nets.deeplab(sd["Gis"], lab_gt.detach(), True)        # :409 result unused, but advances Gis' BN running stats
-        recon_gt = self.interp(nets.deeplab(sd["Gsi"], fake_img, True))                          # :410,415
+            nets.deeplab(sd["Gis"], lab_gt.detach(), True, q=q)        # :409 result unused, but advances Gis' BN running stats
+        recon_gt = self.interp(nets.deeplab(sd["Gsi"], fake_img, True, q=q))                          # :410,415
         with torch.no_grad():
             resnet_fake_gt = torch.softmax(self._old_g("old_Gsi", unl_img, False), 1)            # :418,421
             resnet_recon_img = self._old_g("old_Gis", resnet_fake_gt, True)                      # :422

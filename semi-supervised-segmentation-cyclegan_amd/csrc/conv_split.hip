@@ -78,7 +78,7 @@ __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
 template <int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void convs_kernel(KsParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -473,17 +473,26 @@ __global__ __launch_bounds__(256) void ks_reduce_kernel(const float* __restrict_
 }
 
 // ---- host side: tile classes and the split-K plan of the tail (same policy as conv_igemm.hip)
-enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_NCFG = 5 };
-const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64};
-const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128};
-const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2};        // wave rows of a tile = statistics records per tile row
+enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_128x128_W8 = 5, KS_64x64_W2 = 6, KS_NCFG = 7 };
+const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64, 128, 64};
+const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128, 128, 64};
+const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2, 4, 2};        // wave rows of a tile = statistics records per tile row
 
+// Measured on the step's shapes (tools/convs_bench.py, profiles/r03_convs_tile_classes.txt):
+//  * 128x128 (4 waves of 64x64) wins wherever it fills the chip twice over (>= 512 tiles; >= 1024 when the reduction is short):
+//    197-200 TF/s on the 65536-row and 17424-row 3x3 convs;
+//  * 128x64 (4 waves of 32x64: every A fragment is split by ONE wave) for long reductions on the 8712 / 17424-row maps whose
+//    128x128 tiling would leave CUs idle (135-185 TF/s against 95-168);
+//  * 64x64 for short reductions (1x1 convs with <= 512 source channels: prologue / epilogue bound) and few output channels.
 int ks_choose(long M, int Ng, int Ktot, int tuning) {
     const int forced = (tuning & 0xff) - 1;
     if (forced >= 0 && forced < KS_NCFG && Ng >= KS_BN[forced] / 2) return forced;
-    (void)Ktot;
-    if (Ng <= 64) return cdiv(M, 128) >= 384 ? KS_128x64 : KS_64x64;
-    if ((long)cdiv(M, 128) * cdiv(Ng, 128) >= 384) return KS_128x128;
+    const long tm = cdiv(M, 128);
+    if (Ng <= 64) return tm >= 384 ? KS_128x64 : KS_64x64;
+    const long t128 = tm * cdiv(Ng, 128);
+    if (Ng <= 128) return (t128 >= 1024 && Ktot >= 512) ? KS_128x128 : KS_64x64;
+    if (t128 >= (Ktot >= 1024 ? 512 : 1024) && Ktot >= 512) return KS_128x128;
+    if (Ktot >= 1024) return KS_128x64;
     return KS_64x64;
 }
 
@@ -574,6 +583,8 @@ int dispatch_ks(const KsParams& p, int tuning, hipStream_t st) {
         case KS_64x64: return launch_ks<MODE, 2, 2, 1, 1>(p, st);
         case KS_128x64: return launch_ks<MODE, 4, 1, 1, 2>(p, st);
         case KS_64x128: return launch_ks<MODE, 2, 2, 1, 2>(p, st);
+        case KS_128x128_W8: return launch_ks<MODE, 4, 2, 1, 2>(p, st);    // 8 waves of 32x64: 4 waves per SIMD with two workgroups per CU
+        case KS_64x64_W2: return launch_ks<MODE, 2, 1, 1, 2>(p, st);      // 2 waves of 32x64
         default: return SSCG_ERR_BAD_ARG;
     }
 }

@@ -536,9 +536,14 @@ def test_deeplab_stages_bf16_vs_bf16_emulation(dev, bf16_mode):
 
 def test_cityscapes_first_step_bf16_vs_fp64_oracle(dev, bf16_mode):
     """BASELINE config 3's dataset geometry (Cityscapes, 20 classes, 1:2 crop) in bf16: first G+D step against the fp64
-    CPU oracle on the same keyed weights / inputs.  Stated bf16 tolerance: 5e-2 relative on the losses one DeepLab pass deep,
-    1e-1 on the three that chain two passes (the reference's own fp32 run is up to 1e-2 off fp64 there).
-    Measured (round 2): 3e-4 .. 3.3e-2."""
+    CPU oracle on the same keyed weights / inputs.  The yardstick is the WHOLE STEP under bf16 emulation (oracle.nets.Bf16Emulation:
+    the fp64 oracle with every tensor the build keeps in bf16 rounded at the same place).  The build's step and the emulated step
+    are two draws of the same bf16 rounding noise around the exact fp64 losses; a per-loss ratio of two such draws has no finite
+    bound worth stating (one of nine exceeds 4x about four times in five), so the criterion is POOLED: the rms over the nine losses
+    of the build's relative distance to fp64 may not exceed twice the emulation's (+ 2e-3) - and every single loss stays inside
+    the stated flat bf16 bound (5e-2 one DeepLab pass deep, 1e-1 for the three losses that chain two passes).
+    Measured: build 0.3e-3 .. 1.5e-2, emulation 0.6e-3 .. 1.6e-2 per loss; pooled rms 5.4e-3 vs 5.5e-3."""
+    from oracle import nets as onets
     F = bf16_mode
     md = load_sub("model")
     C, H, Wd = 20, 64, 128
@@ -555,15 +560,109 @@ def test_cityscapes_first_step_bf16_vs_fp64_oracle(dev, bf16_mode):
     np.random.seed(0)
     o64 = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float64, tag), crop=(H, Wd))
     r64 = o64.step(l_img.double(), l_gt, unl_img.double())
-    worst = 0.0
+    np.random.seed(0)
+    oem = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float64, tag), crop=(H, Wd), q=onets.Bf16Emulation)
+    rem = oem.step(l_img.double(), l_gt, unl_img.double())
+    es, ds = [], []
     for k in ostep.LOSS_KEYS:
         e = abs(got[k] - r64[k]) / abs(r64[k])
-        worst = max(worst, e)
-        print("%-20s bf16 %.6f oracle64 %.6f  rel %.2e" % (k, got[k], r64[k], e))
-        chained = k in ("img_cycle_loss", "gt_cycle_loss", "cycle_img_dis_loss")
-        assert e < (1e-1 if chained else 5e-2), k
+        d_emu = abs(rem[k] - r64[k]) / abs(r64[k])
+        es.append(e)
+        ds.append(d_emu)
+        print("%-20s bf16 %.6f emulation %.6f oracle64 %.6f  rel %.2e (emulation %.2e)" % (k, got[k], rem[k], r64[k], e, d_emu))
+        assert e < (1e-1 if k in FX.CHAINED_LOSSES else 5e-2), k
+    rms = lambda v: float(np.sqrt(np.mean(np.square(v))))
+    print("pooled over the nine losses: build %.2e, emulation %.2e" % (rms(es), rms(ds)))
+    assert rms(es) < 2.0 * rms(ds) + 2e-3
     # a second step runs on the updated bf16 shadow weights and stays finite
     l_img, l_gt, unl_img = FX.step_batch(tag, 1, C, H, Wd, 2)
     out2 = m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev))
     assert all(bool(torch.isfinite(v)) for v in out2.values())
     assert got["lab_loss_CE"] != float(out2["lab_loss_CE"])
+
+
+# ---- full-size shapes of the bf16 configurations (BASELINE configs 3 and 5)
+def _bf16_bench_shapes(name):
+    import os
+    import re
+    out = []
+    for line in open(os.path.join(os.path.dirname(__file__), "golden", name)):
+        m = re.match(r"(\d+)x(\d+)x(\d+) c(\d+) k(\d+) r(\d+) s(\d+) p(\d+) d(\d+)", line.strip())
+        if m:
+            sh = tuple(int(v) for v in m.groups())
+            if sh[3] % 64 == 0 and sh[4] % 64 == 0:        # both tensors bf16 inside the networks (stems / heads keep an fp32 side)
+                out.append(sh)
+    return sorted(set(out))
+
+
+def _adjoint_bf16(shape, F, dev):
+    N, H, W, C, K, R, s, p, d = shape
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    x = torch.randn(N, C, H, W, device=dev, generator=g).to(BF).contiguous(memory_format=CL)
+    w = (torch.randn(K, C, R, R, device=dev, generator=g) * 0.05).to(BF).contiguous(memory_format=CL)
+    y = F.conv2d_fwd(x, w, None, s, p, d, out_f32=True)
+    dy = torch.randn(y.shape, device=dev, generator=g).to(BF).contiguous(memory_format=CL)
+    dx = F.conv2d_dgrad(dy, F.weight_transposed(w, BF), x.shape, w.shape, s, p, d, out_dtype=torch.float32)
+    dw = F.conv2d_wgrad(x, dy, w.shape, s, p, d)
+
+    def dot(a, b):          # fp64 inner product in slices (these tensors reach gigabytes)
+        a, b = a.reshape(-1), b.reshape(-1)
+        t = 0.0
+        for i in range(0, a.numel(), 1 << 26):
+            t += float((a[i:i + (1 << 26)].double() * b[i:i + (1 << 26)].double()).sum())
+        return t
+    lhs, via_x, via_w = dot(y, dy), dot(x, dx), dot(w, dw)
+    scale = float(y.norm(dtype=torch.float64) * dy.norm(dtype=torch.float64))
+    # the products of bf16 operands are exact, the sums are fp32: the same noise class as the fp32 kernels
+    assert abs(lhs - via_x) <= 5e-8 * scale, (lhs, via_x, scale)
+    assert abs(lhs - via_w) <= 5e-8 * scale, (lhs, via_w, scale)
+
+
+@pytest.mark.parametrize("shape", _bf16_bench_shapes("bench_conv_shapes_c3.txt"), ids=lambda s: "%dx%dx%d_c%d_k%d_r%d_s%d_p%d_d%d" % s)
+def test_conv_bf16_adjoint_identities_at_config3_size(shape, dev, bf16_mode):
+    """Every bf16 convolution shape of BASELINE config 3 (Cityscapes 256x512, batch 16; list recorded by bench.py --config 3) at FULL
+    size on bf16 tensors: <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)> (fp32 results, fp64 inner products) - ties the
+    three bf16 kernels, their tile classes, tail splits, parity-class and pixel-split plans at these sizes to each other."""
+    _adjoint_bf16(shape, bf16_mode, dev)
+
+
+@pytest.mark.parametrize("shape", _bf16_bench_shapes("bench_conv_shapes_c5.txt"), ids=lambda s: "%dx%dx%d_c%d_k%d_r%d_s%d_p%d_d%d" % s)
+def test_conv_bf16_adjoint_identities_at_config5_rank_size(shape, dev, bf16_mode):
+    """The same for the per-rank workload of BASELINE config 5 (Cityscapes 512x1024, batch 4 per rank)."""
+    _adjoint_bf16(shape, bf16_mode, dev)
+
+
+@pytest.mark.parametrize("geom", [(256, 512, 16, 3), (512, 1024, 4, 5)], ids=["config3_256x512_b16", "config5_rank_512x1024_b4"])
+def test_full_size_bf16_step_agrees_with_fp32(geom, dev):
+    """ONE as-written G+D step of BASELINE config 3 (256x512, batch 16) and of config 5's per-rank workload (512x1024, batch 4) at
+    their own size, in bf16 and in the fp32 arithmetic, from the same seeded weights and batches: finite, and the nine losses agree
+    within the stated bf16 bound (5e-2 one DeepLab pass deep, 1e-1 for the three losses that chain two passes)."""
+    H, Wd, B, cfgno = geom
+    F = load_sub("functional")
+    md = load_sub("model")
+    data = load_sub("data")
+    C = 20
+    res = {}
+    try:
+        for mode in ("f32", "bf16"):
+            F.set_conv_precision(mode)
+            args = FX.make_args(dataset="cityscapes", crop_height=H, crop_width=Wd, batch_size=B, gpu_ids=[dev.index or 0],
+                                checkpoint_dir="/tmp/sscg_test_ckpt_full_%d" % cfgno, as_written=True)
+            torch.manual_seed(0)
+            m = quiet(md.semisuper_cycleGAN, args)
+            (l_img, l_gt, _), = list(data.SyntheticLoader(B, C, H, Wd, 1, 1, device=dev))
+            (unl_img, _, _), = list(data.SyntheticLoader(B, C, H, Wd, 1, 2, device=dev))
+            np.random.seed(0)
+            out = m.step(l_img, l_gt, unl_img)
+            m.sync_losses()
+            res[mode] = {k: float(v) for k, v in out.items()}
+            del m, out
+            torch.cuda.empty_cache()
+    finally:
+        F.set_conv_precision("f32")
+    for k in ostep.LOSS_KEYS:
+        a, b = res["bf16"][k], res["f32"][k]
+        e = abs(a - b) / abs(b)
+        print("%-20s bf16 %.6f fp32 %.6f rel %.2e" % (k, a, b, e))
+        assert np.isfinite(a) and np.isfinite(b), k
+        assert e < (1e-1 if k in ("img_cycle_loss", "gt_cycle_loss", "cycle_img_dis_loss") else 5e-2), k

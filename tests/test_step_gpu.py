@@ -198,7 +198,7 @@ def test_first_step_other_datasets_vs_live_oracle(cfg, dev):
         # chained = two DeepLab passes with discrete argmax/ReLU-mask flips in between: SURVEY App. D.2, k = 4 times the
         # oracle's own fp32-vs-fp64 distance, measured to the nearer of its two runs
         e32 = abs(got[k] - ref[k]) / abs(ref[k])
-        assert (min(e, e32) < max(4 * noise, 1e-3)) if chained else (e < 1e-3), k
+        assert (min(e, e32) < max(4 * noise, FX.CHAINED_LOSS_FLOOR)) if chained else (e < 1e-3), k
 
 
 def test_opt_in_nets_and_loss_variants(dev):

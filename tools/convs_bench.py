@@ -30,6 +30,17 @@ SHAPES = [
     (8, 64, 256, 256, 128, 1, 1, 0, 1),
     (16, 64, 256, 256, 128, 3, 2, 1, 1),
     (16, 128, 128, 128, 256, 3, 2, 1, 1),
+    (16, 512, 33, 33, 512, 3, 1, 4, 4),
+    (16, 512, 33, 33, 2048, 1, 1, 0, 1),
+    (8, 2048, 33, 33, 512, 1, 1, 0, 1),
+    (8, 1024, 33, 33, 2048, 1, 1, 0, 1),
+    (8, 64, 65, 65, 256, 1, 1, 0, 1),
+    (8, 256, 65, 65, 64, 1, 1, 0, 1),
+    (8, 128, 33, 33, 512, 1, 1, 0, 1),
+    (8, 512, 33, 33, 128, 1, 1, 0, 1),
+    (8, 512, 33, 33, 1024, 1, 1, 0, 1),
+    (8, 1024, 33, 33, 512, 1, 1, 0, 1),
+    (8, 64, 256, 256, 64, 3, 1, 1, 1),
 ]
 CHECK = [(2, 64, 32, 32, 128, 3, 2, 1, 1), (2, 128, 16, 16, 256, 3, 2, 1, 1), (2, 256, 9, 9, 256, 3, 1, 2, 2), (3, 64, 17, 17, 64, 3, 1, 1, 1),
          (2, 256, 33, 33, 1024, 1, 1, 0, 1), (8, 256, 33, 33, 256, 3, 1, 2, 2), (2, 64, 16, 16, 128, 4, 2, 1, 1), (1, 96, 20, 20, 160, 3, 1, 1, 1)]
@@ -85,7 +96,7 @@ def bench(tunings):
     for (N, C, H, W, K, R, s, p, d) in ([SHAPES[i] for i in idx] if idx else SHAPES):
         x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=CL)
         w = (torch.randn(K, C, R, R, device=dev) * 0.05).contiguous(memory_format=CL)
-        F.set_conv_precision("f32")
+        F.set_conv_precision("f32x")
         y = F.conv2d_fwd(x, w, None, s, p, d)
         wt = F.weight_transposed(w)
         gy = torch.randn_like(y)
@@ -93,7 +104,7 @@ def bench(tunings):
         line = "%-40s" % ("%dx%dx%d c%d k%d r%d s%d d%d" % (N, H, W, C, K, R, s, d))
         tf = timeit(lambda: F.conv2d_fwd(x, w, None, s, p, d))
         td = timeit(lambda: F.conv2d_dgrad(gy, wt, x.shape, w.shape, s, p, d))
-        line += " | f32 f %5.1f d %5.1f" % (flops / tf / 1e12, flops / td / 1e12)
+        line += " | exact f %5.1f d %5.1f" % (flops / tf / 1e12, flops / td / 1e12)
         F.set_conv_precision("f32s")
         wt3 = F.weight_transposed(w, "x3")
         for tun in tunings:
