@@ -62,8 +62,10 @@ typedef struct sscg_conv_desc {
     int32_t w_dtype;    /* ... of the weight operand handed to forward ([K][R][S][C]) / dgrad ([C][R][S][K]) */
     int32_t y_dtype;    /* ... of the [N][P][Q][K] tensor (forward output, dgrad / wgrad dy) */
     int32_t precision;  /* fp32 tensors only: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = operands rounded to bf16
-                         * (RNE) between LDS and the matrix cores, v_mfma_f32_32x32x16_bf16, fp32 accumulation.  (The
-                         * fp32-accurate split contraction of forward / data gradient is selected by w_dtype = SSCG_BF16X3.) */
+                         * (RNE) between LDS and the matrix cores, v_mfma_f32_32x32x16_bf16, fp32 accumulation; 2 (weight
+                         * gradient only) = both operands split into three bf16 pieces between LDS and the matrix cores, six
+                         * exact piece products accumulated in fp32 (fp32-accurate; the two LDS-DMA tile classes, exact fp32
+                         * elsewhere).  Forward / data gradient select the split contraction through w_dtype = SSCG_BF16X3. */
     int32_t tuning;     /* 0 = the library's own plan.  Tuning / test aid carried by the call (the library keeps no mutable state):
                          * bits 0..7 = 1 + forced tile class of the forward / data-gradient kernel family that serves the call,
                          * bits 8..15 = split-K (1 = never, n > 1 = every tile cut in n) */
@@ -114,9 +116,8 @@ int sscg_weight_krsc_to_crsk(const void* w, int w_dtype, void* wt, int wt_dtype,
  * sscg_weight_krsc_to_crsk produces directly with wt_dtype = SSCG_BF16X3). */
 int sscg_split3(const float* src, void* dst, int64_t n, int64_t plane_stride, void* stream);
 /* 1 when the split kernels serve this call (kind 0 = forward, 1 = data gradient; dtypes of `d` are ignored: fp32 tensors are
- * implied), 0 when the caller should use the exact-fp32 path (few-channel stems and heads, ragged channels).  Weight gradients
- * always run the exact-fp32 kernel: both of their operands would have to be split on the fly, which costs what the faster
- * matrix-core path saves. */
+ * implied), 0 when the caller should use the exact-fp32 path (few-channel stems and heads, ragged channels).  (The weight
+ * gradient takes precision = 2 for every geometry and falls back to exact fp32 by itself.) */
 int sscg_conv2d_split_applies(const sscg_conv_desc* d, int kind);
 /* dst[i] = (dst_dtype) src[i] */
 int sscg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);

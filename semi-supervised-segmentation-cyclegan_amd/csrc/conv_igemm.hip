@@ -768,7 +768,7 @@ static int check_desc(const sscg_conv_desc* d) {
     if (!d) return SSCG_ERR_BAD_ARG;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0) return SSCG_ERR_BAD_ARG;
     if (d->stride <= 0 || d->dil <= 0 || d->pad < 0) return SSCG_ERR_BAD_ARG;
-    if (!dt_ok(d->x_dtype) || !wdt_ok(d->w_dtype) || !dt_ok(d->y_dtype) || (d->precision < 0 || d->precision > 1)) return SSCG_ERR_BAD_ARG;
+    if (!dt_ok(d->x_dtype) || !wdt_ok(d->w_dtype) || !dt_ok(d->y_dtype) || (d->precision < 0 || d->precision > 2)) return SSCG_ERR_BAD_ARG;
     int P = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
     int Q = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
     if (P != d->P || Q != d->Q) return SSCG_ERR_BAD_ARG;

@@ -244,6 +244,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
             // the lane half h keeps the pixel parity it has in the fp32 walk, A and B alike
 #pragma unroll
             for (int g2 = 0; g2 < BKP / 16; ++g2) {
+                if constexpr (BF16 == 2) {      // split contraction (common.h sscg_split8): fp32-accurate on the bf16 matrix cores
+                    bf16x8 a0[TM], a1[TM], a2[TM], b0[TN], b1[TN], b2[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = a[(g2 * 8 + e) * 2 * LDA + i * 32];
+                        sscg_split8(v, a0[i], a1[i], a2[i]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = b[(g2 * 8 + e) * 2 * LDB + j * 32];
+                        sscg_split8(v, b0[j], b1[j], b2[j]);
+                    }
+                    // six piece products, smallest terms first; consecutive MFMAs write different accumulators
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) {
+                                const bf16x8& pa = t == 0 ? a2[i] : (t == 1 || t == 3) ? a1[i] : a0[i];
+                                const bf16x8& pb = (t == 0 || t == 3 || t == 5) ? b0[j] : (t == 1 || t == 4) ? b1[j] : b2[j];
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, pb, acc[i][j], 0, 0, 0);
+                            }
+                    continue;
+                }
                 bf16x8 pa[TM], pb[TN];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -412,8 +441,10 @@ template <int VA, int VB>
 int dispatch_wg(const WgParams& p, const WgPlan& pl, int precision, hipStream_t st) {
     switch (pl.cfg) {
         case 0: if (precision == 1) return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4), 1>(p, pl.splits, st);
+                if constexpr (VA == 4 && VB == 4) { if (precision == 2) return launch_wg<2, 2, 2, 2, VA, VB, true, 2>(p, pl.splits, st); }
                 return launch_wg<2, 2, 2, 2, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);   // LDS-DMA staging when vectorisable
         case 1: if (precision == 1) return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4), 1>(p, pl.splits, st);
+                if constexpr (VA == 4 && VB == 4) { if (precision == 2) return launch_wg<2, 2, 1, 1, VA, VB, true, 2>(p, pl.splits, st); }
                 return launch_wg<2, 2, 1, 1, VA, VB, (VA == 4 && VB == 4)>(p, pl.splits, st);
         case 2: if (precision == 1) return launch_wg<1, 4, 1, 1, VA, VB, false, true>(p, pl.splits, st);
                 return launch_wg<1, 4, 1, 1, VA, VB>(p, pl.splits, st);

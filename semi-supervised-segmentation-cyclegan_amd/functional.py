@@ -347,12 +347,18 @@ def split_applies(xshape, wshape, stride, pad, dil, pad_mode, kind):
     return v
 
 
-SPLIT_KINDS = {"fwd", "dgrad"}      # which products the split mode covers (bisection aid; weight gradients always run exact fp32)
+# Products the split mode covers (bisection aid).  The weight gradient has no pre-split operand: BOTH of its operands are split
+# between LDS and the matrix cores, which makes the kernel VALU-bound and no faster than the exact fp32 one when it runs alone -
+# but it then needs 2.7x fewer matrix-core cycles, and in the step's four-stream schedule those go to the forward / data-gradient
+# kernels running beside it: 156.6 -> 148.7 ms per step (SSCG_WGRAD_SPLIT=0 restores the exact fp32 weight gradient).
+SPLIT_KINDS = {"fwd", "dgrad"} | ({"wgrad"} if os.environ.get("SSCG_WGRAD_SPLIT", "1") == "1" else set())
 
 
 def _prec(kind="fwd"):
     """`precision` field for fp32-tensor contractions: 1 = bf16 rounding between LDS and the matrix cores (both bf16 modes); the
     split mode selects its kernels through the weight operand's dtype (SSCG_BF16X3), not through this field."""
+    if _MODE[0] == "f32s" and kind == "wgrad" and "wgrad" in SPLIT_KINDS:
+        return 2
     return 0 if _MODE[0] in ("f32", "f32s") else 1
 
 

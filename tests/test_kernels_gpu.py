@@ -685,11 +685,26 @@ def _sampled_dgrad_ref(dy, w, idx, xshape, s, p, d):
     return out
 
 
+def _sampled_wgrad_ref(x, dy, idx, s, p, d):
+    """fp64 values of the weight gradient at the sampled entries idx = (k, c, r, q): sum over every output pixel."""
+    N, C, H, W = x.shape
+    _, K, P, Q = dy.shape
+    k, c, r, q = idx
+    out = torch.zeros(k.numel(), dtype=torch.float64, device=x.device)
+    for i in range(k.numel()):
+        xp = TF.pad(x[:, int(c[i])].double(), (p, p, p, p))
+        r0, q0 = int(r[i]) * d, int(q[i]) * d
+        win = xp[:, r0:r0 + s * (P - 1) + 1:s, q0:q0 + s * (Q - 1) + 1:s]
+        out[i] = (win * dy[:, int(k[i])].double()).sum()
+    return out
+
+
 @pytest.mark.parametrize("shape", _bench_shapes(), ids=lambda s: "%dx%dx%d_c%d_k%d_r%d_s%d_p%d_d%d" % s)
 def test_split_contraction_is_fp32_accurate_at_bench_size(shape, F, dev):
     """The split contraction (conv_split.hip: every fp32 operand as three bfloat16 pieces, six exact piece products per pair on the
     bf16 matrix cores, fp32 accumulation) on EVERY convolution shape of the BASELINE step at full size (list recorded by bench.py).
-    Ground truth: 4096 sampled outputs of the forward and of the data gradient, each recomputed in fp64 from its receptive field.
+    Ground truth: 4096 sampled outputs of the forward and of the data gradient, each recomputed in fp64 from its receptive field,
+    and 96 sampled entries of the weight gradient (both operands split on the fly), each summed in fp64 over every output pixel.
     The split result must be as close to it as the exact-fp32 MFMA kernel is (rms error; both are a few 1e-7 of the tensor's rms) -
     three orders of magnitude below a bf16-rounded contraction - and the adjoint identity must hold between the two split products.
     Shapes the split kernels do not serve (few-channel stems / heads) run the exact kernel in either mode: both errors coincide."""
@@ -703,8 +718,12 @@ def test_split_contraction_is_fp32_accurate_at_bench_size(shape, F, dev):
     ri = lambda hi: torch.randint(0, hi, (ns,), device=dev, generator=g)
     fidx = (ri(N), ri(K), ri(P), ri(Q))
     didx = (ri(N), ri(C), ri(H), ri(W))
+    nw = 96
+    rw = lambda hi: torch.randint(0, hi, (nw,), device=dev, generator=g)
+    widx = (rw(K), rw(C), rw(R), rw(R))
     yref = _sampled_fwd_ref(x, w, fidx, s, p, d)
     dxref = _sampled_dgrad_ref(dy, w, didx, x.shape, s, p, d)
+    dwref = _sampled_wgrad_ref(x, dy, widx, s, p, d)
     rms = lambda t: float(t.double().pow(2).mean().sqrt())
     errs = {}
     served = False
@@ -713,15 +732,24 @@ def test_split_contraction_is_fp32_accurate_at_bench_size(shape, F, dev):
             F.set_conv_precision(mode)
             y = F.conv2d_fwd(x, w, None, s, p, d)
             dx = F.conv2d_dgrad(dy, F.dgrad_operand(w, x.shape, s, p, d), x.shape, w.shape, s, p, d)
-            errs[mode] = (rms(y[fidx].double() - yref) / rms(yref), rms(dx[didx].double() - dxref) / rms(dxref))
+            dw = F.conv2d_wgrad(x, dy, w.shape, s, p, d)
+            errs[mode] = (rms(y[fidx].double() - yref) / rms(yref), rms(dx[didx].double() - dxref) / rms(dxref),
+                          rms(dw[widx].double() - dwref) / rms(dwref))
             if mode == "f32s":
                 served = F.split_applies(x.shape, w.shape, s, p, d, 0, 0) or F.split_applies(x.shape, w.shape, s, p, d, 0, 1)
                 dot = lambda a, b: float((a.double() * b.double()).sum())
-                lhs, via_x = dot(y, dy), dot(x, dx)
+                lhs, via_x, via_w = dot(y, dy), dot(x, dx), dot(w, dw)
                 assert abs(lhs - via_x) <= 5e-8 * float(y.double().norm() * dy.double().norm()), (lhs, via_x)
+                assert abs(lhs - via_w) <= 5e-8 * float(y.double().norm() * dy.double().norm()), (lhs, via_w)
     finally:
         F.set_conv_precision("f32")
-    print("rms error against fp64 samples (fwd, dgrad): exact fp32 %s, split %s, split kernels used: %s" % (errs["f32x"], errs["f32s"], served))
-    for e_split, e_exact in zip(errs["f32s"], errs["f32x"]):
+    print("rms error against fp64 samples (fwd, dgrad, wgrad): exact fp32 %s, split %s, split kernels used: %s" % (errs["f32x"], errs["f32s"], served))
+    for e_split, e_exact in zip(errs["f32s"][:2], errs["f32x"][:2]):
         assert e_split < 2e-6
         assert e_split <= 1.1 * e_exact + 2e-8
+    # weight gradient: the reduction runs over up to 524288 pixels (cut into chunks of a few thousand per workgroup); once the
+    # running sum is ~100x a single product, the smallest piece products (2^-16 of a product) fall below its last bit, so on the
+    # longest reductions the split result is up to 2x the exact kernel's error - still fp32 roundoff class (1.4e-6 at worst
+    # against 2.2e-6 for the exact kernel's own worst shape); 96 samples: +-10 % on either estimate
+    assert errs["f32s"][2] < 3e-6
+    assert errs["f32s"][2] <= 2.2 * errs["f32x"][2] + 5e-8
