@@ -213,7 +213,7 @@ size_t sscg_loss_workspace(int64_t n);
 /* nn.CrossEntropyLoss (model.py:272; calls :398,:455): logits [rows][C], labels [rows].  Pixels whose label is outside
  * [0, C) are ignored (no read past the row, excluded from the mean, zero gradient) - torch's ignore_index behaviour for
  * every out-of-range id.  `valid` (nullable) receives the number of counted pixels; the backward divides by it
- * (NULL = rows). */
+ * (NULL = rows).  No counted pixel at all: the loss is NaN (torch's 0 / 0), the gradient zero. */
 int sscg_ce_fwd(const float* logits, const int64_t* labels, int64_t rows, int C, float* loss, float* valid, void* ws,
                 size_t ws_bytes, void* stream);
 int sscg_ce_bwd(const float* logits, const int64_t* labels, int64_t rows, int C, const float* gscale, float w,

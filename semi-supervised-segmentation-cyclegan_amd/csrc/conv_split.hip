@@ -78,7 +78,7 @@ __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
 template <int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void convs_kernel(KsParams p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -473,10 +473,10 @@ __global__ __launch_bounds__(256) void ks_reduce_kernel(const float* __restrict_
 }
 
 // ---- host side: tile classes and the split-K plan of the tail (same policy as conv_igemm.hip)
-enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_128x128_W8 = 5, KS_64x64_W2 = 6, KS_NCFG = 7 };
-const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64, 128, 64};
-const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128, 128, 64};
-const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2, 4, 2};        // wave rows of a tile = statistics records per tile row
+enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_NCFG = 5 };
+const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64};
+const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128};
+const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2};        // wave rows of a tile = statistics records per tile row
 
 // Measured on the step's shapes (tools/convs_bench.py, profiles/r03_convs_tile_classes.txt):
 //  * 128x128 (4 waves of 64x64) wins wherever it fills the chip twice over (>= 512 tiles; >= 1024 when the reduction is short):
@@ -583,8 +583,6 @@ int dispatch_ks(const KsParams& p, int tuning, hipStream_t st) {
         case KS_64x64: return launch_ks<MODE, 2, 2, 1, 1>(p, st);
         case KS_128x64: return launch_ks<MODE, 4, 1, 1, 2>(p, st);
         case KS_64x128: return launch_ks<MODE, 2, 2, 1, 2>(p, st);
-        case KS_128x128_W8: return launch_ks<MODE, 4, 2, 1, 2>(p, st);    // 8 waves of 32x64: 4 waves per SIMD with two workgroups per CU
-        case KS_64x64_W2: return launch_ks<MODE, 2, 1, 1, 2>(p, st);      // 2 waves of 32x64
         default: return SSCG_ERR_BAD_ARG;
     }
 }

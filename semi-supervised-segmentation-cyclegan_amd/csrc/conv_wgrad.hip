@@ -381,6 +381,9 @@ WgPlan plan_wgrad(const sscg_conv_desc* d) {
     const long steps = cdiv(npix, BKP);
     const double out_bytes = (double)Kc * Ng * sizeof(float);
     int first = 0, last = 1;   // candidate classes
+    // split contraction: the 64x64 class (one fragment per operand and wave) spends 14.7 VALU operations per MFMA on the operand split,
+    // the 128x128 class 7.3 - and the VALU pipe is what the step's concurrent kernels contend for (149.5 -> 147.0 ms per step)
+    if (d->precision == 2 && Kc >= 128 && Ng >= 128) last = 0;
     if (Kc <= 32) first = last = 2;
     else if (Ng <= 32 || d->C < 32) first = last = 3;
     else if (Kc <= 64 || Ng <= 64) first = last = 1;

@@ -125,7 +125,7 @@ __global__ void finish_ce_kernel(const double* __restrict__ part, int nparts, fl
     if (threadIdx.x == 0) {
         double t = 0.0, n = 0.0;
         for (int i = 0; i < 256; ++i) { t += sm[i]; n += sm[256 + i]; }
-        *loss = n > 0.0 ? (float)(t / n) : 0.f;
+        *loss = n > 0.0 ? (float)(t / n) : __builtin_nanf("");      // no pixel with a label in [0, C): NaN, as nn.CrossEntropyLoss gives
         if (valid) *valid = (float)n;
     }
 }

@@ -1551,6 +1551,10 @@ def backward(loss):
     not depend on the thread)."""
     with torch.autograd.set_multithreading_enabled(False):
         loss.backward()
+    # weight / bias / norm gradients are queued per side lane in batches (run_on_side_stream(defer=True)): launch what is still
+    # pending, so that a stream synchronisation after this call covers every gradient kernel of the pass (the arenas are complete
+    # once the side lanes are joined: SideStream.join / FusedAdam.step)
+    flush_side_work()
 
 
 def conv_norm_act(x, w, bias, stride, pad, dil, pad_mode, gamma, beta, residual, running_mean, running_var, per_sample, eps, momentum,

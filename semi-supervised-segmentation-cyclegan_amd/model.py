@@ -23,6 +23,17 @@ from .arch import define_Dis, define_Gen, set_grad
 from .optim import FusedAdam
 from .utils import CLASSES, make_one_hot
 
+def _check_bf16_widths(args):
+    """--dtype bf16: the bf16 conv kernels move 64-channel k-tiles, so every activation between a network's first conv and its head
+    must have a multiple of 64 channels - true for the reference's default widths (--ngf 64 --ndf 64), not for e.g. --ngf 32."""
+    if F.get_conv_precision() == "bf16":
+        for name in ("ngf", "ndf"):
+            v = getattr(args, name, 64)
+            if v % 64:
+                raise ValueError("--dtype bf16 needs --%s to be a multiple of 64 (got %d): bf16 activations are tiled 64 channels at a "
+                                 "time; use --dtype f32 for narrower networks" % (name, v))
+
+
 def _select_device(args):
     """The reference puts everything on gpu_ids[0] (arch/ops.py:31-34, utils.py:221-227).  Kernels are launched on the
     CURRENT device's stream, so that device is made current once, here - `--gpu_ids 1` then works as in the reference."""
@@ -38,6 +49,7 @@ class semisuper_cycleGAN(object):
     def __init__(self, args, data_parallel=None):
         self.args = args
         _select_device(args)
+        _check_bf16_widths(args)
         self.n_channels = CLASSES[args.dataset]                     # model.py:205-210
         C, ids = self.n_channels, args.gpu_ids
         drop = not args.no_dropout
@@ -405,6 +417,7 @@ class supervised_model(object):
     def __init__(self, args, data_parallel=None):
         self.args = args
         _select_device(args)
+        _check_bf16_widths(args)
         self.n_channels = CLASSES[args.dataset]
         self.Gsi = define_Gen(input_nc=3, output_nc=self.n_channels, ngf=args.ngf, netG='deeplab', norm=args.norm,
                               use_dropout=not args.no_dropout, gpu_ids=args.gpu_ids)

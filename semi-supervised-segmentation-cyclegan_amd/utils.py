@@ -101,6 +101,10 @@ class Vgg16(torch.nn.Module):
                     seq.add_module(str(idx), conv)
                     seq.add_module(str(idx + 1), ops.ReLU(True))
             setattr(self, name, seq)
+        if weights is None:
+            # the reference always loads the ImageNet weights (utils.py:149): without them the loss is finite but not the
+            # reference's perceptual loss - say so, once per construction
+            print("**perceptual loss: no --vgg_weights given, VGG16 is He-initialised (NOT the reference's pretrained features)**")
         if weights is not None:
             sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
             own = self.state_dict()

@@ -65,8 +65,19 @@ def ref_conv(x, w, b, stride, pad, dil, reflect, act):
     return y
 
 
+@pytest.mark.parametrize("mode", ["f32x", "f32s"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_bwd(case, F, dev):
+def test_conv_fwd_bwd(case, mode, F, dev):
+    """nn.Conv2d forward / input gradient / weight gradient / bias gradient through the autograd function, against torch fp64, in
+    both contractions of fp32 tensors: the exact fp32 MFMA family ("f32x") and the split contraction ("f32s" = --dtype f32)."""
+    F.set_conv_precision(mode)
+    try:
+        _conv_fwd_bwd(case, F, dev)
+    finally:
+        F.set_conv_precision("f32")
+
+
+def _conv_fwd_bwd(case, F, dev):
     N, C, H, W, K, R, stride, pad, dil, reflect, bias, act = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
@@ -296,6 +307,11 @@ def test_cross_entropy_ignores_out_of_range_labels(F, dev):
     assert float(xg.grad[0, :, :4].abs().max()) == 0.0
     oh = F.label_onehot(lab.unsqueeze(1).to(dev), C).cpu()
     assert float(oh[0, :, :4].abs().max()) == 0.0 and float(oh.sum()) == float(((lab >= 0) & (lab < C)).sum())
+    # not one valid pixel: NaN, like torch (a broken label pipeline must not train on a silently empty loss), zero gradient
+    xe = gpu(x, dev).requires_grad_(True)
+    le = F.cross_entropy(xe, torch.full_like(lab, 255).to(dev))
+    assert bool(torch.isnan(le))
+    assert bool(torch.isnan(TF.cross_entropy(x, torch.full_like(lab, -100), ignore_index=-100)))
 
 
 def test_gauss_noise_statistics(F, dev):
@@ -431,18 +447,28 @@ def _bench_shapes():
     return sorted(set(out))
 
 
+@pytest.mark.parametrize("mode", ["f32x", "f32s"])
 @pytest.mark.parametrize("shape", _bench_shapes(), ids=lambda s: "%dx%dx%d_c%d_k%d_r%d_s%d_p%d_d%d" % s)
-def test_conv_adjoint_identities_at_bench_size(shape, F, dev):
+def test_conv_adjoint_identities_at_bench_size(shape, mode, F, dev):
     """Every convolution shape of the BASELINE step (VOC 256x256, batch 8; list recorded by bench.py) at FULL size:
     <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)>.  Size-independent, ties the three kernels (and their split /
-    parity-class / tile plans at these sizes) to each other; the inner products are taken in fp64."""
+    parity-class / tile plans at these sizes) to each other; the inner products are taken in fp64.  Both fp32 kernel families:
+    the exact fp32 MFMA ("f32x") and the split contraction ("f32s", what --dtype f32 runs)."""
+    F.set_conv_precision(mode)
+    try:
+        _adjoint_at_bench_size(shape, F, dev)
+    finally:
+        F.set_conv_precision("f32")
+
+
+def _adjoint_at_bench_size(shape, F, dev):
     N, H, W, C, K, R, s, p, d = shape
     g = torch.Generator(device=dev).manual_seed(sum(shape))
     x = torch.randn(N, C, H, W, device=dev, generator=g).contiguous(memory_format=CL)
     w = (torch.randn(K, C, R, R, device=dev, generator=g) * 0.05).contiguous(memory_format=CL)
     y = F.conv2d_fwd(x, w, None, s, p, d)
     dy = torch.randn(y.shape, device=dev, generator=g).contiguous(memory_format=CL)
-    dx = F.conv2d_dgrad(dy, F.weight_transposed(w), x.shape, w.shape, s, p, d)
+    dx = F.conv2d_dgrad(dy, F.dgrad_operand(w, x.shape, s, p, d), x.shape, w.shape, s, p, d)
     dw = F.conv2d_wgrad(x, dy, w.shape, s, p, d)
     dot = lambda a, b: float((a.double() * b.double()).sum())
     lhs, via_x, via_w = dot(y, dy), dot(x, dx), dot(w, dw)
@@ -499,7 +525,7 @@ def test_conv_bf16_contraction_mode(shape, F, dev):
         assert F.get_conv_precision() == "bf16c"
         xg, wg, gyg = gpu(x, dev), gpu(w, dev), gpu(gy, dev)
         y = F.conv2d_fwd(xg, wg, None, s, p, d)
-        dx = F.conv2d_dgrad(gyg, F.weight_transposed(wg), xg.shape, wg.shape, s, p, d)
+        dx = F.conv2d_dgrad(gyg, F.dgrad_operand(wg, xg.shape, s, p, d), xg.shape, wg.shape, s, p, d)
         dw = F.conv2d_wgrad(xg, gyg, wg.shape, s, p, d)
     finally:
         F.set_conv_precision("f32")
@@ -753,3 +779,4 @@ def test_split_contraction_is_fp32_accurate_at_bench_size(shape, F, dev):
     # against 2.2e-6 for the exact kernel's own worst shape); 96 samples: +-10 % on either estimate
     assert errs["f32s"][2] < 3e-6
     assert errs["f32s"][2] <= 2.2 * errs["f32x"][2] + 5e-8
+

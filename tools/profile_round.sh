@@ -16,7 +16,7 @@ DB=$(find /tmp/prof_$TAG/kt -name "*.db" | head -1)
 python $ROOT/tools/kstats.py $DB $OUT/${TAG}_bench_kernel_stats_c$CFG.csv > $OUT/${TAG}_kstats_c$CFG.txt 2>&1
 i=0
 # FETCH_SIZE and WRITE_SIZE do not fit the TCC counter slots together: one pass each
-for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
   timeout 900 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d /tmp/prof_$TAG/pmc$i -o pmc -- python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-elided --no-bf16 --no-small > $OUT/${TAG}_pmc${i}_c$CFG.log 2>&1
 done
