@@ -163,3 +163,22 @@ def block_input(name, dtype=torch.float32):
 
 def block_grad_out(golden_name, yshape, dtype=torch.float32):
     return W.normal(SEED, "g1/%s/gy" % golden_name, tuple(yshape), dtype=dtype)
+
+
+# ---- VGG16 perceptual loss (utils.py:145-208): keyed weights of torchvision's `features[0:23]` (He-scaled normal,
+# small biases) in the build's Vgg16 state-dict layout (slice{1..4}.{features index}.{weight,bias}), and the two images of the golden
+VGG_SHAPE = (2, 3, 24, 40)
+
+
+def vgg_state_dict(dtype=torch.float32):
+    from . import nets as _nets
+    sd = {}
+    for idx, cin, cout in _nets.VGG16_CONVS:
+        k = "slice%d.%d" % (_nets._VGG_SLICE[idx], idx)
+        sd[k + ".weight"] = W.normal(SEED, "vgg/" + k + ".weight", (cout, cin, 3, 3), 0.0, (2.0 / (cin * 9)) ** 0.5, dtype)
+        sd[k + ".bias"] = W.normal(SEED, "vgg/" + k + ".bias", (cout,), 0.0, 0.05, dtype)
+    return sd
+
+
+def vgg_images(dtype=torch.float32):
+    return (W.uniform(SEED, "vgg/x", VGG_SHAPE, -1.0, 1.0, dtype), W.uniform(SEED, "vgg/y", VGG_SHAPE, -1.0, 1.0, dtype))

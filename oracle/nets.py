@@ -402,9 +402,10 @@ def conv_norm_act(w, b, x, stride, pad, norm, act, slope=0.2, transposed=False, 
     return torch.relu(y) if act == "relu" else TF.leaky_relu(y, slope)
 
 
-# utils.Vgg16 / utils.perceptual_loss (utils.py:145-208).  PARITY UNPINNED for this pair: the reference builds
-# torchvision.models.vgg16(pretrained=True) - torchvision and the weights are absent in the build container, so the restatement
-# below follows the reference's text and torchvision's published VGG16 layer table, not a run of the reference.
+# utils.Vgg16 / utils.perceptual_loss (utils.py:145-208).  Pinned (tests/golden/gen_golden.py g6_perceptual): the reference's own
+# function run on the CPU - torchvision.models.vgg16 stubbed by torchvision's published configuration-D layer table built from torch.nn
+# with keyed weights (the pretrained ImageNet weights are not in the image), Module.cuda the identity - agrees with this restatement
+# to 0.0 relative (loss and gradient, fp32 and fp64); golden: g6_perceptual.npz.
 VGG16_CONVS = ((0, 3, 64), (2, 64, 64), (5, 64, 128), (7, 128, 128), (10, 128, 256), (12, 256, 256), (14, 256, 256),
                (17, 256, 512), (19, 512, 512), (21, 512, 512))
 _VGG_SLICE = {0: 1, 2: 1, 5: 2, 7: 2, 10: 3, 12: 3, 14: 3, 17: 4, 19: 4, 21: 4}

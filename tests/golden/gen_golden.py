@@ -438,7 +438,72 @@ def g4(meta, md):
     meta["g4"] = {"config": dict(C=C, H=H, B=B, steps=2), "reference_f32": ref, "oracle_f32": out["f32"], "oracle_f64": out["f64"]}
 
 
+def g6_perceptual(meta):
+    """N4: the reference's own utils.Vgg16 / utils.perceptual_loss (utils.py:145-208) run on the CPU.  What the image
+    lacks is stubbed, nothing of the function itself: `torchvision.models.vgg16` returns a module whose `.features` is torchvision's
+    published configuration-D layer table (64 64 M 128 128 M 256 256 256 M 512 512 512 M 512 512 512 M: conv3x3+ReLU, MaxPool 2/2)
+    built from torch.nn and loaded with KEYED weights, and nn.Module.cuda is the identity for the duration of the call (the function
+    moves its VGG to gpu_ids[0], utils.py:199).  Checked: oracle.nets.perceptual_loss reproduces the loss and the gradient to the
+    generated image; written: the fp32 / fp64 loss and the fp64 gradient (g6_perceptual.npz)."""
+    from torch import nn
+    from oracle.fixtures import vgg_images, vgg_state_dict
+    import utils as ref_utils
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        sd = vgg_state_dict(dt)
+
+        def vgg16(pretrained=False, sd=sd, dt=dt):
+            layers, cin = [], 3
+            for v in (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"):
+                if v == "M":
+                    layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                else:
+                    layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                    cin = v
+            feats = nn.Sequential(*layers).to(dt)
+            with torch.no_grad():
+                for k, t in sd.items():                      # "sliceS.IDX.weight" -> features[IDX]
+                    idx, leaf = k.split(".")[1:]
+                    getattr(feats[int(idx)], leaf).copy_(t)
+                for i in range(24, len(feats)):               # layers past features[22] are never run by the reference's slices
+                    if isinstance(feats[i], nn.Conv2d):
+                        feats[i].weight.zero_()
+                        feats[i].bias.zero_()
+            m = nn.Module()
+            m.features = feats
+            return m
+        sys.modules["torchvision.models"].vgg16 = vgg16
+        ref_utils.models = sys.modules["torchvision.models"]
+        x, y = vgg_images(dt)
+        xr = x.clone().requires_grad_(True)
+        cuda = nn.Module.cuda
+        nn.Module.cuda = lambda self, device=None: self
+        try:
+            loss_ref = ref_utils.perceptual_loss(xr, y.clone(), [0])
+        finally:
+            nn.Module.cuda = cuda
+        loss_ref.backward()
+        xo = x.clone().requires_grad_(True)
+        loss_or = nets.perceptual_loss(sd, xo, y.clone())
+        loss_or.backward()
+        e_l, e_g = rel(loss_or, loss_ref), rel(xo.grad, xr.grad)
+        print("[g6] perceptual loss %s: reference %.9g oracle %.9g (rel %.1e), gradient rel %.1e" % (tag, float(loss_ref), float(loss_or), e_l, e_g))
+        assert e_l < (1e-6 if tag == "f32" else 1e-12) and e_g < (1e-5 if tag == "f32" else 1e-11)
+        out["loss/" + tag] = npf(loss_ref)
+        if tag == "f64":
+            out["dx/f64"] = npf(xr.grad)
+    np.savez_compressed(os.path.join(OUT, "g6_perceptual.npz"), **out)
+    meta["g6_perceptual"] = {"loss_f32": float(out["loss/f32"]), "loss_f64": float(out["loss/f64"])}
+
+
 def main():
+    if "--only-g6" in sys.argv:           # add the perceptual golden without re-running the half-hour of step goldens
+        install_stubs()
+        meta = json.load(open(os.path.join(OUT, "meta.json")))
+        g6_perceptual(meta)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        return
     os.makedirs(OUT, exist_ok=True)
     os.makedirs("/tmp/gg", exist_ok=True)
     install_stubs()
@@ -457,6 +522,7 @@ def main():
     g3(meta, md)
     print("g3 done")
     g4(meta, md)
+    g6_perceptual(meta)
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote", OUT)

@@ -652,26 +652,29 @@ def test_maxpool2x2_and_mse_between_tensors(F, dev):
     assert rel_err(ag.grad, ar.grad) < 1e-6 and rel_err(bg.grad, br.grad) < 1e-6
 
 
-def test_perceptual_loss_vs_restatement(dev):
+def test_perceptual_loss_vs_reference_golden(dev):
     """utils.perceptual_loss (commented out at model.py:454,462): VGG16 to relu2_2 on both images, MSE between the
-    features - against oracle.nets.perceptual_loss in fp64 on the same weights (loss and gradient to the generated image)."""
+    features - against the loss and the gradient the REFERENCE's own utils.perceptual_loss produced on keyed VGG weights
+    (g6_perceptual.npz, gen_golden.py g6_perceptual: fp64), and against oracle.nets.perceptual_loss."""
+    import os
+    from oracle import fixtures as FX
     from oracle import nets
     utils = load_sub("utils")
-    torch.manual_seed(4)
-    vgg = utils.Vgg16(requires_grad=False).to(dev)
+    F = load_sub("functional")
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_perceptual.npz"))
+    vgg = utils.Vgg16(requires_grad=False, weights={"features." + k.split(".", 1)[1]: v for k, v in FX.vgg_state_dict().items()}).to(dev)
     sd = {k: v.detach().double().cpu() for k, v in vgg.state_dict().items()}
     assert list(sd.keys())[:4] == ["slice1.0.weight", "slice1.0.bias", "slice1.2.weight", "slice1.2.bias"] and "slice4.21.bias" in sd
-    g = torch.Generator().manual_seed(6)
-    x = torch.rand(2, 3, 24, 40, generator=g, dtype=torch.float64) * 2 - 1
-    y = torch.rand(2, 3, 24, 40, generator=g, dtype=torch.float64) * 2 - 1
+    x, y = FX.vgg_images(torch.float64)
     xr = x.clone().requires_grad_(True)
-    lr = nets.perceptual_loss(sd, xr, y)
+    lr = nets.perceptual_loss(FX.vgg_state_dict(torch.float64), xr, y)
     lr.backward()
+    assert abs(float(lr) - float(gold["loss/f64"])) <= 1e-12 * float(gold["loss/f64"])
     xg = gpu(x, dev).requires_grad_(True)
     lg = utils.perceptual_loss(xg, gpu(y, dev), [0], vgg)
-    assert rel_err(lg, lr) < 1e-5
+    assert abs(float(lg) - float(gold["loss/f64"])) < 1e-5 * float(gold["loss/f64"])
     lg.backward()
-    assert rel_err(xg.grad, xr.grad) < 1e-4
+    assert rel_err(F.to_nchw(xg.grad), torch.from_numpy(gold["dx/f64"])) < 1e-4
     out = vgg(gpu(x, dev))
     assert tuple(out["relu4_3"].shape) == (2, 512, 3, 5)
 

@@ -177,8 +177,23 @@ def test_bf16_emulation_rounds_where_the_build_stores_bf16():
     assert 1e-5 < rel(y1, y0) < 5e-2
 
 
+def test_perceptual_loss_vs_reference_golden():
+    """oracle.nets.perceptual_loss against the loss / gradient the REFERENCE's utils.perceptual_loss produced (g6_perceptual.npz:
+    torchvision's VGG16 layer table with keyed weights behind a stub, gen_golden.py g6_perceptual)."""
+    g = np.load(os.path.join(GOLD, "g6_perceptual.npz"))
+    for tag, dt, tol in (("f32", torch.float32, 1e-6), ("f64", torch.float64, 1e-12)):
+        sd = FX.vgg_state_dict(dt)
+        x, y = FX.vgg_images(dt)
+        xr = x.clone().requires_grad_(True)
+        loss = nets.perceptual_loss(sd, xr, y)
+        assert abs(float(loss) - float(g["loss/" + tag])) <= tol * abs(float(g["loss/" + tag]))
+        if tag == "f64":
+            loss.backward()
+            assert rel(xr.grad, torch.from_numpy(g["dx/f64"])) < 1e-11
+
+
 def test_perceptual_loss_restatement_against_torch_modules():
-    """oracle.nets.perceptual_loss (utils.py:145-208; UNPINNED against the live reference: torchvision is absent) against an
+    """oracle.nets.perceptual_loss (utils.py:145-208) against an
     independent composition of torch.nn modules laid out like torchvision's VGG16 `features[0:9]` (configuration D: 64, 64, M,
     128, 128) with the reference's preprocessing (x / 2 + 1 / 2, then per channel * std + mean, in place)."""
     from torch import nn

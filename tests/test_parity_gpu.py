@@ -161,6 +161,51 @@ def test_evaluation_matches_the_references_label_maps(dev, meta):
             assert abs(class_iou[int(k)] - v) < 5e-3, k
 
 
+def test_validation_driver_writes_the_references_label_maps(dev, meta, tmp_path):
+    """validation.py (reference validation.py:42-157) end to end on the synthetic val set of the evaluation golden: checkpoint file ->
+    DeepLab Gsi in eval mode -> interp -> Softmax2d -> argmax -> paletted PNG.  The label maps read back from the PNGs must be the
+    ones the REFERENCE's modules predicted (g5_eval.npz), pixel for pixel except where the reference's own top-2 softmax margin is
+    below the fp32 noise of the logits; both drivers' paths (supervised: one PNG per image; semi-supervised: generated_labels)."""
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import validation as vdrv
+    utils = load_sub("utils")
+    cfg = meta["g5_eval"]["config"]
+    gold = np.load(os.path.join(GOLD, "g5_eval.npz"))
+    C, H, Wd, B = cfg["C"], cfg["H"], cfg["W"], cfg["B"]
+    sds = FX.semisup_state_dicts(C, torch.float32, cfg["tag"])
+    ck = tmp_path / "ckpt"
+    os.makedirs(ck)
+    utils.save_checkpoint({"epoch": 1, "Gsi": sds["Gsi"], "best_iou": 0.5}, str(ck / "latest_supervised_model.ckpt"))
+    utils.save_checkpoint({"epoch": 1, "Gsi": sds["Gsi"], "Gis": sds["Gis"], "best_iou": 0.5}, str(ck / "latest_semisuper_cycleGAN.ckpt"))
+    batches = []
+    for b in range(cfg["batches"]):
+        smp = [FX.synth_sample(cfg["tag"] + "/val", b * B + i, C, H, Wd) for i in range(B)]
+        batches.append((torch.stack([a for a, _ in smp]), torch.stack([g for _, g in smp]), ["v%d_%d" % (b, i) for i in range(B)]))
+    for model, sub in (("supervised_model", "supervised"), ("semisupervised_cycleGAN", os.path.join("unsupervised", "generated_labels"))):
+        args = FX.make_args(dataset=cfg["dataset"], crop_height=H, crop_width=Wd, batch_size=B, gpu_ids=[dev.index or 0],
+                            checkpoint_dir=str(ck), as_written=True)
+        args.model, args.validation_dir = model, str(tmp_path / ("val_" + model))
+        assert quiet(vdrv.validation, args, batches) == 0.5            # the checkpoint's best_iou comes back (validation.py:157)
+        mism = total = 0
+        for b in range(cfg["batches"]):
+            for i in range(B):
+                png = Image.open(os.path.join(args.validation_dir, sub, "v%d_%d.png" % (b, i)))
+                assert png.mode == "P" and png.size == (Wd, H)
+                got = np.asarray(png)
+                bad = got != gold["pred"][b][i]
+                mism += int(bad.sum())
+                total += bad.size
+                if bad.any():
+                    assert float(gold["margin"][b][i][bad].max()) < 1e-3      # only near-ties of the reference's own softmax may flip
+        print("%s: %d of %d pixels differ from the reference's label maps" % (model, mism, total))
+        assert mism < 2e-3 * total
+    sub = os.path.join(str(tmp_path / "val_semisupervised_cycleGAN"), "unsupervised")
+    for d in ("regenerated_labels", "regenerated_image", "image_from_labels"):
+        assert len(os.listdir(os.path.join(sub, d))) == cfg["batches"] * B
+
+
 # ------------------------------------------------------------------------------------------ 256x256 step (bench geometry)
 def test_training_step_256_vs_reference_golden(dev, meta):
     """one G+D step at 256x256 (batch 2) against the losses the reference recorded.  Criteria of App. D.4: the
