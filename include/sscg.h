@@ -71,8 +71,10 @@ typedef struct sscg_conv_desc {
                          * bits 8..15 = split-K (1 = never, n > 1 = every tile cut in n) */
     int64_t w_plane;    /* w_dtype == SSCG_BF16X3: elements between two planes of the weight operand; 0 = K*R*S*C (dense) */
     int32_t wgrad_tuning; /* 0 = the library's cost model.  bits 0..7 = 1 + forced weight-gradient tile class (0 = 128x128,
-                         * 1 = 64x64) with bits 8..23 = pixel splits; bits 24..31 = kernel-variant switches of the bf16
-                         * weight gradient (tools/conv16_bench.py) */
+                         * 1 = 64x64) with bits 8..23 = pixel splits; precision 2 only: class 2 = never the pre-split-planes
+                         * kernel (operands split on the fly), class 3 = the planes kernel also for 1x1 filters; bits 24..31 =
+                         * kernel-variant switches (bf16 weight gradient: tools/conv16_bench.py; planes kernel: bit 24 = two
+                         * copy stages) */
 } sscg_conv_desc;
 /* Supported dtype combinations.  forward: (x, w) both fp32 -> y fp32|bf16 (fp32 MFMA kernel: stems and few-channel
  * inputs); (x, w) both bf16 with C % 64 == 0 -> y fp32|bf16 (bf16 MFMA kernel, bf16 LDS tiles).  dgrad: the same with

@@ -758,3 +758,316 @@ int sscg_krsc_to_crsk_split(const float* w, void* wt, int K, int RS, int C, hipS
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
+
+// =====================================================================================================================
+// Weight gradient by the split contraction:  dW[k][tap][c] = sum_p dy[p][k] * x[src(p, tap)][c]   (fp32 tensors, fp32 result)
+//
+// Both operands are activations.  Split between LDS and the matrix cores (conv_wgrad.hip, BF16 == 2) every element is split once per
+// tile that touches it - 36 tiles for a 256-channel 3x3 - and the kernel is VALU-bound at 7-15 VALU operations per MFMA.  Here the
+// two tensors are split ONCE, by an element-wise pass into scratch planes (sscg_split3's rounding: 10 bytes of HBM traffic per
+// element, a tenth of the kernel's time), and the contraction reads bf16 planes only: the [pixel][channel] rows go to LDS as they
+// are, by LDS-DMA, and gfx950's transposing LDS read (`ds_read_b64_tr_b16`, conv_bf16.hip wgrad16t_kernel) hands every lane the
+// 8 pixels of its channel.  No VALU work in the k-loop.
+//   tile 128 (output channels) x 128 (tap, source channel); 4 waves of 64 x 64; k-tile = 16 pixels = ONE MFMA k-step of six piece
+//   products per accumulator; three planes per operand and stage = 24 KB: three workgroups per CU.
+namespace {
+
+constexpr int WS_BKP = 16;                 // pixels per k-tile
+constexpr int WS_ROWB = 256;               // bytes of one pixel row of one plane tile (128 channels bf16)
+constexpr int WS_PLANE = WS_BKP * WS_ROWB; // 4 KB
+constexpr int WS_OP = 3 * WS_PLANE;        // one operand, one stage
+constexpr int WS_STAGE = 2 * WS_OP;
+
+struct WgsParams {
+    const bf16* __restrict__ x3;      // three planes of x  [N*H*W][C], xplane elements apart
+    const bf16* __restrict__ dy3;     // three planes of dy [N*P*Q][Kc], yplane elements apart
+    long xplane, yplane;
+    float* __restrict__ out;          // dw (splits == 1) or workspace [splits][Kc][Ng]
+    int Kc, Ng, C;
+    int H, W, P, Q, S;
+    int stride, pad, dil, pad_mode;
+    int npix, chunk;
+    int tiles_n, tiles, splits;
+    float beta;
+    FastDiv div_pq, div_q;
+};
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4s;
+__device__ __forceinline__ int ws_sw(int pixel) { return (pixel & 3) << 2; }      // chunk swizzle of a 256-byte pixel row (wgrad16t_kernel)
+
+template <int NSTAGE>
+__global__ __launch_bounds__(256, 2) void wgrads_kernel(WgsParams p) {
+    constexpr int TM = 2, TN = 2, WN = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [NSTAGE][A planes 0..2][B planes 0..2]
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds0 = (lds_char*)smem_raw;
+
+    const int tid = threadIdx.x;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / p.tiles;
+    const int tl = lin - split * p.tiles;
+    const int tile_n = tl % p.tiles_n;
+    const int tile_m = tl / p.tiles_n;
+    const int m0 = tile_m * 128;
+    const int n0 = tile_n * 128;
+    const int p_begin = split * p.chunk;
+    const int p_end = min(p.npix, p_begin + p.chunk);
+    const bool reflect = p.pad_mode == 1;
+    const int wave_id = tid >> 6;
+    const int lane = tid & 63;
+    const bf16* const zero = reinterpret_cast<const bf16*>(sscg_zero_page_s);
+
+    // ---- copy side: wave w owns pixel rows 4 w .. 4 w + 3 of every k-tile, in all three planes of both operands (one 1 KB piece
+    // each); lane l writes chunk l % 16 of row l / 16, i.e. FETCHES source chunk (l % 16) ^ ws_sw(row)
+    const int c_row = wave_id * 4 + (lane >> 4);
+    const int c_q = (lane & 15) ^ ws_sw(c_row);
+    const bool a_colok = m0 + c_q * 8 < p.Kc;
+    const bf16* const a_src = p.dy3 + (a_colok ? m0 + c_q * 8 : 0);
+    const int b_n = n0 + c_q * 8;
+    const bool b_colok = b_n < p.Ng;
+    int tdy, tdx;
+    const bf16* b_src;
+    {
+        const int nn = b_colok ? b_n : 0;
+        const int tap = nn / p.C;
+        const int c = nn - tap * p.C;
+        const int ky = tap / p.S;
+        const int kx = tap - ky * p.S;
+        tdy = ky * p.dil - p.pad;
+        tdx = kx * p.dil - p.pad;
+        b_src = p.x3 + c;
+    }
+    const bool plain = p.Ng == p.C && p.stride == 1 && p.pad == 0;      // 1x1, stride 1: source pixel = output pixel
+    int dma_stage = 0;
+    int f_pix = p_begin;
+    const int lds_wave = __builtin_amdgcn_readfirstlane(wave_id * 1024);
+    auto request_tile = [&]() {
+        const int pix = f_pix + c_row;
+        const bool pok = pix < p_end;
+        const bf16* ga = (a_colok && pok) ? a_src + (size_t)pix * p.Kc : zero;
+        const long ya = (a_colok && pok) ? p.yplane : 0;
+        bool ok = b_colok && pok;
+        const int pp = ok ? pix : 0;
+        size_t spix;
+        if (plain) {
+            spix = (size_t)pp;
+        } else {
+            const int img = fd_div(pp, p.div_pq);
+            const int rem = pp - img * (p.P * p.Q);
+            const int oy = fd_div(rem, p.div_q);
+            const int ox = rem - oy * p.Q;
+            int sy = oy * p.stride + tdy;
+            int sx = ox * p.stride + tdx;
+            if (reflect) {
+                sy = sy < 0 ? -sy : sy;
+                sx = sx < 0 ? -sx : sx;
+                sy = sy >= p.H ? 2 * (p.H - 1) - sy : sy;
+                sx = sx >= p.W ? 2 * (p.W - 1) - sx : sx;
+            }
+            ok = ok & ((unsigned)sy < (unsigned)p.H) & ((unsigned)sx < (unsigned)p.W);
+            spix = (size_t)((img * p.H + sy) * p.W + sx);
+        }
+        const bf16* gb = ok ? b_src + spix * p.C : zero;
+        const long xb = ok ? p.xplane : 0;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + pl * ya),
+                                             (__attribute__((address_space(3))) void*)(lds0 + dma_stage * WS_STAGE + pl * WS_PLANE + lds_wave), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + pl * xb),
+                                             (__attribute__((address_space(3))) void*)(lds0 + dma_stage * WS_STAGE + WS_OP + pl * WS_PLANE + lds_wave), 16, 0, 0);
+        }
+        dma_stage = dma_stage + 1 == NSTAGE ? 0 : dma_stage + 1;
+        f_pix += WS_BKP;
+    };
+    constexpr int NPIECE = 6;
+
+    // ---- matrix-core side
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int i16 = lane & 15;
+    const int wm = wave_id / WN;
+    const int wn = wave_id % WN;
+    const int row_w = wm * TM * 32;
+    const int col_w = wn * TN * 32;
+    // transposing read: the lane supplies 4 consecutive channels (8 bytes) of pixel 8 lh + (i16 >> 2) and receives 4 pixels of ITS channel
+    const int tr_pix = 8 * lh + (i16 >> 2);
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ch = row_w + i * 32 + (li & 16) + 4 * (i16 & 3);
+        a_off[i] = tr_pix * WS_ROWB + (((ch >> 3) ^ ws_sw(tr_pix)) << 4) + ((ch >> 2) & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ch = col_w + j * 32 + (li & 16) + 4 * (i16 & 3);
+        b_off[j] = WS_OP + tr_pix * WS_ROWB + (((ch >> 3) ^ ws_sw(tr_pix)) << 4) + ((ch >> 2) & 1) * 8;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nsteps = (p_end - p_begin + WS_BKP - 1) / WS_BKP;
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+        if (s < nsteps) { request_tile(); ++issued; }
+    }
+    if (nsteps >= NSTAGE - 1) wait_vm<(NSTAGE - 2) * NPIECE>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+
+    int rd_stage = 0;
+    for (int it = 0; it < nsteps; ++it) {
+        const lds_char* base = lds0 + rd_stage * WS_STAGE;
+        bf16x4s fa[TM][3][2], fb[TN][3][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[i][pl][0]) : "v"(base + a_off[i]), "n"(pl * WS_PLANE));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[i][pl][1]) : "v"(base + a_off[i]), "n"(pl * WS_PLANE + 4 * WS_ROWB));
+            }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[j][pl][0]) : "v"(base + b_off[j]), "n"(pl * WS_PLANE));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[j][pl][1]) : "v"(base + b_off[j]), "n"(pl * WS_PLANE + 4 * WS_ROWB));
+            }
+        const bool more = issued < nsteps;
+        if (more) { request_tile(); ++issued; }      // into the stage read in the previous iteration (every wave is past that barrier)
+        __builtin_amdgcn_sched_barrier(0);
+        wait_lgkm<0>();
+        bf16x8 va[TM][3], vb[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                va[i][pl] = __builtin_shufflevector(fa[i][pl][0], fa[i][pl][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                pin(va[i][pl]);
+            }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                vb[j][pl] = __builtin_shufflevector(fb[j][pl][0], fb[j][pl][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                pin(vb[j][pl]);
+            }
+        // six piece products, smallest terms first; consecutive MFMAs write different accumulators
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int ap = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0;
+            const int bp = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1 || t == 4) ? 1 : 2;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i][ap], vb[j][bp], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rd_stage = rd_stage + 1 == NSTAGE ? 0 : rd_stage + 1;
+        if (more) wait_vm<(NSTAGE - 2) * NPIECE>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+    }
+
+    float* out = p.out + (size_t)split * p.Kc * p.Ng;
+    const bool direct = (p.splits == 1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + col_w + j * 32 + li;
+        if (n >= p.Ng) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.Kc) {
+                    const size_t o = (size_t)m * p.Ng + n;
+                    float v = acc[i][j][e];
+                    if (direct && p.beta != 0.f) v += p.beta * out[o];
+                    out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+struct WgsPlan { int splits, chunk; };
+
+// Pixel split: two workgroups per CU fit with three stages (72 KB of LDS), three with two (48 KB); one round of workgroups; at
+// least 8 k-tiles (128 pixels) per workgroup.
+WgsPlan plan_wgs(const sscg_conv_desc* d) {
+    const int Kc = d->K, Ng = d->R * d->S * d->C;
+    const long npix = (long)d->N * d->P * d->Q;
+    const long steps = cdiv(npix, WS_BKP);
+    const long tiles = (long)cdiv(Kc, 128) * cdiv(Ng, 128);
+    const int force = (d->wgrad_tuning >> 8) & 0xffff;
+    const bool two_stages = ((d->wgrad_tuning >> 24) & 1) != 0;       // tuning flag: two copy stages, three workgroups per CU
+    long s = force > 0 ? force : (two_stages ? 768 : 512) / tiles;
+    if (s > steps / 8) s = steps / 8;
+    if (s > 1024) s = 1024;
+    if (s < 1) s = 1;
+    WgsPlan pl;
+    pl.chunk = (int)(cdiv(steps, s) * WS_BKP);
+    pl.splits = cdiv(npix, pl.chunk);
+    return pl;
+}
+
+}  // namespace
+
+bool sscg_wgrads_applies(const sscg_conv_desc* d) {
+    if (d->precision != 2 || d->x_dtype != SSCG_F32 || d->y_dtype != SSCG_F32) return false;
+    if ((d->wgrad_tuning & 0xff) == 3) return false;      // tuning: class 2 = the on-the-fly split kernel of conv_wgrad.hip
+    const int Ng = d->R * d->S * d->C;
+    if ((d->wgrad_tuning & 0xff) != 4 && d->R * d->S == 1) return false;      // 1x1: too few flops per element for the split pass to pay (class 3 forces it)
+    return d->K >= 128 && Ng >= 128 && d->K % 8 == 0 && d->C % 8 == 0 && (long)d->N * d->P * d->Q >= 1024;
+}
+
+static size_t wgs_planes_bytes(const sscg_conv_desc* d) {
+    return ((size_t)d->N * d->H * d->W * d->C + (size_t)d->N * d->P * d->Q * d->K) * 3 * sizeof(bf16);
+}
+
+size_t sscg_wgrads_workspace(const sscg_conv_desc* d) {
+    const WgsPlan pl = plan_wgs(d);
+    const size_t part = pl.splits > 1 ? (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float) : 0;
+    return ((wgs_planes_bytes(d) + 255) & ~(size_t)255) + part;
+}
+
+int sscg_wgrads(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!ws || ws_bytes < sscg_wgrads_workspace(d)) return SSCG_ERR_WORKSPACE;
+    const WgsPlan pl = plan_wgs(d);
+    const size_t nx = (size_t)d->N * d->H * d->W * d->C, ny = (size_t)d->N * d->P * d->Q * d->K;
+    bf16* x3 = reinterpret_cast<bf16*>(ws);
+    bf16* y3 = x3 + 3 * nx;
+    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((wgs_planes_bytes(d) + 255) & ~(size_t)255));
+    // the two operands, split once (sscg_split3's rounding)
+    hipLaunchKernelGGL(split3_kernel, dim3(cdiv((long)((nx + 7) / 8), 256)), dim3(256), 0, st, reinterpret_cast<const float*>(x), x3, nx, nx);
+    hipLaunchKernelGGL(split3_kernel, dim3(cdiv((long)((ny + 7) / 8), 256)), dim3(256), 0, st, reinterpret_cast<const float*>(dy), y3, ny, ny);
+    SSCG_LAUNCH_CHECK();
+    WgsParams p = {};
+    p.x3 = x3; p.dy3 = y3; p.xplane = (long)nx; p.yplane = (long)ny;
+    p.out = pl.splits > 1 ? part : dw;
+    p.Kc = d->K; p.Ng = d->R * d->S * d->C; p.C = d->C;
+    p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.S = d->S;
+    p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.pad_mode = d->pad_mode;
+    p.npix = d->N * d->P * d->Q; p.chunk = pl.chunk;
+    p.tiles_n = cdiv(p.Ng, 128); p.tiles = cdiv(p.Kc, 128) * p.tiles_n; p.splits = pl.splits;
+    p.beta = pl.splits > 1 ? 0.f : beta;
+    p.div_pq = make_fastdiv(d->P * d->Q);
+    p.div_q = make_fastdiv(d->Q);
+    if ((d->wgrad_tuning >> 24) & 1) {
+        hipLaunchKernelGGL(wgrads_kernel<2>, dim3(p.tiles * pl.splits), dim3(256), 2 * WS_STAGE, st, p);
+    } else {
+        const size_t smem = (size_t)3 * WS_STAGE;      // 72 KB
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrads_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(wgrads_kernel<3>, dim3(p.tiles * pl.splits), dim3(256), smem, st, p);
+    }
+    SSCG_LAUNCH_CHECK();
+    if (pl.splits > 1) return sscg_wgrad_reduce(part, dw, (size_t)d->K * p.Ng, pl.splits, beta, st);
+    return SSCG_OK;
+}

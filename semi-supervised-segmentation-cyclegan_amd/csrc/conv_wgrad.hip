@@ -650,6 +650,7 @@ extern "C" size_t sscg_conv2d_wgrad_workspace(const sscg_conv_desc* d) {
     if (thin_wgrad_applies(d) && thin_wgrad_supported_T(d->K < d->C ? d->K : d->C))
         return (size_t)THIN_BLOCKS * d->K * d->C * sizeof(float);
     if (sscg_wgrad16_applies(d)) return sscg_wgrad16_workspace(d);
+    if (sscg_wgrads_applies(d)) return sscg_wgrads_workspace(d);
     WgPlan pl = plan_wgrad(d);
     if (pl.splits <= 1) return 0;
     return (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float);
@@ -668,6 +669,7 @@ extern "C" int sscg_conv2d_wgrad(const sscg_conv_desc* d, const void* x, const v
         return thin_wgrad(d, x, dy, dw, beta, ws, st);
     }
     if (sscg_wgrad16_applies(d)) return sscg_wgrad16(d, x, dy, dw, beta, ws, ws_bytes, st);
+    if (sscg_wgrads_applies(d)) return sscg_wgrads(d, x, dy, dw, beta, ws, ws_bytes, st);
     WgPlan pl = plan_wgrad(d);
     size_t need = pl.splits > 1 ? (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float) : 0;
     if (need > 0 && (!ws || ws_bytes < need)) return SSCG_ERR_WORKSPACE;

@@ -28,6 +28,10 @@ int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const 
 int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
                      void* ws, size_t ws_bytes, hipStream_t st);
 int sscg_krsc_to_crsk_split(const float* w, void* wt, int K, int RS, int C, hipStream_t st);
+// weight gradient by the split contraction on pre-split scratch planes (precision = 2, >= 128 x 128 outputs)
+bool sscg_wgrads_applies(const sscg_conv_desc* d);
+size_t sscg_wgrads_workspace(const sscg_conv_desc* d);
+int sscg_wgrads(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_thin.hip: HBM-streaming kernels for 1x1 convolutions with a handful of channels on one side (PixelDiscriminator ends)
 bool sscg_thin1x1_fwd_applies(const sscg_conv_desc* d);
 int sscg_thin1x1_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, hipStream_t st);

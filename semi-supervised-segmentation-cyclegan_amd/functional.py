@@ -309,7 +309,7 @@ _DESC_CACHE = {}
 
 
 TUNING = [0]        # sscg_conv_desc.tuning of every descriptor built from here on (tools/ and tile-class tests; 0 = the library's plan)
-WGRAD_TUNING = [0]  # sscg_conv_desc.wgrad_tuning, likewise
+WGRAD_TUNING = [int(os.environ.get("SSCG_WGRAD_TUNING", "0"), 0)]  # sscg_conv_desc.wgrad_tuning, likewise (env: A/B aid)
 
 
 def tuning(tile_class=None, split=0, wgrad_class=None, wgrad_splits=0, wgrad_flags=0):

@@ -783,3 +783,41 @@ def test_split_contraction_is_fp32_accurate_at_bench_size(shape, F, dev):
     assert errs["f32s"][2] < 3e-6
     assert errs["f32s"][2] <= 2.2 * errs["f32x"][2] + 5e-8
 
+
+
+_WGRAD_SPLIT_CASES = [
+    # N, H, W, C, K, R, stride, pad, dil  - ragged on purpose: K, C*R*S and the pixel count are no multiples of the 128x128x16 tile
+    (1, 37, 29, 72, 136, 3, 1, 1, 1),
+    (2, 33, 47, 128, 256, 3, 2, 1, 1),
+    (1, 40, 40, 264, 128, 3, 1, 2, 2),
+    (2, 32, 32, 256, 512, 1, 1, 0, 1),
+    (3, 19, 23, 16, 200, 4, 2, 1, 1),
+]
+
+
+@pytest.mark.parametrize("shape", _WGRAD_SPLIT_CASES, ids=lambda s: "%dx%dx%d_c%d_k%d_r%d_s%d_p%d_d%d" % s)
+@pytest.mark.parametrize("variant", ["plan", "fly", "planes", "planes_2stage", "planes_split3", "fly_64x64"])
+def test_split_weight_gradient_variants(shape, variant, F, dev):
+    """Every route of the fp32-accurate weight gradient (precision 2): the library's own plan, the on-the-fly split in
+    conv_wgrad.hip (both tile classes), and wgrads_kernel of conv_split.hip (operands pre-split into bf16 planes; three and two
+    copy stages, forced pixel splits, 1x1 filters) against the fp64 weight gradient of torch - full tensor, ragged tiles."""
+    N, H, W, C, K, R, s, p, d = shape
+    g = torch.Generator(device=dev).manual_seed(sum(shape) + 11)
+    x = torch.randn(N, C, H, W, device=dev, generator=g).contiguous(memory_format=CL)
+    P, Q = F.conv_out_size(H, R, s, p, d), F.conv_out_size(W, R, s, p, d)
+    dy = torch.randn(N, K, P, Q, device=dev, generator=g).contiguous(memory_format=CL)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (K, C, R, R), dy.double(), stride=s, padding=p, dilation=d)
+    kw = {"plan": {}, "fly": dict(wgrad_class=2), "planes": dict(wgrad_class=3), "planes_2stage": dict(wgrad_class=3, wgrad_flags=1),
+          "planes_split3": dict(wgrad_class=3, wgrad_splits=3), "fly_64x64": dict(wgrad_class=1, wgrad_splits=2)}[variant]
+    old = F.tuning(**kw)
+    try:
+        F.set_conv_precision("f32s")
+        dw = F.conv2d_wgrad(x, dy, (K, C, R, R), s, p, d)
+        acc = torch.ones_like(dw)
+        F.conv2d_wgrad(x, dy, (K, C, R, R), s, p, d, out=acc, accumulate=True)
+    finally:
+        F.TUNING[0], F.WGRAD_TUNING[0] = old
+        F.set_conv_precision("f32")
+    err = float((dw.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert err < 1e-6, err
+    assert float((acc.double() - 1 - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6
