@@ -60,7 +60,7 @@ CONFIGS = {
 DTYPE_TEXT = {"f32": "fp32", "f32x": "fp32 tensors, exact fp32 MFMA contractions (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 (bf16 activations + conv weight operands in HBM, fp32 accumulate / master weights / norm statistics / losses)",
               "bf16c": "bf16 conv contractions (fp32 tensors)",
               "f32s": "fp32 tensors, 3-piece split-bf16 contraction, fp32-accurate (six exact bf16 piece products per fp32 product on "
-                      "the bf16 matrix cores, fp32 accumulation; weight gradients, few-channel stems and heads on the exact fp32 MFMA)"}
+                      "the bf16 matrix cores, fp32 accumulation - forward, data and weight gradients; few-channel stems and heads on the exact fp32 MFMA)"}
 
 
 def main():

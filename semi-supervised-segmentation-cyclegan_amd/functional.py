@@ -77,6 +77,29 @@ class _Workspace:
 _WS = _Workspace()
 
 
+_HIPRT = []
+
+
+def _make_stream(device, priority=0):
+    """A HIP stream of the given priority (HIP's scale: -1 high, 0 normal, 1 low).  torch only creates normal / high priority
+    streams; a LOW priority one comes from hipStreamCreateWithPriority and is wrapped (it lives as long as the process)."""
+    if priority <= 0:
+        return torch.cuda.Stream(device=device, priority=priority)
+    import ctypes
+    if not _HIPRT:
+        _HIPRT.append(ctypes.CDLL("libamdhip64.so"))
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = _HIPRT[0].hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority))   # 1 = hipStreamNonBlocking
+    if rc != 0:
+        raise _lib.SscgError("hipStreamCreateWithPriority(%d) failed: %d" % (priority, rc))
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
+SIDE_PRIORITY = int(os.environ.get("SSCG_SIDE_PRIORITY", "1"))
+FORK_PRIORITY = int(os.environ.get("SSCG_FORK_PRIORITY", "0"))
+
+
 class SideStream:
     """A second HIP stream per device for work that is independent of the main stream's critical path:
     weight gradients (needed only by the optimiser step) and the frozen generators' forward (needed only by
@@ -92,7 +115,7 @@ class SideStream:
     def get(cls, device, lane=0):
         s = cls._streams.get((device, lane))
         if s is None:
-            s = torch.cuda.Stream(device=device)
+            s = _make_stream(device, SIDE_PRIORITY)
             cls._streams[(device, lane)] = s
         return s
 
@@ -117,7 +140,7 @@ class ForkStream:
     def get(cls, device, lane=0):
         s = cls._streams.get((device, lane))
         if s is None:
-            s = torch.cuda.Stream(device=device)
+            s = _make_stream(device, FORK_PRIORITY)
             cls._streams[(device, lane)] = s
         return s
 
