@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 9
+#define SSCG_ABI_VERSION 10
 
 /* element types of activation / weight tensors */
 #define SSCG_F32 0
@@ -155,6 +155,21 @@ size_t sscg_norm_bwd_workspace(int G, int64_t L, int C);
 int sscg_norm_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int dtype, int G,
                   int64_t L, int C, int act, float slope, int stats_grad, void* ws, size_t ws_bytes, void* stream);   /* dy, x, y, dx, dres share `dtype` */
+
+/* PixelDiscriminator tail, arch/discriminators.py:72-75: norm_layer(2 ndf) -> nn.LeakyReLU(0.2) -> nn.Conv2d(2 ndf, 1, 1x1) as ONE
+ * pass over the C-channel map x (the conv output the statistics were taken from): out[r] = bias + sum_c w[c] * act(norm(x)[r][c]),
+ * out fp32 [G * L].  The normalised map is never materialised, in either direction: the backward recomputes it from x, forms
+ * dy[r][c] = dout[r] * w[c] in registers, and produces dx (gradient at x, dtype of x), dw[C] / dbias[1] (the head's weight and bias
+ * gradient) and dgamma / dbeta.  flags: bit 0 = the statistics are functions of x (training-mode normalisation), bit 1 = dgamma /
+ * dbeta are written (else accumulated), bit 2 = dw / dbias are written (else accumulated).  C: a power of two in [16, 256]
+ * (sscg_norm_head_applies); act: none / ReLU / LeakyReLU. */
+int sscg_norm_head_applies(int C);
+int sscg_norm_head_fwd(const void* x, int dtype, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const float* w, const float* bias, float* out, int G, int64_t L, int C, int act, float slope, void* stream);
+size_t sscg_norm_head_bwd_workspace(int G, int64_t L, int C);
+int sscg_norm_head_bwd(const float* dout, const float* w, const void* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, void* dx, float* dw, float* dbias, float* dgamma, float* dbeta, int dtype, int G, int64_t L,
+                       int C, int act, float slope, int flags, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ pointwise / pooling / resize */
 /* standalone activation (nn.ReLU / nn.LeakyReLU / nn.Tanh not adjacent to a norm) */

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 F32, BF16, BF16X3 = 0, 1, 2     # SSCG_F32 / SSCG_BF16 / SSCG_BF16X3 (split weight operand)
 
@@ -63,6 +63,10 @@ SIGNATURES = {
     "sscg_rstd_from_var": (_i, [_p, _p, _i, _f, _p]),
     "sscg_norm_bwd_workspace": (_sz, [_i, _i64, _i]),
     "sscg_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
+    "sscg_norm_head_applies": (_i, [_i]),
+    "sscg_norm_head_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _f, _p]),
+    "sscg_norm_head_bwd_workspace": (_sz, [_i, _i64, _i]),
+    "sscg_norm_head_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
     "sscg_act_fwd": (_i, [_p, _p, _i, _i64, _i, _f, _p]),
     "sscg_act_bwd": (_i, [_p, _p, _p, _i, _i64, _i, _f, _p]),
     "sscg_add": (_i, [_p, _p, _p, _i, _i64, _p]),

@@ -265,6 +265,29 @@ def conv_norm_act(conv, norm, x, act=ACT_NONE, slope=0.0, residual=None, reflect
                            per_sample, eps, momentum, act, slope)
 
 
+FUSE_HEAD = [os.environ.get("SSCG_FUSE_HEAD", "1") != "0"]     # A/B aid: PixelDiscriminator's tail as separate norm / conv launches
+
+
+def _is_pixel_head(conv, norm, act, head):
+    """conv -> norm -> ReLU / LeakyReLU -> Conv2d(C, 1, 1x1): PixelDiscriminator from its second conv on
+    (arch/discriminators.py:70-75), served by one fused node when the norm uses batch statistics."""
+    return (FUSE_HEAD[0] and ONE_NODE[0] and F.FUSE_STATS[0] and isinstance(conv, Conv2d) and isinstance(head, Conv2d)
+            and head.out_channels == 1 and head.kernel_size == 1 and head.stride == 1 and head.padding == 0
+            and act.code in (ACT_RELU, ACT_LRELU) and norm.stat_spec() is not None and F.norm_head_applies(conv.out_channels))
+
+
+def conv_norm_act_head(conv, norm, act, head, x, reflect=0):
+    per_sample, eps, rmean, rvar, momentum = norm.stat_spec()
+    x, pad, mode = conv._geometry(x, reflect)
+    if isinstance(norm, BatchNorm2d):
+        norm._pending += _BATCH_GROUPS[0]          # num_batches_tracked, as BatchNorm2d.forward counts it
+        gamma, beta = norm.weight, norm.bias
+    else:
+        gamma = beta = None
+    return F.conv_norm_act_head(x, conv.weight, conv.bias, conv.stride, pad, conv.dilation, mode, gamma, beta, head.weight, head.bias,
+                                rmean, rvar, per_sample, eps, momentum, act.code, act.slope)
+
+
 ONE_NODE = [os.environ.get("SSCG_ONE_NODE", "1") != "0"]       # A/B aid: conv and norm as two autograd nodes
 
 
@@ -289,7 +312,11 @@ class FusedSequential(nn.Sequential):
                 nxt = mods[i + 1] if i + 1 < n else None
                 nx2 = mods[i + 2] if i + 2 < n else None
                 if _is_norm(nxt):
-                    if isinstance(nx2, _Act):
+                    nx3 = mods[i + 3] if i + 3 < n else None
+                    if isinstance(nx2, _Act) and _is_pixel_head(m, nxt, nx2, nx3):
+                        x = conv_norm_act_head(m, nxt, nx2, nx3, x, reflect)
+                        i += 4
+                    elif isinstance(nx2, _Act):
                         x = conv_norm_act(m, nxt, x, nx2.code, nx2.slope, reflect=reflect)
                         i += 3
                     else:

@@ -13,7 +13,7 @@
 
 namespace {
 
-enum { RM_SUM = 0, RM_STATS = 1, RM_BWD = 2 };
+enum { RM_SUM = 0, RM_STATS = 1, RM_BWD = 2, RM_BWD_HEAD = 3 };
 
 struct RedParams {
     const void* __restrict__ x;      // SUM/STATS: input; BWD: x (pre-norm)           (fp32 or bf16: template T)
@@ -24,6 +24,9 @@ struct RedParams {
     const float* __restrict__ gamma; // BWD, y == NULL: the activation mask is recomputed as gamma * xhat + beta > 0
     const float* __restrict__ beta;
     double* __restrict__ part;       // [G][chunks][C][2]
+    const float* __restrict__ head_w;    // BWD_HEAD: dy[r][c] = head_dout[r] * head_w[c] (the 1x1 single-channel conv behind the activation)
+    const float* __restrict__ head_dout; // BWD_HEAD [G * L]
+    double* __restrict__ head_part;      // BWD_HEAD [G][chunks][C][2]: (sum act(y) * dout, sum dout)
     long L;
     int C;
     int chunks;
@@ -71,18 +74,25 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
     const int c = (blockIdx.z * CW + col) * VEC;
     const bool cok = c < p.C;
 
-    double s0[VEC], s1[VEC];
+    constexpr bool BWD = MODE == RM_BWD || MODE == RM_BWD_HEAD;
+    constexpr bool HEAD = MODE == RM_BWD_HEAD;
+    double s0[VEC], s1[VEC], s2[HEAD ? VEC : 1], sd = 0.0;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s0[e] = 0.0; s1[e] = 0.0; }
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s2[e] = 0.0;
+    }
 
-    float mu[VEC], rs[VEC], ga[VEC], be[VEC];
-    const bool remask = MODE == RM_BWD && p.act != SSCG_ACT_NONE && p.y == nullptr;   // no residual joined the forward: y = act(gamma * xhat + beta)
-    if (MODE == RM_BWD && cok) {
+    float mu[VEC], rs[VEC], ga[VEC], be[VEC], hw[VEC];
+    const bool remask = BWD && p.act != SSCG_ACT_NONE && p.y == nullptr;   // no residual joined the forward: y = act(gamma * xhat + beta)
+    if (BWD && cok) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             mu[e] = p.mean[(size_t)g * p.C + c + e]; rs[e] = p.rstd[(size_t)g * p.C + c + e];
-            ga[e] = (remask && p.gamma) ? p.gamma[c + e] : 1.f;
-            be[e] = (remask && p.beta) ? p.beta[c + e] : 0.f;
+            ga[e] = ((remask || HEAD) && p.gamma) ? p.gamma[c + e] : 1.f;
+            be[e] = ((remask || HEAD) && p.beta) ? p.beta[c + e] : 0.f;
+            hw[e] = HEAD ? p.head_w[c + e] : 0.f;
         }
     }
 
@@ -90,9 +100,9 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
         const long r_begin = (long)chunk * p.rows_per_chunk;
         const long r_end = min(p.L, r_begin + p.rows_per_chunk);
         const size_t base = (size_t)g * p.L * p.C + c;
-        const bool has_y = MODE == RM_BWD && p.act != SSCG_ACT_NONE && !remask;  // y may be NULL without an activation / with the recomputed mask
+        const bool has_y = BWD && p.act != SSCG_ACT_NONE && !remask;  // y may be NULL without an activation / with the recomputed mask
         for (long r0 = r_begin + rl; r0 < r_end; r0 += (long)RW * U) {
-            float xv[U][VEC], dv[U][VEC], yv[U][VEC];
+            float xv[U][VEC], dv[U][VEC], yv[U][VEC], dout[U];
             bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -100,7 +110,11 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
                 ok[u] = r < r_end;
                 const size_t o = base + (size_t)(ok[u] ? r : r_begin) * p.C;
                 ldv<T, VEC>(px + o, xv[u]);
-                if (MODE == RM_BWD) {
+                if constexpr (HEAD) {
+                    dout[u] = p.head_dout[(size_t)g * p.L + (ok[u] ? r : r_begin)];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { dv[u][e] = dout[u] * hw[e]; yv[u][e] = 0.f; }
+                } else if (MODE == RM_BWD) {
                     ldv<T, VEC>(pdy + o, dv[u]);
                     if (has_y) ldv<T, VEC>(py + o, yv[u]);
                     else {
@@ -123,12 +137,14 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
                     } else {
                         float xh = (xv[u][e] - mu[e]) * rs[e];
                         float ym = yv[u][e];
-                        if (remask) ym = xh * ga[e] + be[e];      // the forward's own expression (norm_apply_kernel): same sign
+                        if (remask || HEAD) ym = xh * ga[e] + be[e];      // the forward's own expression (norm_apply_kernel): same sign
                         float gg = act_grad(dv[u][e], ym, p.act, p.slope);
                         s0[e] += (double)gg;
                         s1[e] += (double)gg * (double)xh;
+                        if constexpr (HEAD) s2[e] += (double)sscg_act(ym, p.act, p.slope) * (double)dout[u];
                     }
                 }
+                if constexpr (HEAD) sd += (double)dout[u];
             }
         }
     }
@@ -147,6 +163,27 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(RedParams p, int CW) {
                 size_t o = (((size_t)g * p.chunks + chunk) * p.C + c + e) * 2;
                 p.part[o] = a;
                 p.part[o + 1] = b;
+            }
+        }
+    }
+    if constexpr (HEAD) {       // second round through the same LDS: the head's weight-gradient sums
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { sm[(tid * VEC + e) * 2] = s2[e]; sm[(tid * VEC + e) * 2 + 1] = sd; }
+        __syncthreads();
+        if (rl == 0 && cok) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                double a = 0.0, b = 0.0;
+                for (int r = 0; r < RW; ++r) {
+                    a += sm[((r * CW + col) * VEC + e) * 2];
+                    b += sm[((r * CW + col) * VEC + e) * 2 + 1];
+                }
+                if (c + e < p.C) {
+                    size_t o = (((size_t)g * p.chunks + chunk) * p.C + c + e) * 2;
+                    p.head_part[o] = a;
+                    p.head_part[o + 1] = b;
+                }
             }
         }
     }
@@ -232,6 +269,20 @@ __global__ __launch_bounds__(256) void finalize_sum_kernel(const double* __restr
     double s, unused;
     chunk_sum16(part, 0, chunks, C, c, cok, sm, s, unused);
     if ((threadIdx.x & 63) == 0 && cok) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
+}
+
+// head (norm -> act -> 1x1 conv to one channel): dw[c] = sum over groups and chunks of act(y) * dout; dbias = sum dout
+__global__ __launch_bounds__(256) void finalize_head_kernel(const double* __restrict__ part, float* __restrict__ dw,
+                                                             float* __restrict__ dbias, int C, int chunks_total, float beta) {
+    __shared__ double sm[512];
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
+    const bool cok = c < C;
+    double s, sd;
+    chunk_sum16(part, 0, chunks_total, C, c, cok, sm, s, sd);
+    if ((threadIdx.x & 63) == 0 && cok) {
+        if (dw) dw[c] = (beta != 0.f ? beta * dw[c] : 0.f) + (float)s;
+        if (c == 0 && dbias) dbias[0] = (beta != 0.f ? beta * dbias[0] : 0.f) + (float)sd;
+    }
 }
 
 __global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __restrict__ part, float* __restrict__ mean,
@@ -348,6 +399,8 @@ struct BwdApplyParams {
     const float* __restrict__ gamma;
     const float* __restrict__ beta;  // y == NULL with an activation: mask recomputed as gamma * xhat + beta > 0
     const float* __restrict__ coef;  // [G][C][2] or null when stats are constants
+    const float* __restrict__ head_w;    // non-null: dy[r][c] = head_dout[r] * head_w[c] (never read from memory)
+    const float* __restrict__ head_dout;
     void* __restrict__ dx;
     void* __restrict__ dres;
     long L;
@@ -374,7 +427,15 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdApplyParams p) {
         const size_t o = (size_t)i * VEC;
         const bool remask = p.act != SSCG_ACT_NONE && py == nullptr;
         float dv[VEC], xv[VEC], yv[VEC];
-        ldv<T, VEC>(pdy + o, dv);
+        if (p.head_w) {
+            float hw[VEC];
+            ldv<float, VEC>(p.head_w + c, hw);
+            const float d = p.head_dout[row];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dv[e] = d * hw[e];
+        } else {
+            ldv<T, VEC>(pdy + o, dv);
+        }
         ldv<T, VEC>(px + o, xv);
         if (p.act != SSCG_ACT_NONE && !remask) ldv<T, VEC>(py + o, yv);
         float gx[VEC], gr[VEC];
@@ -410,6 +471,67 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdApplyParams p) {
         }
         stv<T, VEC>(pdx + o, gx);
         if (p.dres) stv<T, VEC>(pdres + o, gr);
+    }
+}
+
+// ---- PixelDiscriminator tail (arch/discriminators.py:72-75): norm -> LeakyReLU -> Conv2d(C, 1, 1x1) in one pass over the C-channel
+// map: out[r] = bias + sum_c w[c] * act(gamma * xhat + beta).  A row's C / 4 lanes (a power of two <= 64) hold four channels each
+// and are combined by a butterfly; the normalised map is never written (the backward recomputes it from x).
+struct HeadParams {
+    const void* __restrict__ x;
+    const float* __restrict__ mean;
+    const float* __restrict__ rstd;
+    const float* __restrict__ gamma;
+    const float* __restrict__ beta;
+    const float* __restrict__ w;
+    const float* __restrict__ bias;
+    float* __restrict__ out;
+    long L;
+    long rows;       // G * L
+    int C;
+    int act;
+    float slope;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_head_fwd_kernel(HeadParams p) {
+    const int lanes = p.C >> 2;                    // lanes per row
+    const int rows_per_wave = 64 / lanes;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / lanes;
+    const int c = (lane - sub * lanes) * 4;
+    const T* px = reinterpret_cast<const T*>(p.x);
+    float w[4], ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+    ld4<float>(p.w + c, w);
+    if (p.gamma) { ld4<float>(p.gamma + c, ga); ld4<float>(p.beta + c, be); }
+    const float b0 = p.bias ? p.bias[0] : 0.f;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    constexpr int U = 4;                           // rows in flight per lane
+    for (long r0 = wave * rows_per_wave * U; r0 < p.rows; r0 += nwaves * rows_per_wave * U) {
+        float xv[U][4], mu[U][4], rs[U][4];
+        long r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            r[u] = r0 + (long)u * rows_per_wave + sub;
+            const long rr = r[u] < p.rows ? r[u] : p.rows - 1;
+            const long g = rr / p.L;
+            ld4<T>(px + (size_t)rr * p.C + c, xv[u]);
+            ld4<float>(p.mean + (size_t)g * p.C + c, mu[u]);
+            ld4<float>(p.rstd + (size_t)g * p.C + c, rs[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = (xv[u][e] - mu[u][e]) * rs[u][e];
+                if (p.gamma) v = v * ga[e] + be[e];
+                acc += w[e] * sscg_act(v, p.act, p.slope);
+            }
+            for (int m = 1; m < lanes; m <<= 1) acc += __shfl_xor(acc, m, 64);
+            if (c == 0 && r[u] < p.rows) p.out[r[u]] = acc + b0;
+        }
     }
 }
 
@@ -646,6 +768,79 @@ extern "C" int sscg_norm_bwd(const void* dy, const void* x, const void* y, const
     q.dy = dy; q.x = x; q.y = y; q.mean = mean; q.rstd = rstd; q.gamma = gamma; q.beta = beta;
     q.coef = stats_grad ? coef : nullptr;
     q.dx = dx; q.dres = dres; q.L = L; q.C = C; q.act = act; q.slope = slope;
+    const int vec = vec_for(C, dtype);
+    if ((size_t)G * L * C / vec >= ((size_t)1 << 31)) return SSCG_ERR_UNSUPPORTED;
+    q.total = (uint32_t)((size_t)G * L * C / vec);
+    q.div_cg = make_fastdiv(C / vec);
+    q.div_l = make_fastdiv((int)L);
+    if (dtype == SSCG_BF16) launch_bwd_apply<__bf16>(q, vec, st);
+    else launch_bwd_apply<float>(q, vec, st);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+// ---- PixelDiscriminator tail: norm -> activation -> 1x1 conv to ONE channel (arch/discriminators.py:72-75)
+static bool head_ok(int C) { return C >= 16 && C <= 256 && (C & (C - 1)) == 0; }
+
+extern "C" int sscg_norm_head_applies(int C) { return head_ok(C) ? 1 : 0; }
+
+extern "C" int sscg_norm_head_fwd(const void* x, int dtype, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const float* w, const float* bias, float* out, int G, int64_t L, int C, int act, float slope,
+                                  void* stream) {
+    if (!x || !mean || !rstd || !w || !out || G <= 0 || L <= 0 || (dtype != SSCG_F32 && dtype != SSCG_BF16)) return SSCG_ERR_BAD_ARG;
+    if ((gamma != nullptr) != (beta != nullptr)) return SSCG_ERR_BAD_ARG;
+    if (!head_ok(C)) return SSCG_ERR_UNSUPPORTED;
+    HeadParams p = {};
+    p.x = x; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.w = w; p.bias = bias; p.out = out;
+    p.L = L; p.rows = (long)G * L; p.C = C; p.act = act; p.slope = slope;
+    const long rows_per_block = 4L * (256 / C) * 4;       // 4 waves x rows per wave x rows in flight
+    long blocks = cdiv(p.rows, rows_per_block);
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SSCG_BF16) hipLaunchKernelGGL(norm_head_fwd_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(norm_head_fwd_kernel<float>, dim3((int)blocks), dim3(256), 0, st, p);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" size_t sscg_norm_head_bwd_workspace(int G, int64_t L, int C) {
+    return 2 * part_bytes(G, L, C) + (size_t)G * C * 2 * sizeof(float);
+}
+
+// flags: bit 0 = the statistics are functions of x (training-mode norm), bit 1 = dgamma / dbeta written (else accumulated),
+// bit 2 = dw / dbias written (else accumulated)
+extern "C" int sscg_norm_head_bwd(const float* dout, const float* w, const void* x, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, void* dx, float* dw, float* dbias, float* dgamma,
+                                  float* dbeta, int dtype, int G, int64_t L, int C, int act, float slope, int flags, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    if (!dout || !w || !x || !mean || !rstd || !dx || G <= 0 || L <= 0 || (dtype != SSCG_F32 && dtype != SSCG_BF16)) return SSCG_ERR_BAD_ARG;
+    if (act == SSCG_ACT_TANH) return SSCG_ERR_UNSUPPORTED;      // the mask / value is recomputed from x
+    if (!head_ok(C)) return SSCG_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < sscg_norm_head_bwd_workspace(G, L, C)) return SSCG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int stats_grad = flags & 1, overwrite = (flags >> 1) & 1, overwrite_w = (flags >> 2) & 1;
+    RedParams p = {};
+    p.x = x; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta;
+    p.part = reinterpret_cast<double*>(ws); p.L = L; p.C = C; p.act = act; p.slope = slope;
+    p.head_w = w; p.head_dout = dout;
+    p.head_part = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + part_bytes(G, L, C));
+    int rc = launch_reduce<RM_BWD_HEAD>(p, G, dtype, st);
+    if (rc) return rc;
+    RedPlan pl = plan_reduce(G, L, C, dtype);
+    float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 2 * part_bytes(G, L, C));
+    hipLaunchKernelGGL(finalize_bwd_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, st, p.part, coef, dgamma, dbeta, G, C, pl.chunks,
+                       (long)L, overwrite);
+    SSCG_LAUNCH_CHECK();
+    if (dw || dbias) {
+        hipLaunchKernelGGL(finalize_head_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, st, p.head_part, dw, dbias, C, G * pl.chunks,
+                           overwrite_w ? 0.f : 1.f);
+        SSCG_LAUNCH_CHECK();
+    }
+    BwdApplyParams q = {};
+    q.x = x; q.mean = mean; q.rstd = rstd; q.gamma = gamma; q.beta = beta;
+    q.coef = stats_grad ? coef : nullptr;
+    q.head_w = w; q.head_dout = dout;
+    q.dx = dx; q.L = L; q.C = C; q.act = act; q.slope = slope;
     const int vec = vec_for(C, dtype);
     if ((size_t)G * L * C / vec >= ((size_t)1 << 31)) return SSCG_ERR_UNSUPPORTED;
     q.total = (uint32_t)((size_t)G * L * C / vec);

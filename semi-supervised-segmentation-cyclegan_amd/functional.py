@@ -669,6 +669,33 @@ def norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad=Tru
     return dx, dres
 
 
+def norm_head_applies(c):
+    """Does the one-pass norm -> activation -> 1x1 single-channel conv (PixelDiscriminator's tail) serve a C-channel map?"""
+    return bool(lib.sscg_norm_head_applies(int(c)))
+
+
+def norm_head_fwd(x, mean, rstd, gamma, beta, w, bias, per_sample, act, slope):
+    """out[N,1,H,W] (fp32) = bias + sum_c w[c] * act(norm(x)) - one pass over x, the normalised map is never written."""
+    g, l, c = _glc(x, per_sample)
+    n, _, h, wd = x.shape
+    out = torch.empty((n, 1, h, wd), dtype=torch.float32, device=x.device)
+    check(lib.sscg_norm_head_fwd(x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta), w.data_ptr(),
+                                 _ptr(bias), out.data_ptr(), g, l, c, act, slope, _stream()), "sscg_norm_head_fwd")
+    return out
+
+
+def norm_head_bwd(dout, w, x, mean, rstd, gamma, beta, per_sample, act, slope, stats_grad, dwb, dgamma=None, dbeta=None):
+    """Backward of norm_head_fwd: the gradient at x; dwb[:C] / dwb[C] (written) = the head's weight / bias gradient."""
+    g, l, c = _glc(x, per_sample)
+    dx = torch.empty_like(x, memory_format=CL)
+    nb = _cached_size(lib.sscg_norm_head_bwd_workspace, g, l, c)
+    ws = _WS.get(nb, x.device)
+    check(lib.sscg_norm_head_bwd(dout.data_ptr(), w.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta),
+                                 dx.data_ptr(), dwb.data_ptr(), dwb.data_ptr() + 4 * c, _ptr(dgamma), _ptr(dbeta), _dt(x), g, l, c, act,
+                                 slope, (1 if stats_grad else 0) | 2 | 4, ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_head_bwd")
+    return dx
+
+
 def rstd_from_var(var, eps):
     out = torch.empty_like(var)
     check(lib.sscg_rstd_from_var(var.data_ptr(), out.data_ptr(), var.numel(), eps, _stream()), "sscg_rstd_from_var")
@@ -1260,6 +1287,91 @@ class ConvNormActFn(torch.autograd.Function):
         dx, dw, db = _conv_backward(dy, x, w, ctx.wref, ctx.bref if ctx.has_bias else None, (stride, pad, dil, pad_mode),
                                     ni[0], ni[1], ctx.has_bias and ni[2])
         return dx, dw, db, ret_g, ret_b, dres, None, None, None
+
+
+class ConvNormActHeadFn(torch.autograd.Function):
+    """PixelDiscriminator from its second conv on (arch/discriminators.py:70-75): Conv2d(ndf, 2 ndf, 1x1) -> norm (batch statistics
+    from the conv's epilogue) -> LeakyReLU -> Conv2d(2 ndf, 1, 1x1), ONE autograd node.  The 2 ndf-channel map is written once (by
+    the conv) and read once per direction of the tail: the head's output is formed while normalising (sscg_norm_head_fwd), and the
+    backward rebuilds dy = dout * w3 and the activation from x in registers (sscg_norm_head_bwd) - the normalised map, the head's
+    input gradient and the head's weight-gradient pass over it never exist in HBM.
+    cfg = (stride, pad, dil, pad_mode, per_sample, eps, momentum, act, slope)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, hw, hbias, running_mean, running_var, cfg):
+        stride, pad, dil, pad_mode, per_sample, eps, momentum, act, slope = cfg
+        x = to_nhwc(x)
+        n, _, h, wd = x.shape
+        p, q = conv_out_size(h, w.shape[2], stride, pad, dil), conv_out_size(wd, w.shape[3], stride, pad, dil)
+        g, l, c = _glc_shape((n, w.shape[0], p, q), per_sample)
+        y, cs = conv2d_fwd(x, w, bias, stride, pad, dil, pad_mode, ACT_NONE, 0.0, False, stats=(g, l))
+        if cs is not None:
+            mean, rstd = norm_stats_from_conv(cs, (g, l, c), eps, running_mean, running_var, momentum)
+        else:
+            upd = running_mean is not None and per_sample is not True
+            mean, rstd = norm_stats(y, per_sample, eps, running_mean if upd else None, running_var if upd else None, momentum)
+        hw32 = hw.detach().reshape(-1)
+        if hw32.dtype != torch.float32:
+            hw32 = hw32.float()
+        out = norm_head_fwd(y, mean, rstd, gamma, beta, hw32, hbias, per_sample, act, slope)
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.has_hbias = hbias is not None
+        ctx.wref, ctx.bref, ctx.gref, ctx.betaref, ctx.hwref, ctx.hbref = w, bias, gamma, beta, hw, hbias
+        ctx.save_for_backward(x, w, y, mean, rstd, gamma, beta, hw32)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, y, mean, rstd, gamma, beta, hw32 = ctx.saved_tensors
+        stride, pad, dil, pad_mode, per_sample, eps, momentum, act, slope = ctx.cfg
+        ni = ctx.needs_input_grad
+        dout = dout.contiguous()
+        if dout.dtype != torch.float32:
+            dout = dout.float()
+        c = hw32.numel()
+        want_g = gamma is not None and ni[3]
+        dgb = torch.empty((2, c), dtype=torch.float32, device=y.device) if want_g else None
+        dwb = torch.empty(c + 1, dtype=torch.float32, device=y.device)
+        dy = norm_head_bwd(dout, hw32, y, mean, rstd, gamma, beta, per_sample, act, slope, True, dwb,
+                           dgb[0] if want_g else None, dgb[1] if want_g else None)
+        # head weight / bias, norm weight / bias: sums produced beside dy on this stream; their accumulation into the optimiser's
+        # arena runs on each parameter's own side lane (as _norm_backward)
+        ret_hw = ret_hb = ret_g = ret_b = None
+        want_hw, want_hb = ni[5], ctx.has_hbias and ni[6]
+        hwacc = _acc_target(ctx.hwref) if want_hw else None
+        hbacc = _acc_target(ctx.hbref) if want_hb else None
+        if want_hw and hwacc is None:
+            ret_hw = dwb[:c].reshape(ctx.hwref.shape).to(ctx.hwref.dtype)
+        if want_hb and hbacc is None:
+            ret_hb = dwb[c:c + 1].clone()
+        gacc = _acc_target(ctx.gref) if want_g else None
+        bacc = _acc_target(ctx.betaref) if want_g else None
+        if want_g and (gacc is None or bacc is None):
+            gacc = bacc = None
+            ret_g, ret_b = dgb[0], dgb[1]
+
+        def arena_add(acc, src_ptr, count, ref, keep):      # every gradient of a parameter is accumulated on that parameter's lane
+            def go():
+                check(lib.sscg_add(acc.data_ptr(), src_ptr, acc.data_ptr(), F32, count, _stream()), "sscg_add")
+            run_on_side_stream(y.device, (keep,), go, lane=getattr(ref, "_sscg_lane", 0), defer=True)
+        if hwacc is not None:
+            arena_add(hwacc, dwb.data_ptr(), c, ctx.hwref, dwb)
+        if hbacc is not None:
+            arena_add(hbacc, dwb.data_ptr() + 4 * c, 1, ctx.hbref, dwb)
+        if gacc is not None:
+            arena_add(gacc, dgb.data_ptr(), c, ctx.gref, dgb)
+            arena_add(bacc, dgb.data_ptr() + 4 * c, c, ctx.betaref, dgb)
+        dx, dw, db = _conv_backward(dy, x, w, ctx.wref, ctx.bref if ctx.has_bias else None, (stride, pad, dil, pad_mode),
+                                    ni[0], ni[1], ctx.has_bias and ni[2])
+        return dx, dw, db, ret_g, ret_b, ret_hw, ret_hb, None, None, None
+
+
+def conv_norm_act_head(x, w, bias, stride, pad, dil, pad_mode, gamma, beta, hw, hbias, running_mean, running_var, per_sample, eps,
+                       momentum, act, slope):
+    """conv -> norm (batch statistics) -> activation -> 1x1 conv to one channel, as one node (PixelDiscriminator's tail)."""
+    return ConvNormActHeadFn.apply(x, w, bias, gamma, beta, hw, hbias, running_mean, running_var,
+                                   (stride, pad, dil, pad_mode, per_sample, eps, momentum, act, slope))
 
 
 class ActFn(torch.autograd.Function):

@@ -821,3 +821,84 @@ def test_split_weight_gradient_variants(shape, variant, F, dev):
     err = float((dw.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     assert err < 1e-6, err
     assert float((acc.double() - 1 - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6
+
+
+def _torch_pixel_discriminator(net, norm, double=True):
+    """The reference's PixelDiscriminator (arch/discriminators.py:66-80) as stock torch modules holding `net`'s weights."""
+    from torch import nn
+    convs = [m for m in net.dis_model if hasattr(m, "kernel_size")]
+    c1, c2, c3 = convs
+    nl = nn.BatchNorm2d(c2.out_channels) if norm == "batch" else nn.InstanceNorm2d(c2.out_channels)
+    ref = nn.Sequential(nn.Conv2d(c1.in_channels, c1.out_channels, 1), nn.LeakyReLU(0.2), nn.Conv2d(c2.in_channels, c2.out_channels, 1, bias=c2.bias is not None),
+                        nl, nn.LeakyReLU(0.2), nn.Conv2d(c3.in_channels, 1, 1, bias=c3.bias is not None))
+    with torch.no_grad():
+        for r, m in zip((ref[0], ref[2], ref[5]), convs):
+            r.weight.copy_(m.weight.detach().cpu())
+            if m.bias is not None:
+                r.bias.copy_(m.bias.detach().cpu())
+        if norm == "batch":
+            ours = [m for m in net.dis_model if getattr(m, "running_mean", None) is not None][0]
+            nl.weight.copy_(ours.weight.detach().cpu())
+            nl.bias.copy_(ours.bias.detach().cpu())
+    return ref.double() if double else ref
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+@pytest.mark.parametrize("geom", [(3, 3, 64, 37, 29), (2, 21, 64, 64, 48), (2, 3, 32, 40, 40), (1, 4, 8, 33, 17)],
+                         ids=lambda g: "n%d_c%d_ndf%d_%dx%d" % g)
+def test_fused_pixel_discriminator_tail(geom, norm, F, dev):
+    """PixelDiscriminator with its tail (norm -> LeakyReLU -> Conv2d(2 ndf, 1, 1x1)) formed in one pass over the 2 ndf-channel map
+    (ConvNormActHeadFn: sscg_norm_head_fwd / sscg_norm_head_bwd) against the reference's module in fp64: output, input gradient,
+    every parameter gradient; and against the unfused launch sequence of the same library (SSCG_FUSE_HEAD=0 path).  ndf = 8 (16
+    channels) is the smallest width the fused pass serves."""
+    ops = load_sub("arch.ops")
+    disc = load_sub("arch.discriminators")
+    N, Cin, ndf, H, W = geom
+    torch.manual_seed(sum(geom))
+    nl = ops.get_norm_layer(norm)
+    net = disc.PixelDiscriminator(Cin, ndf, norm_layer=nl, use_bias=(norm == "instance")).to(dev)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn(p.shape) * (0.5 if p.dim() == 1 else 1.0 / p.shape[1] ** 0.5))
+    ref = _torch_pixel_discriminator(net, norm)
+    x0 = torch.randn(N, Cin, H, W)
+    g0 = torch.randn(N, 1, H, W)
+    xr = x0.double().requires_grad_(True)
+    yr = ref(xr)
+    (yr * g0.double()).sum().backward()
+    want = [yr, xr.grad] + [p.grad for p in ref.parameters() if p.grad is not None]
+    got = {}
+    for fused in (True, False):
+        ops.FUSE_HEAD[0] = fused
+        try:
+            for p in net.parameters():
+                p.grad = None
+            x = gpu(x0, dev).requires_grad_(True)
+            y = net(x)
+            F.backward((y * gpu(g0, dev)).sum())
+            F.SideStream.join(dev)
+            torch.cuda.synchronize()
+            convs = [m for m in net.dis_model if hasattr(m, "kernel_size")]
+            norms = [m for m in net.dis_model if isinstance(m, ops.BatchNorm2d)]
+            grads = []
+            for m in convs:
+                grads.append(m.weight.grad)
+                if m.bias is not None:
+                    grads.append(m.bias.grad)
+            got[fused] = [y.detach(), x.grad] + grads + ([norms[0].weight.grad, norms[0].bias.grad] if norms else [])
+        finally:
+            ops.FUSE_HEAD[0] = True
+    # the reference's parameter order: conv1 (w, b), conv2 (w[, b]), norm (w, b) for batch, conv3 (w[, b])
+    names = ["y", "dx", "w1", "b1", "w2"] + (["b2"] if norm == "instance" else []) + (["gamma", "beta"] if norm == "batch" else []) + ["w3"] + (["b3"] if norm == "instance" else [])
+    refs = dict(zip(names, want))
+    ours_names = ["y", "dx", "w1", "b1", "w2"] + (["b2"] if norm == "instance" else []) + ["w3"] + (["b3"] if norm == "instance" else []) + (["gamma", "beta"] if norm == "batch" else [])
+    for fused in (True, False):
+        vals = dict(zip(ours_names, got[fused]))
+        for k in names:
+            if k == "b2":
+                continue        # a bias in front of InstanceNorm has zero gradient: nothing to compare against but roundoff
+            e = rel_err(vals[k].reshape(refs[k].shape), refs[k])
+            assert e < 3e-5, (fused, k, e)
+    a, b = dict(zip(ours_names, got[True])), dict(zip(ours_names, got[False]))
+    for k in ("y", "dx", "w2", "w3"):
+        assert rel_err(a[k], b[k]) < 1e-5, k
