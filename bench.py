@@ -109,6 +109,33 @@ def main():
     torch.manual_seed(0)
     F.set_conv_precision(dtype)
     arith = F.get_conv_precision()          # "f32" names fp32 TENSORS; this is the contraction it resolves to ("f32" exact / "f32s" split)
+    # The reference's own default is batch 2 (main.py:14) on small crops: there the step is bound by the host's issue rate, not by
+    # the GPU.  One line beside the headline, single rank only (a second, small model: 64x64, batch 2, same dtype), taken BEFORE the
+    # configuration's own model exists - what a `main.py --batch_size 2` process sees (the registries of weight copies and the
+    # allocator's pools of a large model in the same process cost this case 10-20 ms per step).
+    host_bound_case = None
+    if world == 1 and not a.no_small:
+        sargs = cli.get_args(["--model", "semisupervised_cycleGAN", "--dataset", cfg["dataset"], "--crop_height", "64", "--crop_width", "64",
+                              "--batch_size", "2", "--checkpoint_dir", "/tmp/sscg_bench_ckpt_small", "--dtype", dtype])
+        sargs.gpu_ids, sargs.as_written, sargs.overlap_d = [local], True, args.overlap_d
+        with contextlib.redirect_stdout(io.StringIO()):
+            small = md.semisuper_cycleGAN(sargs)
+        sl = list(data.SyntheticLoader(2, C, 64, 64, 14, 3, device=dev))
+        su = list(data.SyntheticLoader(2, C, 64, 64, 14, 4, device=dev))
+        for i in range(4):
+            small.step(sl[i][0], sl[i][1], su[i][0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(4, 14):
+            small.step(sl[i][0], sl[i][1], su[i][0])
+        th = (time.perf_counter() - t0) / 10
+        torch.cuda.synchronize()
+        ts = (time.perf_counter() - t0) / 10
+        host_bound_case = {"workload": "the same step at 64x64, batch 2 (main.py:14 default batch)", "ms_per_step": round(1e3 * ts, 2),
+                                  "host_issue_ms_per_step": round(1e3 * th, 2), "value": round(2 / ts, 2), "unit": "img/s"}
+        del small, sl, su
+        torch.cuda.empty_cache()
+
     with contextlib.redirect_stdout(io.StringIO()):
         model = md.semisuper_cycleGAN(args, data_parallel=dp)
 
@@ -156,6 +183,8 @@ def main():
         "mfma_peak_tflops": peak,
         "host_issue_ms_per_step": round(1e3 * host[0], 2),
     }
+    if host_bound_case is not None:
+        out["host_bound_case"] = host_bound_case
 
     # secondary figure (BASELINE.md section 2 / SURVEY 8(d)): the same step without the forwards whose outputs the
     # reference never uses (old_Gsi(l_img) -> old_Gis, model.py:419-420,423) and without old_Di's never-applied wgrad
@@ -188,29 +217,6 @@ def main():
         out["f32_exact" if other == "f32x" else "f32_split"] = {
             "value": round(world * bsz * a.steps / dts, 4), "unit": "img/s", "ms_per_step": round(1e3 * dts / a.steps, 3),
             "losses_finite": all(bool(torch.isfinite(v)) for v in ls.values()), "note": "not the headline: " + DTYPE_TEXT[other]}
-
-    # The reference's own default is batch 2 (main.py:14) on small crops: there the step is bound by the host's issue rate, not by
-    # the GPU.  One line beside the headline, single rank only (a second, small model: 64x64, batch 2, same dtype).
-    if world == 1 and not a.no_small:
-        sargs = cli.get_args(["--model", "semisupervised_cycleGAN", "--dataset", cfg["dataset"], "--crop_height", "64", "--crop_width", "64",
-                              "--batch_size", "2", "--checkpoint_dir", "/tmp/sscg_bench_ckpt_small", "--dtype", dtype])
-        sargs.gpu_ids, sargs.as_written, sargs.overlap_d = [local], True, args.overlap_d
-        with contextlib.redirect_stdout(io.StringIO()):
-            small = md.semisuper_cycleGAN(sargs)
-        sl = list(data.SyntheticLoader(2, C, 64, 64, 14, 3, device=dev))
-        su = list(data.SyntheticLoader(2, C, 64, 64, 14, 4, device=dev))
-        for i in range(4):
-            small.step(sl[i][0], sl[i][1], su[i][0])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(4, 14):
-            small.step(sl[i][0], sl[i][1], su[i][0])
-        th = (time.perf_counter() - t0) / 10
-        torch.cuda.synchronize()
-        ts = (time.perf_counter() - t0) / 10
-        out["host_bound_case"] = {"workload": "the same step at 64x64, batch 2 (main.py:14 default batch)", "ms_per_step": round(1e3 * ts, 2),
-                                  "host_issue_ms_per_step": round(1e3 * th, 2), "value": round(2 / ts, 2), "unit": "img/s"}
-        del small, sl, su
 
     if not a.no_roofline:
         # per-kernel timing needs the kernels one at a time: the side stream (concurrent weight gradients /

@@ -96,8 +96,34 @@ def _make_stream(device, priority=0):
     return torch.cuda.ExternalStream(h.value, device=device)
 
 
-SIDE_PRIORITY = int(os.environ.get("SSCG_SIDE_PRIORITY", "1"))
 FORK_PRIORITY = int(os.environ.get("SSCG_FORK_PRIORITY", "0"))
+
+
+def side_priority():
+    """Priority of the side lanes (weight gradients, frozen generators, D step): LOW on a single GPU - the dispatcher then prefers
+    the critical path's workgroups whenever both are ready (-1.3 ms per config-2 step, same-box A/B) - but NORMAL once a process
+    group is up: with RCCL's stream in flight the low-priority lanes cost +30 % (176-190 vs 145 ms, `SSCG_FORCE_DP=1`, measured)."""
+    env = os.environ.get("SSCG_SIDE_PRIORITY")
+    if env is not None:
+        return int(env)
+    import torch.distributed as dist
+    return 0 if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def side_priority_for(pixels_per_batch):
+    """... and only where the lanes compete for CUs: below ~128 K pixels per batch the kernels do not fill the chip, a low-priority
+    lane is merely late at the next join (64x64, batch 2: 48-51 -> 55-61 ms per step)."""
+    p = side_priority()
+    return p if (p <= 0 or os.environ.get("SSCG_SIDE_PRIORITY") is not None or pixels_per_batch >= 131072) else 0
+
+
+def reset_side_streams():
+    """Drop the cached side lanes (they are re-created, with the priority that holds now, on their next use)."""
+    if SideStream._streams:
+        flush_side_work()
+        torch.cuda.synchronize()
+        SideStream._streams.clear()
+        _STREAM_BY_HANDLE.clear()
 
 
 class SideStream:
@@ -111,19 +137,22 @@ class SideStream:
 
     lanes = int(os.environ.get("SSCG_SIDE_LANES", "2"))   # measured: 4 streams in flight (main, fork lane, 2 side lanes) is the sweet spot; a 5th costs 20 %
 
+    priority = None     # None = side_priority(); a model sets its own at the top of every step (model.semisuper_cycleGAN.step)
+
     @classmethod
     def get(cls, device, lane=0):
-        s = cls._streams.get((device, lane))
+        prio = cls.priority if cls.priority is not None else side_priority()
+        s = cls._streams.get((device, lane, prio))
         if s is None:
-            s = _make_stream(device, SIDE_PRIORITY)
-            cls._streams[(device, lane)] = s
+            s = _make_stream(device, prio)
+            cls._streams[(device, lane, prio)] = s
         return s
 
     @classmethod
     def join(cls, device=None):
         """Make the current stream wait for everything queued on the side stream(s) (deferred work is launched first)."""
         flush_side_work(device)
-        for (dev, _), s in cls._streams.items():
+        for (dev, _, _), s in cls._streams.items():
             if device is None or dev == device:
                 torch.cuda.current_stream(dev).wait_stream(s)
 
@@ -199,8 +228,8 @@ def _stream_object(device, handle):
             so = cur
         else:       # a producer stream that is not current any more: every stream this package creates is in the two registries
             for reg in (SideStream._streams, ForkStream._streams):
-                for (dev, _), st in reg.items():
-                    if dev == device and st.cuda_stream == handle:
+                for key, st in reg.items():
+                    if key[0] == device and st.cuda_stream == handle:
                         so = st
             if so is None:
                 so = torch.cuda.ExternalStream(handle, device=device)

@@ -31,6 +31,10 @@ class DataParallel:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+        if torch.cuda.is_available():
+            # side lanes made before the group existed are low-priority streams: beside RCCL's stream those cost +30 % (functional.side_priority)
+            from . import functional as F
+            F.reset_side_streams()
 
     def attach(self, g_opt, d_opt, nets):
         """Make every rank start from rank 0's weights and tell the optimisers the world size."""
