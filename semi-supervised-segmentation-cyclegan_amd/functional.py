@@ -83,9 +83,9 @@ _HIPRT = []
 def _make_stream(device, priority=0):
     """A HIP stream of the given priority (HIP's scale: -1 high, 0 normal, 1 low).  torch only creates normal / high priority
     streams; a LOW priority one comes from hipStreamCreateWithPriority and is wrapped (it lives as long as the process)."""
+    import ctypes
     if priority <= 0:
         return torch.cuda.Stream(device=device, priority=priority)
-    import ctypes
     if not _HIPRT:
         _HIPRT.append(ctypes.CDLL("libamdhip64.so"))
     h = ctypes.c_void_p()
@@ -360,7 +360,7 @@ def conv_out_size(h, k, stride, pad, dil):
 _DESC_CACHE = {}
 
 
-TUNING = [0]        # sscg_conv_desc.tuning of every descriptor built from here on (tools/ and tile-class tests; 0 = the library's plan)
+TUNING = [int(os.environ.get("SSCG_TUNING", "0"), 0)]        # sscg_conv_desc.tuning of every descriptor built from here on (tools/ and tile-class tests; 0 = the library's plan)
 WGRAD_TUNING = [int(os.environ.get("SSCG_WGRAD_TUNING", "0"), 0)]  # sscg_conv_desc.wgrad_tuning, likewise (env: A/B aid)
 
 
