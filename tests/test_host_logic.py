@@ -257,3 +257,32 @@ def test_bench_spawns_its_own_ranks_when_no_launcher_is_present(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     if torch.cuda.device_count() < 4:
         assert seen["env"]["SSCG_DP_SHARED_GPU"] == "1" and seen["env"]["SSCG_DP_BACKEND"] == "gloo"
+
+
+def test_pixel_discriminator_tail_is_recognised_and_lane_priority_follows_the_context(monkeypatch):
+    """Host decisions of round 3 (no GPU): (1) `FusedSequential` hands the PixelDiscriminator's second conv -> norm -> LeakyReLU ->
+    Conv2d(2 ndf, 1, 1x1) to the fused-tail node exactly when the library serves the width (a power of two in [16, 256]) and the norm
+    uses batch statistics; a PatchGAN tail (4x4 head) is not matched.  (2) Side lanes are low priority only for a single process
+    with >= 128 K pixels per batch; an environment override always wins."""
+    ops = load_sub("arch.ops")
+    disc = load_sub("arch.discriminators")
+    F = load_sub("functional")
+    for ndf, want in ((64, True), (8, True), (4, False), (24, False), (256, False)):      # 2 ndf = 128, 16, 8, 48, 512
+        net = disc.PixelDiscriminator(3, ndf, norm_layer=ops.get_norm_layer("instance"), use_bias=True)
+        m = list(net.dis_model)
+        assert ops._is_pixel_head(m[2], m[3], m[4], m[5]) is want, ndf
+        assert bool(F.norm_head_applies(2 * ndf)) is want
+    bn = disc.PixelDiscriminator(3, 64, norm_layer=ops.get_norm_layer("batch"))
+    m = list(bn.dis_model)
+    assert ops._is_pixel_head(m[2], m[3], m[4], m[5])
+    bn.eval()                                                                              # running statistics: the unfused path
+    assert not ops._is_pixel_head(m[2], m[3], m[4], m[5])
+    patch = list(disc.NLayerDiscriminator(3, 16, 2, norm_layer=ops.get_norm_layer("instance"), use_bias=True).dis_model)
+    assert not any(isinstance(a, ops.Conv2d) and ops._is_norm(b) and ops._is_pixel_head(a, b, c, d)
+                   for a, b, c, d in zip(patch, patch[1:], patch[2:], patch[3:]) if isinstance(c, ops._Act))
+    monkeypatch.delenv("SSCG_SIDE_PRIORITY", raising=False)
+    assert F.side_priority() == 1 and F.side_priority_for(8 * 256 * 256) == 1 and F.side_priority_for(2 * 64 * 64) == 0
+    monkeypatch.setenv("SSCG_SIDE_PRIORITY", "0")
+    assert F.side_priority() == 0 and F.side_priority_for(8 * 256 * 256) == 0
+    monkeypatch.setenv("SSCG_SIDE_PRIORITY", "1")
+    assert F.side_priority_for(2 * 64 * 64) == 1

@@ -46,7 +46,11 @@ def timeit(fn, iters=10):
 
 
 def main():
-    for (N, C, H, W, K, R, s, p, d) in SHAPES:
+    only = [a for a in sys.argv[1:]]          # e.g. `r1` = the 1x1 shapes only, `n16` = batch 16
+    shapes = [sh for sh in SHAPES if ("r1" not in only or sh[5] == 1)]
+    if "n16" in only:
+        shapes = [(16,) + sh[1:] for sh in shapes]
+    for (N, C, H, W, K, R, s, p, d) in shapes:
         x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=CL)
         w = (torch.randn(K, C, R, R, device=dev) * 0.05).contiguous(memory_format=CL)
         y = F.conv2d_fwd(x, w, None, s, p, d)
