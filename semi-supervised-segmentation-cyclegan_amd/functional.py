@@ -117,6 +117,18 @@ def side_priority_for(pixels_per_batch):
     return p if (p <= 0 or os.environ.get("SSCG_SIDE_PRIORITY") is not None or pixels_per_batch >= 131072) else 0
 
 
+def set_side_priority(prio):
+    """Select the side lanes' priority for the work issued from here on (a model does this at the top of every step).  A CHANGE of
+    priority swaps the lane objects: everything queued on the old ones is launched and the device drained first, so that no kernel
+    of the previous lanes is still in flight when the new ones start (rare: two models of different size in one process)."""
+    if SideStream.priority != prio:
+        if SideStream._streams:
+            flush_side_work()
+            torch.cuda.synchronize()
+        SideStream.priority = prio
+    return prio
+
+
 def reset_side_streams():
     """Drop the cached side lanes (they are re-created, with the priority that holds now, on their next use)."""
     if SideStream._streams:

@@ -46,3 +46,20 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _drain_the_device_between_gpu_tests(request):
+    """A test may return while its model's side lanes (operand-copy refresh, an overlapped discriminator step) are still running; the
+    next test's allocations must not meet kernels of a model that no longer exists.  Launch what is queued, drain, collect."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import gc
+    import torch
+    if torch.cuda.is_available():
+        F = load_sub("functional")
+        F.flush_side_work()
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()

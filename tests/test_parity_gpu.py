@@ -258,7 +258,7 @@ def test_pool_swaps_under_the_overlapped_discriminator_step(dev):
                 m.sync_losses()
                 hist.append({k: float(v) for k, v in out.items()})
         torch.cuda.synchronize()
-        assert all(np.isfinite(v) for h in hist for v in h.values())
+        assert all(np.isfinite(v) for h in hist for v in h.values()), (overlap, [(i, k, v) for i, h in enumerate(hist) for k, v in h.items() if not np.isfinite(v)][:6])
         res.append((hist, swaps, m.d_optimizer.arena.detach().clone(), m.g_optimizer.arena.detach()[::4099].clone()))
     assert res[0][1] >= 3, "the pool's swap branch never fired"
     assert res[0][1] == res[1][1]
