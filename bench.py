@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-elided", action="store_true")
     ap.add_argument("--no-small", action="store_true", help="skip the 64x64 batch-2 host-bound figure")
+    ap.add_argument("--host-bound-only", action="store_true", help="(internal) run the 64x64 batch-2 case alone and print its JSON object")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--dtype", choices=["f32", "f32x", "f32s", "bf16", "bf16c"], default=None, help="default: the configuration's")
     ap.add_argument("--no-bf16", action="store_true", help="config 2: skip the secondary bf16 / exact-fp32 figures")
@@ -110,11 +111,11 @@ def main():
     F.set_conv_precision(dtype)
     arith = F.get_conv_precision()          # "f32" names fp32 TENSORS; this is the contraction it resolves to ("f32" exact / "f32s" split)
     # The reference's own default is batch 2 (main.py:14) on small crops: there the step is bound by the host's issue rate, not by
-    # the GPU.  One line beside the headline, single rank only (a second, small model: 64x64, batch 2, same dtype), taken BEFORE the
-    # configuration's own model exists - what a `main.py --batch_size 2` process sees (the registries of weight copies and the
-    # allocator's pools of a large model in the same process cost this case 10-20 ms per step).
-    host_bound_case = None
-    if world == 1 and not a.no_small:
+    # the GPU.  One line beside the headline, single rank only: the same step at 64x64, batch 2, same dtype, in a PROCESS OF ITS OWN
+    # (`bench.py --host-bound-only`) - what a `main.py --batch_size 2` run sees.  Inside this process the large model's registries
+    # and allocator pools cost the small case 10-20 ms per step, and a process keeps ONE set of side lanes (functional.set_side_priority):
+    # the small case wants them at normal priority, the configuration's own step at low priority.
+    if a.host_bound_only:
         sargs = cli.get_args(["--model", "semisupervised_cycleGAN", "--dataset", cfg["dataset"], "--crop_height", "64", "--crop_width", "64",
                               "--batch_size", "2", "--checkpoint_dir", "/tmp/sscg_bench_ckpt_small", "--dtype", dtype])
         sargs.gpu_ids, sargs.as_written, sargs.overlap_d = [local], True, args.overlap_d
@@ -131,10 +132,18 @@ def main():
         th = (time.perf_counter() - t0) / 10
         torch.cuda.synchronize()
         ts = (time.perf_counter() - t0) / 10
-        host_bound_case = {"workload": "the same step at 64x64, batch 2 (main.py:14 default batch)", "ms_per_step": round(1e3 * ts, 2),
-                                  "host_issue_ms_per_step": round(1e3 * th, 2), "value": round(2 / ts, 2), "unit": "img/s"}
-        del small, sl, su
-        torch.cuda.empty_cache()
+        print(json.dumps({"workload": "the same step at 64x64, batch 2 (main.py:14 default batch), in a process of its own", "ms_per_step": round(1e3 * ts, 2),
+                          "host_issue_ms_per_step": round(1e3 * th, 2), "value": round(2 / ts, 2), "unit": "img/s"}))
+        return
+    host_bound_case = None
+    if world == 1 and not a.no_small:
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-bound-only", "--config", str(a.config), "--dtype", dtype],
+                               capture_output=True, text=True, timeout=900)
+            host_bound_case = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:      # a secondary figure must not take the headline with it
+            host_bound_case = {"error": "%s: %s" % (type(e).__name__, e)}
 
     with contextlib.redirect_stdout(io.StringIO()):
         model = md.semisuper_cycleGAN(args, data_parallel=dp)

@@ -118,15 +118,13 @@ def side_priority_for(pixels_per_batch):
 
 
 def set_side_priority(prio):
-    """Select the side lanes' priority for the work issued from here on (a model does this at the top of every step).  A CHANGE of
-    priority swaps the lane objects: everything queued on the old ones is launched and the device drained first, so that no kernel
-    of the previous lanes is still in flight when the new ones start (rare: two models of different size in one process)."""
-    if SideStream.priority != prio:
-        if SideStream._streams:
-            flush_side_work()
-            torch.cuda.synchronize()
+    """Choose the side lanes' priority - effective only while the process has no lanes yet.  ONE set of lanes per process: a second
+    set (a small model at normal priority, then a large one at low priority) oversubscribes the hardware queues - the step ran 172
+    instead of 142 ms and produced non-finite losses on this runtime (`tools/nan_probe.sh`, profiles/r03_experiments.txt item 12).
+    The first model that steps decides; returns the priority in force."""
+    if not SideStream._streams:
         SideStream.priority = prio
-    return prio
+    return SideStream.priority
 
 
 def reset_side_streams():
@@ -136,6 +134,7 @@ def reset_side_streams():
         torch.cuda.synchronize()
         SideStream._streams.clear()
         _STREAM_BY_HANDLE.clear()
+    SideStream.priority = None
 
 
 class SideStream:
@@ -149,22 +148,23 @@ class SideStream:
 
     lanes = int(os.environ.get("SSCG_SIDE_LANES", "2"))   # measured: 4 streams in flight (main, fork lane, 2 side lanes) is the sweet spot; a 5th costs 20 %
 
-    priority = None     # None = side_priority(); a model sets its own at the top of every step (model.semisuper_cycleGAN.step)
+    priority = None     # fixed when the first lane is made: set_side_priority() of the first model that steps, else side_priority()
 
     @classmethod
     def get(cls, device, lane=0):
-        prio = cls.priority if cls.priority is not None else side_priority()
-        s = cls._streams.get((device, lane, prio))
+        s = cls._streams.get((device, lane))
         if s is None:
-            s = _make_stream(device, prio)
-            cls._streams[(device, lane, prio)] = s
+            if cls.priority is None:
+                cls.priority = side_priority()
+            s = _make_stream(device, cls.priority)
+            cls._streams[(device, lane)] = s
         return s
 
     @classmethod
     def join(cls, device=None):
         """Make the current stream wait for everything queued on the side stream(s) (deferred work is launched first)."""
         flush_side_work(device)
-        for (dev, _, _), s in cls._streams.items():
+        for (dev, _), s in cls._streams.items():
             if device is None or dev == device:
                 torch.cuda.current_stream(dev).wait_stream(s)
 

@@ -127,7 +127,7 @@ class semisuper_cycleGAN(object):
     def step(self, l_img, l_gt, unl_img):
         """One G step + one D step (model.py:376-542).  Returns the nine losses as 0-dim device tensors."""
         a, C = self.args, self.n_channels
-        self._side_prio = F.set_side_priority(F.side_priority_for(l_img.shape[0] * l_img.shape[2] * l_img.shape[3]))
+        F.set_side_priority(F.side_priority_for(l_img.shape[0] * l_img.shape[2] * l_img.shape[3]))      # (the process's first step decides)
         # ---- generators (model.py:376-474)
         set_grad([self.Di, self.Ds, self.old_Di], False)
         set_grad([self.old_Gsi, self.old_Gis], False)
@@ -304,8 +304,6 @@ class semisuper_cycleGAN(object):
         """Make the current stream wait for the discriminator stream (overlap_d): call before reading a step's losses."""
         if self.overlap_d:
             dev = torch.device("cuda", self.args.gpu_ids[0])
-            if getattr(self, "_side_prio", None) is not None:
-                F.set_side_priority(self._side_prio)          # (another model of another size may have stepped since)
             torch.cuda.current_stream(dev).wait_stream(F.d_stream(dev))
 
     def _d_step(self, a, recon_img, fake_img, fake_gt, unl_img, onehot_gt, resnet_recon_img):

@@ -1,6 +1,8 @@
 """Step-level behaviour on the MI355X beyond loss parity: evaluation path, checkpoint interchange of the
 flat-arena optimiser, reflection-pad adjoint, determinism of the two-stream schedule."""
 import contextlib
+import os
+import sys
 import io
 
 import numpy as np
@@ -248,3 +250,22 @@ def test_overlapped_d_step_is_bit_identical_to_the_serial_schedule(dev):
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
     assert torch.equal(res[0][2], res[1][2])
+
+
+def test_low_priority_side_lanes_compute_the_same_bits():
+    """The side lanes of a large-batch process are LOW-priority HIP streams (functional.side_priority_for); the in-process tests run
+    at the priority of the suite's first model (normal: small batches), so this one starts a process per priority and compares
+    two overlapped steps bit for bit (losses, checksums of both optimisers' arenas)."""
+    import json
+    import subprocess
+    got = {}
+    for prio in ("0", "1"):
+        env = dict(os.environ, SSCG_SIDE_PRIORITY=prio)
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "aids", "prio_step.py")], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[prio] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert got["0"]["priority"] == 0 and got["1"]["priority"] == 1
+    for k in ("losses", "g_sum", "g_abs", "d_sum"):
+        assert got["0"][k] == got["1"][k], k
+    assert all(np.isfinite(float.fromhex(v)) for v in got["1"]["losses"].values())
