@@ -26,7 +26,8 @@ Besides the contract line this prints, in the same JSON object:
                  sample (rank 0, N = 1 only);
   secondary figures, never the headline: elided_dead_work (the step without the reference's unused forwards), bf16 and f32_exact
                  (the fp32 configuration in the bf16 arithmetic / with exact fp32 MFMA contractions), host_bound_case (64x64,
-                 batch 2: the host's issue cost of a step), host_issue_ms_per_step.
+                 batch 2: the host's issue cost of a step; measured by `bench.py --host-bound-only` in a process of its own),
+                 host_issue_ms_per_step.
 """
 import argparse
 import contextlib
