@@ -146,6 +146,8 @@ class SideStream:
     enabled = True
     _streams = {}
 
+    # A/B aid only: with a third lane (or a second lane set) streams share hardware queues, and the overlapped D step then produces
+    # non-finite losses (open issue, profiles/r03_experiments.txt items 12-13)
     lanes = int(os.environ.get("SSCG_SIDE_LANES", "2"))   # measured: 4 streams in flight (main, fork lane, 2 side lanes) is the sweet spot; a 5th costs 20 %
 
     priority = None     # fixed when the first lane is made: set_side_priority() of the first model that steps, else side_priority()
