@@ -77,8 +77,14 @@ class SemiSupOracle:
     """State + one step of the semi-supervised CycleGAN (model.py:203-311 ctor, :370-552 loop body)."""
 
     def __init__(self, n_classes, state_dicts, lr=2e-4, lab_CE_weight=1.0, lab_MSE_weight=1.0, adversarial_weight=1.0,
-                 discriminator_weight=1.0, lamda_gt=0.1, norm="instance", use_dropout=False, crop=(64, 64), as_written=False, q=None):
+                 discriminator_weight=1.0, lamda_gt=0.1, norm="instance", use_dropout=False, crop=(64, 64), as_written=False, q=None,
+                 variants=(), lamda_img=0.5):
         self.C = n_classes
+        # loss terms the reference has commented out (the build's --variants, SURVEY 8(f) N4), restated as the commented lines read:
+        #   "l1_cycle"   model.py:453  img_cycle_loss = L1(recon_img, unl_img), weighted like the other image-cycle term (lamda_img)
+        #   "lab_gt_dis" model.py:439,447  gt_label_gen_loss = MSE(Ds(lab_gt), ones), an adversarial term (adversarial_weight)
+        self.variants = set(variants)
+        self.lamda_img = lamda_img
         # q = nets.Bf16Emulation: the same step in the caller's dtype (fp64) with every tensor the bf16 build keeps in bf16 rounded
         # to bf16 at the same place - the yardstick of the bf16 parity tests (not the reference's arithmetic; None = exact)
         self.q = nets._NOQ if q is None else q
@@ -142,6 +148,13 @@ class SemiSupOracle:
         lab_loss_MSE = (fake_img - l_img).abs().mean()                                           # :461 (an L1 loss)
         full = w["ce"] * lab_loss_CE + w["l1"] * lab_loss_MSE                                    # :464
         unsup = w["adv"] * (img_gen_loss + gt_gen_loss) + img_cycle_loss + gt_cycle_loss * w["gt"]  # :466
+        extras = {}
+        if "l1_cycle" in self.variants:
+            extras["img_cycle_l1"] = (recon_img - unl_img).abs().mean()                          # :453 (commented out)
+            unsup = unsup + self.lamda_img * extras["img_cycle_l1"]
+        if "lab_gt_dis" in self.variants:
+            extras["gt_label_gen_loss"] = mse(self._dis("Ds", lab_gt), 1.0)                      # :439,:447 (commented out)
+            unsup = unsup + w["adv"] * extras["gt_label_gen_loss"]
         (full + unsup).backward()                                                                # :472
         if collect is not None:
             collect["g_grads"] = [None if p.grad is None else p.grad.detach().clone() for p in self.g_params]
@@ -169,7 +182,9 @@ class SemiSupOracle:
         self.d_opt.step()                                                                        # :542
         vals = (img_dis_loss, gt_dis_loss, cycle_img_dis_loss, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss,
                 lab_loss_CE, lab_loss_MSE)
-        return {k: float(v.detach()) for k, v in zip(LOSS_KEYS, vals)}                            # scalars of :548-550
+        out = {k: float(v.detach()) for k, v in zip(LOSS_KEYS, vals)}                             # scalars of :548-550
+        out.update({k: float(v.detach()) for k, v in extras.items()})
+        return out
 
 
 class SupervisedOracle:

@@ -123,6 +123,13 @@ def _load():
         raise ImportError("libsscg.so ABI version %d != binding version %d" % (v, ABI_VERSION))
     if os.environ.get("SSCG_TRACE"):
         return _Traced(lib)
+    if os.environ.get("SSCG_RACECHECK"):        # debug: log every launch into the stream-ordering checker (racecheck.py)
+        from . import racecheck
+        racecheck.install()
+        return racecheck._Checked(lib)
+    if os.environ.get("SSCG_FUZZ"):             # debug: schedule fuzzer (racecheck.fuzz(seed) switches it on)
+        from . import racecheck
+        return racecheck._Fuzzed(lib)
     return lib
 
 

@@ -439,3 +439,10 @@ def set_grad(nets, requires_grad=False):
     for net in nets:
         for param in net.parameters():
             param.requires_grad = requires_grad
+
+
+import os as _os
+if _os.environ.get("SSCG_RACECHECK"):     # debug: see functional.py (stream-ordering checker)
+    import sys as _sys
+    from .. import racecheck as _racecheck
+    _racecheck.wrap_functions(_sys.modules[__name__])

@@ -80,19 +80,44 @@ _WS = _Workspace()
 _HIPRT = []
 
 
+def _hip_runtime():
+    """The HIP runtime torch itself loaded (a second copy's stream handles would be foreign to torch): its path is taken from this
+    process's own mappings; None when it cannot be found or lacks the symbol."""
+    import ctypes
+    if not _HIPRT:
+        h = None
+        try:
+            path = None
+            with open("/proc/self/maps") as f:
+                for line in f:
+                    if "libamdhip64.so" in line:
+                        path = line.split(None, 5)[-1].strip()
+                        break
+            if path is not None:
+                h = ctypes.CDLL(path)       # already mapped: dlopen returns the loaded library
+                h.hipStreamCreateWithPriority.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint, ctypes.c_int]
+                h.hipStreamCreateWithPriority.restype = ctypes.c_int
+        except (OSError, AttributeError):
+            h = None
+        _HIPRT.append(h)
+    return _HIPRT[0]
+
+
 def _make_stream(device, priority=0):
     """A HIP stream of the given priority (HIP's scale: -1 high, 0 normal, 1 low).  torch only creates normal / high priority
-    streams; a LOW priority one comes from hipStreamCreateWithPriority and is wrapped (it lives as long as the process)."""
+    streams; a LOW priority one comes from hipStreamCreateWithPriority and is wrapped (it lives as long as the process).  Where
+    that is not possible (runtime not found, call refused) the lane is a normal-priority torch stream: slower by ~1 %, never wrong."""
     import ctypes
     if priority <= 0:
         return torch.cuda.Stream(device=device, priority=priority)
-    if not _HIPRT:
-        _HIPRT.append(ctypes.CDLL("libamdhip64.so"))
+    rt = _hip_runtime()
+    if rt is None:
+        return torch.cuda.Stream(device=device, priority=0)
     h = ctypes.c_void_p()
     with torch.cuda.device(device):
-        rc = _HIPRT[0].hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority))   # 1 = hipStreamNonBlocking
-    if rc != 0:
-        raise _lib.SscgError("hipStreamCreateWithPriority(%d) failed: %d" % (priority, rc))
+        rc = rt.hipStreamCreateWithPriority(ctypes.byref(h), 1, priority)   # 1 = hipStreamNonBlocking
+    if rc != 0 or not h.value:
+        return torch.cuda.Stream(device=device, priority=0)
     return torch.cuda.ExternalStream(h.value, device=device)
 
 
@@ -199,6 +224,20 @@ def d_stream(device):
     the next one, which is when the D step runs.  Not a stream of its own: a fifth stream in flight costs ~20 % (the
     hardware runs four queues side by side; more are time-sliced)."""
     return SideStream.get(device, SideStream.lanes - 1)
+
+
+def debug_wait_for_d(device, names):
+    """Bisection aid (SSCG_DBG_TOPWAIT=main,fork,side0,...): order the named streams behind the D stream."""
+    d = d_stream(device)
+    for n in names:
+        if n == "main":
+            s = torch.cuda.current_stream(device)
+        elif n == "fork":
+            s = ForkStream.get(device)
+        else:
+            s = SideStream.get(device, int(n[4:]))
+        if s.cuda_stream != d.cuda_stream:
+            s.wait_stream(d)
 
 
 def run_on_side_stream(device, tensors, fn, lane=0, defer=False):
@@ -974,6 +1013,14 @@ def refresh_transposed_weights(weights=(), all_users=True):
 
     `all_users` is only safe on a stream that is ordered behind EVERY optimiser's last update and every reader of the
     stale copies (a rebuild frees the old copy: the allocator may hand its block to the next allocation at once)."""
+    _IN_REFRESH[0] = True
+    try:
+        _refresh_all(weights, all_users)
+    finally:
+        _IN_REFRESH[0] = False
+
+
+def _refresh_all(weights, all_users):
     bf16 = _MODE[0] == "bf16"
     if _MODE[0] != "f32s":       # (split mode: which copy a weight needs depends on its geometry - the registry below knows)
         for w in weights:
@@ -1009,21 +1056,67 @@ def _wtag(w):
     return (w._version, getattr(w, "_sscg_epoch", _WEIGHT_EPOCH)[0], w.data_ptr())
 
 
+_NO_COPY_SYNC = os.environ.get("SSCG_DBG_NO_COPY_SYNC") == "1"      # A/B aid: round 3's behaviour (tests/aids/fuzz_step.py shows the race)
+_IN_REFRESH = [False]       # inside refresh_transposed_weights: the CALLER orders the readers (one event for the whole batch)
+
+
+class _Copy(object):
+    """A cached operand copy of a weight.  A copy built inside `refresh_transposed_weights` is ordered by its caller (one event for
+    the batch: model._copies_ready).  A copy built LAZILY - by the first pass that needs it, on that pass's stream - carries its own
+    event: a reader on another stream waits for it first (once per stream), and every reader stream is announced to the allocator
+    (`record_stream`) when the copy is replaced, so that the block is not handed out while a reader is still in flight.  (Round 3
+    had neither: at a model's first step - empty registry, nothing prebuilt - the copies were built by whichever of the two forward
+    lanes reached a layer first and read by the other unsynchronised; racecheck.py reports exactly these launches.)"""
+    __slots__ = ("tag", "t", "ev", "stream", "readers")
+
+    def __init__(self, tag, build):
+        self.tag = tag
+        self.stream = _stream()
+        self.t = build()
+        self.readers = None
+        self.ev = None
+        if not _IN_REFRESH[0] and not _NO_COPY_SYNC:
+            self.ev = torch.cuda.Event()
+            self.ev.record()
+            self.readers = set()
+
+    def get(self):
+        if self.ev is not None:
+            h = _stream()
+            if h != self.stream and h not in self.readers:
+                torch.cuda.current_stream().wait_event(self.ev)
+                self.readers.add(h)
+        return self.t
+
+    def retire(self):
+        """The copy is about to be dropped: its block must outlive the readers on other streams."""
+        if self.readers:
+            dev = self.t.device
+            for h in self.readers:
+                self.t.record_stream(_stream_object(dev, h))
+
+
+def _cached_copy(w, attr, build):
+    tag = _wtag(w)
+    ent = getattr(w, attr, None)
+    if ent is None or ent.tag != tag:
+        if ent is not None:
+            ent.retire()
+        ent = _Copy(tag, build)
+        try:
+            setattr(w, attr, ent)
+        except AttributeError:
+            pass
+    return ent.get()
+
+
 def _cached_wt(w, dtype=torch.float32):
     """Transposed copy of a weight, cached ON the tensor object (dies with it; a recycled address can never
     alias).  Valid while neither torch (`_version`) nor our optimiser (`_WEIGHT_EPOCH`) has rewritten it."""
     kind = "tx3" if dtype == "x3" else ("t16" if dtype == torch.bfloat16 else "t32")
     _note_user(w, kind)
     attr = {"tx3": "_sscg_wtx3", "t16": "_sscg_wt16", "t32": "_sscg_wt"}[kind]
-    tag = _wtag(w)
-    ent = getattr(w, attr, None)
-    if ent is None or ent[0] != tag:
-        ent = (tag, weight_transposed(w, dtype))
-        try:
-            setattr(w, attr, ent)
-        except AttributeError:
-            pass
-    return ent[1]
+    return _cached_copy(w, attr, lambda: weight_transposed(w, dtype))
 
 
 def weight_bf16(w):
@@ -1035,15 +1128,15 @@ def weight_bf16(w):
     opt = opt() if opt is not None else None
     if opt is not None:
         return opt.shadow_view(w)
-    tag = _wtag(w)
-    ent = getattr(w, "_sscg_w16", None)
-    if ent is None or ent[0] != tag:
-        ent = (tag, cast(w, torch.bfloat16))
-        try:
-            w._sscg_w16 = ent
-        except AttributeError:
-            pass
-    return ent[1]
+    return _cached_copy(w, "_sscg_w16", lambda: cast(w, torch.bfloat16))
+
+
+def _split3_copy(w):
+    n = w.numel()
+    t = torch.empty(3 * n, dtype=torch.bfloat16, device=w.device)
+    src = w if w.is_contiguous(memory_format=CL) else w.contiguous(memory_format=CL)
+    check(lib.sscg_split3(src.data_ptr(), t.data_ptr(), n, n, _stream()), "sscg_split3")
+    return t
 
 
 def weight_split(w):
@@ -1055,19 +1148,7 @@ def weight_split(w):
     opt = opt() if opt is not None else None
     if opt is not None and hasattr(opt, "split_view"):
         return opt.split_view(w)
-    tag = _wtag(w)
-    ent = getattr(w, "_sscg_wx3", None)
-    if ent is None or ent[0] != tag:
-        n = w.numel()
-        t = torch.empty(3 * n, dtype=torch.bfloat16, device=w.device)
-        src = w if w.is_contiguous(memory_format=CL) else w.contiguous(memory_format=CL)
-        check(lib.sscg_split3(src.data_ptr(), t.data_ptr(), n, n, _stream()), "sscg_split3")
-        ent = (tag, t)
-        try:
-            w._sscg_wx3 = ent
-        except AttributeError:
-            pass
-    return ent[1], w.numel()
+    return _cached_copy(w, "_sscg_wx3", lambda: _split3_copy(w)), w.numel()
 
 
 def _acc_target(param):
@@ -1490,6 +1571,28 @@ class BatchSplitFn(torch.autograd.Function):
         return out, None
 
 
+class CatBatchFn(torch.autograd.Function):
+    """Two batches stacked along N (device copies); the gradient is the two halves."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_nhwc(a), to_nhwc(b)
+        ctx.na = a.shape[0]
+        out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device).contiguous(memory_format=CL)
+        out[:ctx.na].copy_(a)
+        out[ctx.na:].copy_(b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = to_nhwc(g)
+        return (g[:ctx.na] if ctx.needs_input_grad[0] else None), (g[ctx.na:] if ctx.needs_input_grad[1] else None)
+
+
+def cat_batch(a, b):
+    return CatBatchFn.apply(a, b)
+
+
 def split_batch(x, k):
     x = to_nhwc(x)
     if not (torch.is_grad_enabled() and x.requires_grad):
@@ -1815,3 +1918,9 @@ def l1_loss(a, b):
 
 def weighted_sum(terms, weights):
     return WeightedSumFn.apply(list(weights), *terms)
+
+
+if os.environ.get("SSCG_RACECHECK"):     # debug: model the autograd engine's stream hand-over for the ordering checker
+    import sys as _sys
+    from . import racecheck as _racecheck
+    _racecheck.wrap_functions(_sys.modules[__name__])

@@ -23,6 +23,9 @@ from .arch import define_Dis, define_Gen, set_grad
 from .optim import FusedAdam
 from .utils import CLASSES, make_one_hot
 
+_DBG_TOPWAIT = [x for x in os.environ.get("SSCG_DBG_TOPWAIT", "").split(",") if x]
+
+
 def _check_bf16_widths(args):
     """--dtype bf16: the bf16 conv kernels move 64-channel k-tiles, so every activation between a network's first conv and its head
     must have a multiple of 64 channels - true for the reference's default widths (--ngf 64 --ndf 64), not for e.g. --ngf 32."""
@@ -89,6 +92,9 @@ class semisuper_cycleGAN(object):
         self.as_written = getattr(args, "as_written", True)         # keep the reference's unused forwards
         self.fork_forward = getattr(args, "fork_forward", True)     # two stream lanes for the trainable generator passes
         self.stack_gsi = getattr(args, "stack_gsi", True)           # the two independent Gsi passes as one grouped-BN pass
+        # Gis(onehot_gt) and Gis(fake_gt) (:385, :408) as ONE grouped-BN pass behind the Gsi pass, everything on the main lane
+        # (no fork lane): convolutions over 17424 instead of 8712 rows, one DeepLab pass of launches fewer per direction
+        self.stack_gis = bool(getattr(args, "stack_gis", os.environ.get("SSCG_STACK_GIS", "0") == "1"))
         # D step on its own stream: it then overlaps the NEXT step's generator forwards (which read no discriminator
         # weight until :431).  Opt-in, because the three discriminator losses a step returns are then produced on that
         # stream: callers read them after `sync_losses()` (train() and bench.py do).
@@ -128,10 +134,15 @@ class semisuper_cycleGAN(object):
         """One G step + one D step (model.py:376-542).  Returns the nine losses as 0-dim device tensors."""
         a, C = self.args, self.n_channels
         F.set_side_priority(F.side_priority_for(l_img.shape[0] * l_img.shape[2] * l_img.shape[3]))      # (the process's first step decides)
+        if self.overlap_d and _DBG_TOPWAIT:     # bisection aid: these streams wait for the previous D step before anything of this step
+            F.debug_wait_for_d(l_img.device, _DBG_TOPWAIT)
         # ---- generators (model.py:376-474)
         set_grad([self.Di, self.Ds, self.old_Di], False)
         set_grad([self.old_Gsi, self.old_Gis], False)
         self.g_optimizer.zero_grad()
+        # the generators' operand copies (bf16 shadow / split planes) exist and are current before any lane reads them: a no-op
+        # after the first step (the Adam kernel rewrites them); the discriminators' follow at :431, behind their own update
+        self.g_optimizer.ensure_operand_copies()
         labels = l_gt.reshape(l_gt.shape[0], l_gt.shape[2], l_gt.shape[3])          # l_gt.squeeze(1)
         onehot_gt = make_one_hot(l_gt, a.dataset, a.gpu_ids)
 
@@ -149,7 +160,7 @@ class semisuper_cycleGAN(object):
                 return self.old_Gis(fake)                                            # :422
         resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch)
         dev = l_img.device
-        fork = F.SideStream.enabled and self.fork_forward
+        fork = F.SideStream.enabled and self.fork_forward and not self.stack_gis
         self._wait_operand_copies(torch.cuda.current_stream(dev))
         if fork:
             # Two lanes: Gis(onehot) -> Gsi(fake_img) on the fork stream, Gsi(unl) -> Gsi(l_img) -> Gis(fake_gt) here.
@@ -166,7 +177,7 @@ class semisuper_cycleGAN(object):
                 gis_first = torch.cuda.Event()
                 gis_first.record(lane)
             onehot_gt.record_stream(lane)
-        else:
+        elif not self.stack_gis:
             fake_img = self.interp(self.Gis(onehot_gt))                              # :385,390
         if self.stack_gsi:
             # Gsi(unl_img) and Gsi(l_img) (:386-387) as ONE pass over both batches: every BatchNorm normalises the two
@@ -187,7 +198,17 @@ class semisuper_cycleGAN(object):
         fake_gt = F.softmax2d(fake_gt)                                               # :402
         if fork:
             main.wait_event(gis_first)
-        recon_img = self.interp(self.Gis(fake_gt))                                   # :408,413
+        if self.stack_gis:
+            # :385 and :408 in one pass: group 0 = onehot_gt, group 1 = fake_gt - every BatchNorm of Gis normalises the two halves
+            # separately and advances its running statistics twice in the reference's order (:385 before :408)
+            fake_gt, fake_gt_gis = F.split(fake_gt, 2)
+            with arch.batch_groups(2):
+                gis_both = self.Gis(F.cat_batch(onehot_gt, fake_gt_gis))
+            fake_lo, recon_lo = F.split_batch(gis_both, 2)
+            fake_img = self.interp(fake_lo)                                          # :385,390
+            recon_img = self.interp(recon_lo)                                        # :408,413
+        else:
+            recon_img = self.interp(self.Gis(fake_gt))                               # :408,413
         # :409 - output unused by the reference, but it advances Gis' BN running stats (after those of the :408 pass
         # above, which the side stream waits for).  Nothing reads the result: it runs beside the critical path and is
         # joined before the optimiser touches Gis' weights.
@@ -229,6 +250,7 @@ class semisuper_cycleGAN(object):
             extra_weights.append(a.adversarial_weight)
         if self.overlap_d:      # the previous step's discriminator update (on the D stream) must have landed
             torch.cuda.current_stream(dev).wait_stream(F.d_stream(dev))
+        self.d_optimizer.ensure_operand_copies()
         fake_img_dis = self.Di(fake_img_d)                                           # :431
         resnet_fake_img_dis = self.old_Di(recon_img)                                 # :432
         fake_gt_onehot, _ = F.argmax_onehot(fake_gt.detach())                        # :435-437 (no gradient path)

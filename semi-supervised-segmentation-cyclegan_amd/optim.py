@@ -113,6 +113,29 @@ class FusedAdam(torch.optim.Optimizer):
         off, n = self.slices[p]
         return self.arena_x3[off:off + n], self.arena.numel()
 
+    def ensure_operand_copies(self):
+        """Bring the operand copy the current arithmetic mode reads (bf16 shadow / split planes) up to date on the CURRENT stream.
+        The step calls this on the main lane before it forks: left to the first conv that asks (`shadow_view` / `split_view`), the
+        whole-arena pass runs on whichever lane gets there first - at a model's first step that was the fork lane, with the main
+        lane reading the planes unsynchronised (racecheck.py: 103 read-after-write reports per first step)."""
+        mode = F.get_conv_precision()
+        if F._NO_COPY_SYNC:
+            return
+        if mode == "bf16":
+            if self.arena16 is None:
+                self.refresh_shadow()
+            else:
+                for p in self.trainable:
+                    if self._shadow_ver.get(p) != p._version:
+                        self.shadow_view(p)
+        elif mode == "f32s":
+            if self.arena_x3 is None:
+                self.refresh_split()
+            else:
+                for p in self.trainable:
+                    if self._split_ver.get(p) != p._version:
+                        self.split_view(p)
+
     def zero_grad(self, set_to_none=False):
         F.fill_(self.grad, 0.0)
 

@@ -1,0 +1,104 @@
+"""Is the split contraction (what `--dtype f32` computes with) "fp32-accurate" at NETWORK and STEP level, not only per kernel?
+
+Measured against the fp64 oracle, side by side with the build's exact-fp32-MFMA mode (`f32x`) and with the reference's own fp32
+arithmetic (the CPU oracle in fp32, pinned bit-exact against the reference): tests/golden/g7_first_steps.json holds the first-step
+losses of six independent keyed weight sets (VOC 21 classes, 64x64, batch 2) in fp32 and fp64 (tests/golden/gen_first_steps.py).
+
+The three CHAINED losses (two DeepLab passes with argmax / ReLU-mask flips in between) are a heavy-tailed noise: on these six
+seeds the REFERENCE's fp32 arithmetic sits 0.06e-3 .. 3.7e-3 from fp64 (gt_cycle_loss: 3.7e-3, 3.3e-3; img_cycle_loss: 1.5e-3) -
+north_star's 1e-3 cannot be asked of quantities the reference itself misses it on.  What can be asked, and is asserted here:
+the split mode is no further from fp64 than the exact-fp32 mode, and neither is further than the reference's own arithmetic."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_sub
+from oracle import fixtures as FX
+from test_nets_gpu import CHAINED, DIRECT, build, quiet, rel_l2
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SEEDS = ["ch%d" % i for i in range(6)]
+
+
+def _first_step(tag, cfg, dev):
+    md = load_sub("model")
+    args = FX.make_args(dataset=cfg["dataset"], crop_height=cfg["H"], crop_width=cfg["W"], batch_size=cfg["B"], gpu_ids=[dev.index or 0],
+                        checkpoint_dir="/tmp/sscg_test_ckpt_acc", as_written=True)
+    m = quiet(md.semisuper_cycleGAN, args)
+    for k, sd in FX.semisup_state_dicts(cfg["C"], torch.float32, tag).items():
+        getattr(m, k).load_state_dict(sd, strict=True)
+    l_img, l_gt, unl_img = FX.step_batch(tag, 0, cfg["C"], cfg["H"], cfg["W"], cfg["B"])
+    np.random.seed(0)
+    out = {k: float(v) for k, v in m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev)).items()}
+    torch.cuda.synchronize()
+    return out
+
+
+def test_split_mode_is_as_close_to_fp64_as_exact_fp32_at_step_level(dev):
+    F = load_sub("functional")
+    G = json.load(open(os.path.join(GOLD, "g7_first_steps.json")))
+    err = {"f32x": {}, "f32s": {}, "ref": {}}
+    old = F.get_conv_precision()
+    try:
+        for tag in SEEDS:
+            r64, r32 = G[tag]["oracle_f64"], G[tag]["oracle_f32"]
+            for mode in ("f32x", "f32s"):
+                F.set_conv_precision(mode)
+                got = _first_step(tag, G[tag], dev)
+                for k in r64:
+                    err[mode].setdefault(k, []).append(abs(got[k] - r64[k]) / abs(r64[k]))
+            for k in r64:
+                err["ref"].setdefault(k, []).append(abs(r32[k] - r64[k]) / abs(r64[k]))
+    finally:
+        F.set_conv_precision("f32" if old in ("f32", "f32s") else old)
+    print()
+    for k in CHAINED + DIRECT:
+        print("%-20s " % k + "  ".join("%s med %.2e max %.2e" % (m, float(np.median(err[m][k])), max(err[m][k])) for m in ("ref", "f32x", "f32s")))
+        print("%-20s " % "" + "  ".join("%s %s" % (m, " ".join("%.1e" % e for e in err[m][k])) for m in ("f32x", "f32s")))
+    # losses one DeepLab pass deep: north_star's 1e-3 against fp64, both modes, every seed
+    for k in DIRECT:
+        assert max(err["f32x"][k]) < 1e-3 and max(err["f32s"][k]) < 1e-3, k
+    # chained losses, pooled over the three losses and six seeds (18 draws per mode), each normalised by the noise scale of its loss
+    # = the largest distance the REFERENCE's arithmetic shows on that loss over the six seeds
+    scale = {k: max(err["ref"][k]) for k in CHAINED}
+    pooled = {m: np.array([e / scale[k] for k in CHAINED for e in err[m][k]]) for m in err}
+    rms = {m: float(np.sqrt(np.mean(pooled[m] ** 2))) for m in pooled}
+    print("pooled chained error / reference noise scale: " + "  ".join("%s rms %.2f med %.2f max %.2f" % (m, rms[m], float(np.median(pooled[m])), float(pooled[m].max())) for m in pooled))
+    assert rms["f32s"] <= 1.5 * rms["f32x"], rms
+    assert float(np.median(pooled["f32s"])) <= 1.5 * float(np.median(pooled["f32x"])), pooled
+    assert float(pooled["f32s"].max()) <= 1.5 * float(pooled["f32x"].max()), pooled
+    # ... and neither mode is further from fp64 than the reference's own fp32 arithmetic is (same pooled statistic)
+    assert rms["f32s"] <= 1.5 * rms["ref"] and rms["f32x"] <= 1.5 * rms["ref"], rms
+    for k in CHAINED:       # per loss: no draw beyond twice the worst the reference shows on that loss
+        assert max(err["f32s"][k]) <= 2.0 * scale[k] and max(err["f32x"][k]) <= 2.0 * scale[k], (k, err["f32s"][k], err["f32x"][k], scale[k])
+
+
+@pytest.mark.parametrize("name", ["deeplab_3_21", "deeplab_21_3"])
+def test_deeplab_forward_split_vs_exact_vs_fp64(name, dev):
+    """DeepLab forward (101 BatchNorm layers at batch 2) against the fp64 golden, rel-L2 over the logits: the split mode's distance
+    is within 1.25 x the exact mode's (+ 2e-7)."""
+    F = load_sub("functional")
+    g2 = np.load(os.path.join(GOLD, "g2_nets.npz"))
+    net = [n for n in FX.NETS if n[0] == name][0]
+    _, kind, args, xshape = net
+    e = {}
+    old = F.get_conv_precision()
+    try:
+        for mode in ("f32x", "f32s"):
+            F.set_conv_precision(mode)
+            m = build(kind, args, dev)
+            m.load_state_dict(FX.net_weights(name, kind, args), strict=True)
+            m.train()
+            with torch.no_grad():
+                y = m(FX.net_input(name, xshape).to(dev))
+            e[mode] = rel_l2(y, g2[name + "/y/f64"])
+    finally:
+        F.set_conv_precision("f32" if old in ("f32", "f32s") else old)
+    e["ref"] = rel_l2(g2[name + "/y/f32"], g2[name + "/y/f64"])
+    print("%s forward rel-L2 vs fp64: reference fp32 %.2e, exact-fp32 MFMA %.2e, split %.2e" % (name, e["ref"], e["f32x"], e["f32s"]))
+    assert e["f32s"] <= 1.25 * e["f32x"] + 2e-7
+    assert e["f32s"] <= 1.25 * e["ref"] + 2e-7

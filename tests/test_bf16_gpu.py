@@ -7,6 +7,7 @@ class); where the kernel writes a bf16 tensor the comparison adds one bf16 round
 Network / step level: bf16 rounding of every activation is real arithmetic noise; the tolerances are stated per test."""
 import contextlib
 import io
+import os
 
 import numpy as np
 import pytest
@@ -543,7 +544,6 @@ def test_cityscapes_first_step_bf16_vs_fp64_oracle(dev, bf16_mode):
     of the build's relative distance to fp64 may not exceed twice the emulation's (+ 2e-3) - and every single loss stays inside
     the stated flat bf16 bound (5e-2 one DeepLab pass deep, 1e-1 for the three losses that chain two passes).
     Measured: build 0.3e-3 .. 1.5e-2, emulation 0.6e-3 .. 1.6e-2 per loss; pooled rms 5.4e-3 vs 5.5e-3."""
-    from oracle import nets as onets
     F = bf16_mode
     md = load_sub("model")
     C, H, Wd = 20, 64, 128
@@ -557,12 +557,12 @@ def test_cityscapes_first_step_bf16_vs_fp64_oracle(dev, bf16_mode):
     np.random.seed(0)
     out = m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev))
     got = {k: float(v) for k, v in out.items()}
-    np.random.seed(0)
-    o64 = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float64, tag), crop=(H, Wd))
-    r64 = o64.step(l_img.double(), l_gt, unl_img.double())
-    np.random.seed(0)
-    oem = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float64, tag), crop=(H, Wd), q=onets.Bf16Emulation)
-    rem = oem.step(l_img.double(), l_gt, unl_img.double())
+    # both CPU legs (the fp64 step and its bf16 emulation, ~40 s each on the box's host) come from the committed golden of the
+    # same oracle: tests/golden/g7_first_steps.json, written by tests/golden/gen_first_steps.py
+    import json
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_first_steps.json")))[tag]
+    assert (G["C"], G["H"], G["W"], G["B"]) == (C, H, Wd, 2)
+    r64, rem = G["oracle_f64"], G["oracle_f64_bf16_emulation"]
     es, ds = [], []
     for k in ostep.LOSS_KEYS:
         e = abs(got[k] - r64[k]) / abs(r64[k])

@@ -1,0 +1,12 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+O=gpurun_out/r4p3; mkdir -p $O
+f() { grep -v "^\[W\|Warning\|amdgpu.ids" $1 | tail -${2:-9}; }
+( SSCG_DBG_NO_COPY_SYNC=1 SSCG_FUZZ_DELAY_FORK=20000000 timeout 900 python tests/aids/fuzz_step.py 2 3 64 2 ) > $O/fuzz_nosync_delayfork.txt 2>&1; f $O/fuzz_nosync_delayfork.txt
+( SSCG_FUZZ_DELAY_FORK=20000000 timeout 900 python tests/aids/fuzz_step.py 2 3 64 2 ) > $O/fuzz_fixed_delayfork.txt 2>&1; f $O/fuzz_fixed_delayfork.txt
+( SSCG_DBG_NO_COPY_SYNC=1 timeout 900 python tests/aids/fuzz_step.py 6 3 64 2 ) > $O/fuzz_nosync.txt 2>&1; f $O/fuzz_nosync.txt
+( timeout 900 python tests/aids/fuzz_step.py 6 3 64 2 ) > $O/fuzz_fixed.txt 2>&1; f $O/fuzz_fixed.txt
+( GPU_MAX_HW_QUEUES=2 SSCG_SIDE_LANES=3 timeout 900 python tests/aids/fuzz_step.py 4 3 64 2 ) > $O/fuzz_fixed_q2_l3.txt 2>&1; f $O/fuzz_fixed_q2_l3.txt 6
+( SSCG_FORCE_DP=1 timeout 900 python tests/aids/fuzz_step.py 4 3 64 2 ) > $O/fuzz_fixed_dp.txt 2>&1; f $O/fuzz_fixed_dp.txt 6
+for v in "" "SSCG_SIDE_LANES=3" "SSCG_FORCE_DP=1"; do ( env $v timeout 600 python tests/aids/racecheck_step.py 3 64 2 1 ) > "$O/rc_${v:-lanes2}.txt" 2>&1; echo "== $v"; grep "racecheck:\|^\s*\[" "$O/rc_${v:-lanes2}.txt" | cut -c1-250; done
