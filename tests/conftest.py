@@ -61,5 +61,8 @@ def _drain_the_device_between_gpu_tests(request):
         F = load_sub("functional")
         F.flush_side_work()
         torch.cuda.synchronize()
-        gc.collect()
-        torch.cuda.synchronize()
+        # models hold reference cycles (autograd nodes <-> closures): collect them where models are built - the kernel-level files
+        # (500 tests) build none, and a full collection costs ~0.25 s per test (130 s of the round-3 suite)
+        if os.path.basename(str(request.node.fspath)) not in ("test_kernels_gpu.py", "test_abi.py", "test_schedule_gpu.py"):
+            gc.collect()
+            torch.cuda.synchronize()
