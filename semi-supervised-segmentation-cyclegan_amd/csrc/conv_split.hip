@@ -996,6 +996,257 @@ __global__ __launch_bounds__(256, 2) void wgrads_kernel(WgsParams p) {
     }
 }
 
+// =====================================================================================================================
+// 1x1 (stride 1, no padding) weight gradient with the operand split FUSED into the kernel:  dW[k][c] = sum_p dy[p][k] * x[p][c].
+//
+// A 1x1 filter meets every element of x and dy in one tap only, so the element-wise split pass of `wgrads_kernel` (10 bytes of HBM
+// traffic per element) costs what it saves, and conv_wgrad.hip's on-the-fly kernel splits every fragment in the wave that feeds it -
+// every element twice per tile (both waves of a tile row / column), 13 VALU operations per MFMA measured, 75-100 TFLOP/s.  Here the
+// fp32 [pixel][channel] rows of a k-tile (16 pixels x 128 channels per operand) go to LDS by LDS-DMA, every thread splits ONE
+// 8-channel group of each operand (88 VALU operations per k-tile: 3.7 per MFMA) and writes the three bf16 pieces into the plane
+// images `wgrads_kernel` reads - same row swizzle, same `ds_read_b64_tr_b16` fragment reads, same MFMA order.  The split of tile
+// t + 1 runs under the MFMAs of tile t (one plane buffer, two barriers per k-tile: readers of the planes done / pieces written);
+// three raw stages keep two k-tiles of copies in flight.  72 KB of LDS: two workgroups per CU.
+constexpr int WF_ROWB = 512;                       // bytes of one pixel row of a raw tile (128 channels fp32)
+constexpr int WF_RAW_OP = WS_BKP * WF_ROWB;        // 8 KB
+constexpr int WF_RAW_STAGE = 2 * WF_RAW_OP;        // dy rows, then x rows
+constexpr int WF_NRAW = 3;
+constexpr int WF_PLANES = WF_NRAW * WF_RAW_STAGE;  // offset of the plane buffer (A planes 0..2, B planes 0..2 = WS_STAGE bytes)
+constexpr int WF_SMEM = WF_PLANES + WS_STAGE;      // 72 KB
+
+struct WgfParams {
+    const float* __restrict__ x;      // [npix][C]
+    const float* __restrict__ dy;     // [npix][Kc]
+    float* __restrict__ out;          // dw (splits == 1) or workspace [splits][Kc][C]
+    int Kc, C;
+    int npix, chunk;
+    int tiles_n, tiles, splits;
+    float beta;
+};
+
+__global__ __launch_bounds__(256, 2) void wgradf_kernel(WgfParams p) {
+    constexpr int TM = 2, TN = 2, WN = 2;
+    constexpr int NP = 4;                      // copy instructions per wave and k-tile (two per operand)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds0 = (lds_char*)smem_raw;
+
+    const int tid = threadIdx.x;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / p.tiles;
+    const int tl = lin - split * p.tiles;
+    const int tile_n = tl % p.tiles_n;
+    const int tile_m = tl / p.tiles_n;
+    const int m0 = tile_m * 128;
+    const int n0 = tile_n * 128;
+    const int p_begin = split * p.chunk;
+    const int p_end = min(p.npix, p_begin + p.chunk);
+    const int wave_id = tid >> 6;
+    const int lane = tid & 63;
+    const float* const zero = sscg_zero_page_s;
+
+    // ---- copy side: a wave instruction moves two pixel rows (1 KB); wave w owns rows 4 w .. 4 w + 3 of both operands.  LDS unit
+    // u = lane & 31 of a row holds the 16-byte source unit 2 (u & 15) + (u >> 4): the two halves of an 8-channel group sit 256 bytes
+    // apart, so that the split stage's two ds_read_b128 are each contiguous over 16 lanes
+    const int c_u = lane & 31;
+    const int c_g = 2 * (c_u & 15) + (c_u >> 4);              // source 16-byte unit (4 channels)
+    const bool a_colok = m0 + 4 * c_g < p.Kc;
+    const bool b_colok = n0 + 4 * c_g < p.C;
+    const float* const a_src = p.dy + (a_colok ? m0 + 4 * c_g : 0);
+    const float* const b_src = p.x + (b_colok ? n0 + 4 * c_g : 0);
+    int f_pix = p_begin;
+    int dma_stage = 0;
+    const int lds_wave = __builtin_amdgcn_readfirstlane(wave_id * 2048);      // rows 4 w .. 4 w + 3
+    auto request_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pix = f_pix + wave_id * 4 + 2 * j + (lane >> 5);
+            const bool pok = pix < p_end;
+            const float* ga = (a_colok && pok) ? a_src + (size_t)pix * p.Kc : zero;
+            const float* gb = (b_colok && pok) ? b_src + (size_t)pix * p.C : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                             (__attribute__((address_space(3))) void*)(lds0 + dma_stage * WF_RAW_STAGE + lds_wave + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+                                             (__attribute__((address_space(3))) void*)(lds0 + dma_stage * WF_RAW_STAGE + WF_RAW_OP + lds_wave + j * 1024), 16, 0, 0);
+        }
+        dma_stage = dma_stage + 1 == WF_NRAW ? 0 : dma_stage + 1;
+        f_pix += WS_BKP;
+    };
+
+    // ---- split side: thread t owns channels 8 q .. 8 q + 7 of pixel row r of both operands
+    const int s_r = tid >> 4, s_q = tid & 15;
+    const int s_raw = s_r * WF_ROWB + s_q * 16;                                   // + 256: the upper four channels
+    const int s_pl = WF_PLANES + s_r * WS_ROWB + ((s_q ^ ws_sw(s_r)) << 4);       // + pl * WS_PLANE (+ WS_OP for x)
+    f32x4 raw[2][2];
+    bf16x8 pc[2][3];
+    auto read_raw = [&](int stage) {
+        const lds_char* b = lds0 + stage * WF_RAW_STAGE + s_raw;
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(raw[op][0]) : "v"(b), "n"(op * WF_RAW_OP));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(raw[op][1]) : "v"(b), "n"(op * WF_RAW_OP + 256));
+        }
+    };
+    auto split_raw = [&]() {
+#pragma unroll
+        for (int op = 0; op < 2; ++op) split8(raw[op][0], raw[op][1], pc[op][0], pc[op][1], pc[op][2]);
+    };
+    auto write_pieces = [&]() {
+        lds_char* b = lds0 + s_pl;
+#pragma unroll
+        for (int op = 0; op < 2; ++op)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(b), "v"(pc[op][pl]), "n"(op * WS_OP + pl * WS_PLANE) : "memory");
+    };
+
+    // ---- matrix-core side (wgrads_kernel's fragment geometry)
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int i16 = lane & 15;
+    const int wm = wave_id / WN;
+    const int wn = wave_id % WN;
+    const int row_w = wm * TM * 32;
+    const int col_w = wn * TN * 32;
+    const int tr_pix = 8 * lh + (i16 >> 2);
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ch = row_w + i * 32 + (li & 16) + 4 * (i16 & 3);
+        a_off[i] = WF_PLANES + tr_pix * WS_ROWB + (((ch >> 3) ^ ws_sw(tr_pix)) << 4) + ((ch >> 2) & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ch = col_w + j * 32 + (li & 16) + 4 * (i16 & 3);
+        b_off[j] = WF_PLANES + WS_OP + tr_pix * WS_ROWB + (((ch >> 3) ^ ws_sw(tr_pix)) << 4) + ((ch >> 2) & 1) * 8;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nsteps = (p_end - p_begin + WS_BKP - 1) / WS_BKP;
+    int issued = 0;
+    // the copies of tile t have landed (for this wave) once at most `later` tiles requested after it are outstanding
+    auto wait_tile = [&](int t) {
+        const int later = issued - 1 - t;
+        if (later >= 2) wait_vm<2 * NP>();
+        else if (later == 1) wait_vm<NP>();
+        else wait_vm<0>();
+    };
+    if (nsteps > 0) {
+        for (int s = 0; s < WF_NRAW && s < nsteps; ++s) { request_tile(); ++issued; }
+        wait_tile(0);
+        __builtin_amdgcn_s_barrier();
+        read_raw(0);
+        wait_lgkm<0>();
+        pin(raw[0][0]); pin(raw[0][1]); pin(raw[1][0]); pin(raw[1][1]);
+        split_raw();
+        write_pieces();
+        wait_lgkm<0>();
+        if (nsteps > 1) wait_tile(1);
+        __builtin_amdgcn_s_barrier();                 // planes(0) written, raw tile 1 landed for every wave, raw stage 0 read by all
+        if (issued < nsteps) { request_tile(); ++issued; }      // tile 3 -> stage 0
+    }
+    for (int it = 0; it < nsteps; ++it) {
+        const bool next = it + 1 < nsteps;
+        bf16x4s fa[TM][3][2], fb[TN][3][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[i][pl][0]) : "v"(lds0 + a_off[i]), "n"(pl * WS_PLANE));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[i][pl][1]) : "v"(lds0 + a_off[i]), "n"(pl * WS_PLANE + 4 * WS_ROWB));
+            }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[j][pl][0]) : "v"(lds0 + b_off[j]), "n"(pl * WS_PLANE));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[j][pl][1]) : "v"(lds0 + b_off[j]), "n"(pl * WS_PLANE + 4 * WS_ROWB));
+            }
+        if (next) read_raw((it + 1) % WF_NRAW);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_lgkm<0>();
+        bf16x8 va[TM][3], vb[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                va[i][pl] = __builtin_shufflevector(fa[i][pl][0], fa[i][pl][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                pin(va[i][pl]);
+            }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                vb[j][pl] = __builtin_shufflevector(fb[j][pl][0], fb[j][pl][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                pin(vb[j][pl]);
+            }
+        if (next) { pin(raw[0][0]); pin(raw[0][1]); pin(raw[1][0]); pin(raw[1][1]); }
+        __builtin_amdgcn_sched_barrier(0);
+        // six piece products (smallest terms first); the split of the next k-tile is dealt out between the MFMAs of the last five
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int ap = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0;
+            const int bp = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1 || t == 4) ? 1 : 2;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i][ap], vb[j][bp], acc[i][j], 0, 0, 0);
+            if (t == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (next) split_raw();
+            }
+        }
+        if (next) {
+#pragma unroll
+            for (int n = 0; n < 20; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);        // five VALU (88 in all)
+            }
+#pragma unroll
+            for (int op = 0; op < 2; ++op)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) pin(pc[op][pl]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!next) break;
+        __builtin_amdgcn_s_barrier();                 // A: every wave has read the planes of tile `it` and the raw rows of tile it + 1
+        if (issued < nsteps) { request_tile(); ++issued; }      // tile it + 4 -> the raw stage of tile it + 1
+        write_pieces();
+        wait_lgkm<0>();
+        if (it + 2 < nsteps) wait_tile(it + 2);
+        __builtin_amdgcn_s_barrier();                 // B: planes(it + 1) written; raw tile it + 2 landed for every wave
+    }
+
+    float* out = p.out + (size_t)split * p.Kc * p.C;
+    const bool direct = (p.splits == 1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + col_w + j * 32 + li;
+        if (n >= p.C) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.Kc) {
+                    const size_t o = (size_t)m * p.C + n;
+                    float v = acc[i][j][e];
+                    if (direct && p.beta != 0.f) v += p.beta * out[o];
+                    out[o] = v;
+                }
+            }
+        }
+    }
+}
+
 struct WgsPlan { int splits, chunk; };
 
 // Pixel split: two workgroups per CU fit with three stages (72 KB of LDS), three with two (48 KB); one round of workgroups; at
@@ -1017,27 +1268,85 @@ WgsPlan plan_wgs(const sscg_conv_desc* d) {
     return pl;
 }
 
-}  // namespace
-
-bool sscg_wgrads_applies(const sscg_conv_desc* d) {
-    if (d->precision != 2 || d->x_dtype != SSCG_F32 || d->y_dtype != SSCG_F32) return false;
-    if ((d->wgrad_tuning & 0xff) == 3) return false;      // tuning: class 2 = the on-the-fly split kernel of conv_wgrad.hip
-    const int Ng = d->R * d->S * d->C;
-    if ((d->wgrad_tuning & 0xff) != 4 && d->R * d->S == 1) return false;      // 1x1: too few flops per element for the split pass to pay (class 3 forces it)
-    return d->K >= 128 && Ng >= 128 && d->K % 8 == 0 && d->C % 8 == 0 && (long)d->N * d->P * d->Q >= 1024;
+// Pixel split of the fused 1x1 kernel: one round of two workgroups per CU, at least 8 k-tiles (128 pixels) per workgroup; every split
+// costs a partial tile in the workspace and a pass of the reduction over it.
+WgsPlan plan_wgf(const sscg_conv_desc* d) {
+    const long npix = (long)d->N * d->P * d->Q;
+    const long steps = cdiv(npix, WS_BKP);
+    const long tiles = (long)cdiv(d->K, 128) * cdiv(d->C, 128);
+    const int force = (d->wgrad_tuning >> 8) & 0xffff;
+    long s = force > 0 ? force : 512 / tiles;
+    if (s > steps / 8) s = steps / 8;
+    if (s > 1024) s = 1024;
+    if (s < 1) s = 1;
+    WgsPlan pl;
+    pl.chunk = (int)(cdiv(steps, s) * WS_BKP);
+    pl.splits = cdiv(npix, pl.chunk);
+    return pl;
 }
+
+// 1x1, stride 1, no padding, both sides >= 128 channels: the fused-split kernel (tuning class 3 = conv_wgrad.hip's on-the-fly kernel,
+// class 4 = the pre-split planes kernel, for comparison)
+bool wgf_applies(const sscg_conv_desc* d) {
+    const int cls = d->wgrad_tuning & 0xff;
+    if (cls == 3 || cls == 4 || cls == 5) return false;       // (5 = everything as planned except this kernel: A/B aid)
+    return d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->K >= 128 && d->C >= 128 && d->K % 8 == 0 && d->C % 8 == 0 &&
+           (long)d->N * d->P * d->Q >= 1024;
+}
+
+int launch_wgf(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, size_t ws_bytes, hipStream_t st) {
+    const WgsPlan pl = plan_wgf(d);
+    const size_t part = pl.splits > 1 ? (size_t)pl.splits * d->K * d->C * sizeof(float) : 0;
+    if (part && (!ws || ws_bytes < part)) return SSCG_ERR_WORKSPACE;
+    WgfParams p = {};
+    p.x = reinterpret_cast<const float*>(x); p.dy = reinterpret_cast<const float*>(dy);
+    p.out = pl.splits > 1 ? reinterpret_cast<float*>(ws) : dw;
+    p.Kc = d->K; p.C = d->C;
+    p.npix = d->N * d->P * d->Q; p.chunk = pl.chunk;
+    p.tiles_n = cdiv(p.C, 128); p.tiles = cdiv(p.Kc, 128) * p.tiles_n; p.splits = pl.splits;
+    p.beta = pl.splits > 1 ? 0.f : beta;
+    static bool attr_set = false;       // one attribute per process (idempotent; a race sets it twice)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgradf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WF_SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgradf_kernel, dim3(p.tiles * pl.splits), dim3(256), WF_SMEM, st, p);
+    SSCG_LAUNCH_CHECK();
+    if (pl.splits > 1) return sscg_wgrad_reduce(reinterpret_cast<const float*>(ws), dw, (size_t)d->K * d->C, pl.splits, beta, st);
+    return SSCG_OK;
+}
+
+}  // namespace
 
 static size_t wgs_planes_bytes(const sscg_conv_desc* d) {
     return ((size_t)d->N * d->H * d->W * d->C + (size_t)d->N * d->P * d->Q * d->K) * 3 * sizeof(bf16);
 }
 
+bool sscg_wgrads_applies(const sscg_conv_desc* d) {
+    if (d->precision != 2 || d->x_dtype != SSCG_F32 || d->y_dtype != SSCG_F32) return false;
+    if (wgf_applies(d)) return true;
+    if ((d->wgrad_tuning & 0xff) == 3) return false;      // tuning: class 2 = the on-the-fly split kernel of conv_wgrad.hip
+    const int Ng = d->R * d->S * d->C;
+    if ((d->wgrad_tuning & 0xff) != 4 && d->R * d->S == 1) return false;      // 1x1 outside the fused kernel's reach: too few flops per element for a split PASS to pay (class 3 forces it)
+    // the scratch planes live in the caller's per-stream workspace, which only grows: above 1.5 GB of planes (6 bytes per element of
+    // x and dy: 256-channel 3x3 layers beyond ~120 M pixels-times-channels) the on-the-fly kernel of conv_wgrad.hip serves the layer
+    if (wgs_planes_bytes(d) > ((size_t)3 << 29)) return false;
+    return d->K >= 128 && Ng >= 128 && d->K % 8 == 0 && d->C % 8 == 0 && (long)d->N * d->P * d->Q >= 1024;
+}
+
 size_t sscg_wgrads_workspace(const sscg_conv_desc* d) {
+    if (wgf_applies(d)) {
+        const WgsPlan pf = plan_wgf(d);
+        return pf.splits > 1 ? (size_t)pf.splits * d->K * d->C * sizeof(float) : 0;
+    }
     const WgsPlan pl = plan_wgs(d);
     const size_t part = pl.splits > 1 ? (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float) : 0;
     return ((wgs_planes_bytes(d) + 255) & ~(size_t)255) + part;
 }
 
 int sscg_wgrads(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (wgf_applies(d)) return launch_wgf(d, x, dy, dw, beta, ws, ws_bytes, st);
     if (!ws || ws_bytes < sscg_wgrads_workspace(d)) return SSCG_ERR_WORKSPACE;
     const WgsPlan pl = plan_wgs(d);
     const size_t nx = (size_t)d->N * d->H * d->W * d->C, ny = (size_t)d->N * d->P * d->Q * d->K;
@@ -1063,8 +1372,12 @@ int sscg_wgrads(const sscg_conv_desc* d, const void* x, const void* dy, float* d
         hipLaunchKernelGGL(wgrads_kernel<2>, dim3(p.tiles * pl.splits), dim3(256), 2 * WS_STAGE, st, p);
     } else {
         const size_t smem = (size_t)3 * WS_STAGE;      // 72 KB
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrads_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrads_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
         hipLaunchKernelGGL(wgrads_kernel<3>, dim3(p.tiles * pl.splits), dim3(256), smem, st, p);
     }
     SSCG_LAUNCH_CHECK();
