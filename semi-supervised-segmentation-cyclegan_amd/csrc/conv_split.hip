@@ -1290,6 +1290,9 @@ WgsPlan plan_wgf(const sscg_conv_desc* d) {
 bool wgf_applies(const sscg_conv_desc* d) {
     const int cls = d->wgrad_tuning & 0xff;
     if (cls == 3 || cls == 4 || cls == 5) return false;       // (5 = everything as planned except this kernel: A/B aid)
+    // 2 M outputs and more (1024 <-> 2048): every element meets enough output columns for the split PASS of the planes kernel to pay
+    // (tools/wgrad1x1_bench.py: 228 vs 261 us)
+    if ((long)d->K * d->C >= (1L << 21)) return false;
     return d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->K >= 128 && d->C >= 128 && d->K % 8 == 0 && d->C % 8 == 0 &&
            (long)d->N * d->P * d->Q >= 1024;
 }
@@ -1328,7 +1331,7 @@ bool sscg_wgrads_applies(const sscg_conv_desc* d) {
     if (wgf_applies(d)) return true;
     if ((d->wgrad_tuning & 0xff) == 3) return false;      // tuning: class 2 = the on-the-fly split kernel of conv_wgrad.hip
     const int Ng = d->R * d->S * d->C;
-    if ((d->wgrad_tuning & 0xff) != 4 && d->R * d->S == 1) return false;      // 1x1 outside the fused kernel's reach: too few flops per element for a split PASS to pay (class 3 forces it)
+    if ((d->wgrad_tuning & 0xff) != 4 && d->R * d->S == 1 && (long)d->K * d->C < (1L << 21)) return false;      // 1x1 outside the fused kernel's reach: too few flops per element for a split PASS to pay (class 3 forces it)
     // the scratch planes live in the caller's per-stream workspace, which only grows: above 1.5 GB of planes (6 bytes per element of
     // x and dy: 256-channel 3x3 layers beyond ~120 M pixels-times-channels) the on-the-fly kernel of conv_wgrad.hip serves the layer
     if (wgs_planes_bytes(d) > ((size_t)3 << 29)) return false;
