@@ -360,8 +360,10 @@ def pmc_traffic(fam):
 def cpu_sample_text(cfg, torch_version, threads, probes, physical, logical, model):
     return ("as-written G+D step (incl. model.py:419-420,423), %s %d-class %dx%d, batch 2, torch %s CPU fp32 on %s (%d physical / %d logical "
             "cores): one step at each of %s threads, then 2 timed steps at the fastest setting (%d threads); OMP_PROC_BIND / NUMA policy "
-            "left at the box's defaults" % (cfg["dataset"], cfg["C"], cfg["H"], cfg["W"], torch_version, model, physical, logical,
-                                             "/".join(str(t) for t in probes), threads))
+            "left at the box's defaults.  DEVIATION from SURVEY 8(d) (1 warm-up + >= 3 timed steps on ALL physical cores): oneDNN on these "
+            "33x33 maps over-subscribes past 32-64 threads (BENCH_r02: 52 s/step on 128 threads against 10.5 s on 64), so the thread "
+            "count is searched and only 2 steps are timed to keep the leg under ~90 s" % (
+                cfg["dataset"], cfg["C"], cfg["H"], cfg["W"], torch_version, model, physical, logical, "/".join(str(t) for t in probes), threads))
 
 
 def cpu_thread_candidates(physical):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 10
+#define SSCG_ABI_VERSION 11
 
 /* element types of activation / weight tensors */
 #define SSCG_F32 0
@@ -144,6 +144,24 @@ int sscg_norm_stats(const void* x, int dtype, int G, int64_t L, int C, float eps
 int sscg_norm_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const void* residual, void* y, int dtype, int G, int64_t L, int C, int act, float slope, void* stream);
 /* eval-mode BatchNorm: mean = running_mean, rstd = 1/sqrt(running_var + eps) */
+/* The reduction pass of a normalisation layer's backward, fused into the data gradient that produces its upstream gradient
+ * ("Conv -> norm -> ReLU -> Conv" chains: arch/ops.py:40-57, the Bottleneck's conv1-bn1-relu-conv2-bn2-relu-conv3,
+ * arch/generators.py:345-365; autograd of model.py:472,539).  sscg_conv2d_dgrad_bsums is sscg_conv2d_dgrad (no bias, no
+ * activation) of the CONSUMER convolution; its result dx is the gradient at the output of act(norm(nx)) with nx [G * L][C]
+ * (C = d->C), and its epilogue also leaves, per tile row and channel, the fp64 sums of gg and gg * xhat (gg = act'(...) dx,
+ * xhat = (nx - mean) * rstd; the ReLU / LeakyReLU mask recomputed as the sign of gamma * xhat + beta: layers without a residual
+ * only) in `sums`.  sscg_norm_bwd_from_sums (same descriptor d) then finishes that layer's backward - finalize + apply, no
+ * pass over (dx, nx) for the sums.  sscg_conv2d_dgrad_bsums_bytes returns 0 when the fusion does not apply to the geometry
+ * (strided / few-channel / bf16 data gradients, groups shorter than a tile): use sscg_conv2d_dgrad + sscg_norm_bwd. */
+size_t sscg_conv2d_dgrad_bsums_bytes(const sscg_conv_desc* d, int G, int64_t L);
+int sscg_conv2d_dgrad_bsums(const sscg_conv_desc* d, const void* dy, const void* wt, void* dx, const void* nx, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, int G, int64_t L, int act, float slope,
+                            void* sums, size_t sums_bytes, void* ws, size_t ws_bytes, void* stream);
+/* flags: bit 1 = dgamma / dbeta are written (else accumulated); ws: G * C * 2 floats */
+int sscg_norm_bwd_from_sums(const sscg_conv_desc* d, const void* sums, const void* dy, const void* x, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, int dtype,
+                            int G, int64_t L, int C, int act, float slope, int flags, void* ws, size_t ws_bytes, void* stream);
+
 int sscg_rstd_from_var(const float* var, float* rstd, int n, float eps, void* stream);
 /* backward of norm_apply (+ of the statistics): dx always; dres (= masked dy) if non-NULL;
  * dgamma/dbeta accumulate (+=) if non-NULL.  `y` (the forward output) supplies the activation mask; with ReLU / LeakyReLU

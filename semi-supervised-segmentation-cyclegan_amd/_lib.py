@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 F32, BF16, BF16X3 = 0, 1, 2     # SSCG_F32 / SSCG_BF16 / SSCG_BF16X3 (split weight operand)
 
@@ -49,6 +49,9 @@ SIGNATURES = {
     "sscg_norm_stats_from_conv": (_i, [_dp, _p, _i, _i64, _f, _p, _p, _p, _p, _f, _p]),
     "sscg_conv2d_dgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_dgrad": (_i, [_dp, _p, _p, _p, _p, _i, _f, _p, _sz, _p]),
+    "sscg_conv2d_dgrad_bsums_bytes": (_sz, [_dp, _i, _i64]),
+    "sscg_conv2d_dgrad_bsums": (_i, [_dp, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p, _sz, _p, _sz, _p]),
+    "sscg_norm_bwd_from_sums": (_i, [_dp, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
     "sscg_conv2d_wgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_wgrad": (_i, [_dp, _p, _p, _p, _f, _p, _sz, _p]),
     "sscg_weight_krsc_to_crsk": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),

@@ -55,6 +55,15 @@ struct K16Params {
     double* __restrict__ stats;
     int stat_L;                      // rows per normalisation group (a tile spans at most two groups: stat_L >= BM)
     double* __restrict__ xstats;     // host side: records of the split rows ([blocks][Ng][2]), written by the split reduction
+    // data gradient only: the backward sums of the normalisation layer whose OUTPUT this launch differentiates (conv_split.hip KsParams)
+    const bf16* __restrict__ bn_x;       // [M][Ng] the layer's input (pre-normalisation), or null
+    const float* __restrict__ bn_mean;   // [G][Ng]
+    const float* __restrict__ bn_rstd;
+    const float* __restrict__ bn_gamma;  // [Ng] or null
+    const float* __restrict__ bn_beta;
+    double* __restrict__ bn_sums;        // [G][bn_chunks][Ng][2]
+    int bn_L, bn_G, bn_chunks, bn_act;
+    float bn_slope;
 };
 
 __device__ __forceinline__ void store_out(void* dst, size_t idx, float v, int out_bf16) {
@@ -323,11 +332,56 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
     // x and x^2 over this tile's rows, taken from the fp32 accumulators (+ bias), in fp64; a tile may straddle ONE group
     // boundary (rows m < gb belong to the tile's first group, the rest to the next one).
     const bool want_stats = p.stats != nullptr && !partial;
+    const bool want_bsums = MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (the host plans these launches without split-K)
     int gb = 0x7fffffff;
     if (want_stats) {
         const int g0 = m0 / p.stat_L;
         gb = (g0 + 1) * p.stat_L;
     }
+    int bg = 0;
+    if (want_bsums) { bg = m0 / p.bn_L; gb = (bg + 1) * p.bn_L; }
+    // backward sums of the layer in front (norm.hip col_reduce_kernel<RM_BWD>, mask recomputed from the layer's input): one element
+    auto bsum_add = [&](int m, int n, float pre, float mu0, float rs0, float mu1, float rs1, float ga, float be, double& s0, double& q0,
+                        double& s1, double& q1) {
+        const bool lo = m < gb;
+        const float xh = ((float)p.bn_x[(size_t)m * p.Ng + n] - (lo ? mu0 : mu1)) * (lo ? rs0 : rs1);
+        const float ym = xh * ga + be;
+        float gg = pre;
+        if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? pre : 0.f;
+        else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? pre : pre * p.bn_slope;
+        const double d = (double)gg;
+        if (lo) { s0 += d; q0 += d * (double)xh; } else { s1 += d; q1 += d * (double)xh; }
+    };
+    const bool bs_fast = want_bsums && m0 + BM <= gb;      // tile inside one group: short runs of rows in fp32, their sums in fp64
+    auto bsum_add32 = [&](int m, int n, float pre, float mu0, float rs0, float ga, float be, float& fa, float& fb) {
+        const float xh = ((float)p.bn_x[(size_t)m * p.Ng + n] - mu0) * rs0;
+        const float ym = xh * ga + be;
+        float gg = pre;
+        if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? pre : 0.f;
+        else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? pre : pre * p.bn_slope;
+        fa += gg; fb = fmaf(gg, xh, fb);
+    };
+    auto put_bsums = [&](int n, bool nok, double s0, double q0, double s1, double q1) {
+        s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+        if (lh == 0 && nok) {
+            const int k0 = (tile_m - (int)(((long)bg * p.bn_L) / BM)) * WM + wm;
+            double* r0 = p.bn_sums + (((size_t)bg * p.bn_chunks + k0) * p.Ng + n) * 2;
+            r0[0] = s0; r0[1] = q0;
+            if (m0 + BM > gb && bg + 1 < p.bn_G) {
+                double* r1 = p.bn_sums + (((size_t)(bg + 1) * p.bn_chunks + wm) * p.Ng + n) * 2;
+                r1[0] = s1; r1[1] = q1;
+            }
+        }
+    };
+    auto bsum_params = [&](int n, bool nok, float& mu0, float& rs0, float& mu1, float& rs1, float& ga, float& be) {
+        mu0 = rs0 = mu1 = rs1 = be = 0.f; ga = 1.f;
+        if (want_bsums && nok) {
+            mu0 = p.bn_mean[(size_t)bg * p.Ng + n]; rs0 = p.bn_rstd[(size_t)bg * p.Ng + n];
+            if (bg + 1 < p.bn_G) { mu1 = p.bn_mean[(size_t)(bg + 1) * p.Ng + n]; rs1 = p.bn_rstd[(size_t)(bg + 1) * p.Ng + n]; }
+            if (p.bn_gamma) { ga = p.bn_gamma[n]; be = p.bn_beta[n]; }
+        }
+    };
     // tiles inside one group and inside the tensor (nearly all): four consecutive rows are summed in fp32, the 4-row sums in fp64
     const bool slow_stats = want_stats && (m0 + BM > gb || m0 + BM > p.M);
     const bool fast_stats = want_stats && !slow_stats;
@@ -375,6 +429,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             const bool nok = n < p.Ng;
             const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
             double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+            float mu0, rs0, mu1, rs1, ga, be, bf_a = 0.f, bf_b = 0.f;
+            bsum_params(n, nok, mu0, rs0, mu1, rs1, ga, be);
             if (fast_stats) fast_sums(j, bv, s0, q0);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -383,6 +439,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                     const int ro = i * 32 + (e & 3) + 8 * (e >> 2);           // even: rows ro, ro + 1
                     const int m = m0 + row_w + 4 * lh + ro;
                     const float pre0 = acc[i][j][e] + bv, pre1 = acc[i][j][e + 1] + bv;
+                    if (want_bsums && nok) {
+                        if (bs_fast) {
+                            float fa = 0.f, fb = 0.f;
+                            if (m < p.M) bsum_add32(m, n, pre0, mu0, rs0, ga, be, fa, fb);
+                            if (m + 1 < p.M) bsum_add32(m + 1, n, pre1, mu0, rs0, ga, be, fa, fb);
+                            bf_a += fa; bf_b += fb;
+                            if ((e & 3) == 2) { s0 += (double)bf_a; q0 += (double)bf_b; bf_a = 0.f; bf_b = 0.f; }
+                        } else {
+                            if (m < p.M) bsum_add(m, n, pre0, mu0, rs0, mu1, rs1, ga, be, s0, q0, s1, q1);
+                            if (m + 1 < p.M) bsum_add(m + 1, n, pre1, mu0, rs0, mu1, rs1, ga, be, s0, q0, s1, q1);
+                        }
+                    }
                     if (slow_stats) {
                         if (m < p.M) {
                             const double d = (double)pre0;
@@ -401,6 +469,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                 }
             }
             if (want_stats) put_stats(n, nok, s0, q0, s1, q1);
+            if (want_bsums) { s0 += (double)bf_a; q0 += (double)bf_b; put_bsums(n, nok, s0, q0, s1, q1); }
         }
         __syncthreads();
         constexpr int TPR = BN / 8;             // threads per row PAIR (8 channels = two 16-byte row segments each)
@@ -456,17 +525,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         const bool nok = n < p.Ng;
         const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
         double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+        float mu0, rs0, mu1, rs1, ga, be, bf_a = 0.f, bf_b = 0.f;
+        bsum_params(n, nok, mu0, rs0, mu1, rs1, ga, be);
         if (fast_stats) fast_sums(j, bv, s0, q0);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (want_bsums && bs_fast && (e & 3) == 0 && e > 0) { s0 += (double)bf_a; q0 += (double)bf_b; bf_a = 0.f; bf_b = 0.f; }
                 if (m < p.M && nok) {
                     if (partial) {
                         p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc[i][j][e];
                     } else {
                         const float pre = acc[i][j][e] + bv;
+                        if (want_bsums) {
+                            if (bs_fast) bsum_add32(m, n, pre, mu0, rs0, ga, be, bf_a, bf_b);
+                            else bsum_add(m, n, pre, mu0, rs0, mu1, rs1, ga, be, s0, q0, s1, q1);
+                        }
                         if (slow_stats) {
                             const double d = (double)pre;
                             if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
@@ -485,6 +561,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             }
         }
         if (want_stats) put_stats(n, nok, s0, q0, s1, q1);
+        if (want_bsums) { s0 += (double)bf_a; q0 += (double)bf_b; put_bsums(n, nok, s0, q0, s1, q1); }
     }
 }
 
@@ -691,9 +768,31 @@ int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const
     return dispatch16<MODE_FWD>(p, d->tuning, st);
 }
 
+// backward sums of the normalisation layer in front from this launch's epilogue (conv_split.hip sscg_convs_bsums_geometry)
+bool sscg_conv16_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, int* wm, int* chunks) {
+    if (!sscg_conv16_dgrad_applies(d) || d->x_dtype != SSCG_BF16 || dgrad16_by_parity(d) || d->stride != 1) return false;
+    const long M = (long)d->N * d->H * d->W;
+    if (G <= 0 || L <= 0 || (long)G * L != M) return false;
+    const int cfg = choose16(M, d->C, d->R * d->S * d->K, d->tuning);
+    if (cfg == CFG_128x32 || L < C16_BM[cfg]) return false;
+    *bm = C16_BM[cfg];
+    *wm = C16_WM[cfg];
+    *chunks = (int)(cdiv(L, (long)C16_BM[cfg]) + 1) * C16_WM[cfg];
+    return true;
+}
+
 int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st) {
+                      void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs) {
     K16Params p = {};
+    bool fused = false;
+    if (bs) {
+        int bm, wm, chunks;
+        if (bias || act != SSCG_ACT_NONE || !sscg_conv16_bsums_geometry(d, bs->G, bs->L, &bm, &wm, &chunks)) return SSCG_ERR_UNSUPPORTED;
+        p.bn_x = reinterpret_cast<const bf16*>(bs->nx); p.bn_mean = bs->mean; p.bn_rstd = bs->rstd; p.bn_gamma = bs->gamma; p.bn_beta = bs->beta;
+        p.bn_sums = reinterpret_cast<double*>(bs->sums); p.bn_L = (int)bs->L; p.bn_G = bs->G; p.bn_chunks = chunks;
+        p.bn_act = bs->act; p.bn_slope = bs->slope;
+        fused = true;
+    }
     p.src = reinterpret_cast<const bf16*>(dy); p.wgt = reinterpret_cast<const bf16*>(wt); p.bias = bias; p.dst = dx;
     p.out_bf16 = d->x_dtype == SSCG_BF16;
     p.M = d->N * d->H * d->W; p.Ng = d->C; p.Cs = d->K; p.Ktot = d->R * d->S * d->K;
@@ -729,6 +828,11 @@ int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, c
         return SSCG_OK;
     }
     K16Split sp = plan16(p.M, p.Ng, p.Ktot, d->tuning);
+    if (fused && sp.splits > 1) {          // fused sums: the launch is not split (its partial tiles would need the sums in the reduction)
+        const int cfg = choose16(p.M, p.Ng, p.Ktot, d->tuning);
+        sp.splits = 1; sp.ksplit = p.Ktot / BK;
+        sp.full_tiles = cdiv(p.M, C16_BM[cfg]) * cdiv(p.Ng, C16_BN[cfg]); sp.m_tail0 = p.M;
+    }
     if (sp.splits > 1 && (!ws || ws_bytes < split16_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);

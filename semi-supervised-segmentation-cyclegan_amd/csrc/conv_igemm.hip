@@ -961,6 +961,36 @@ extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const void* dy, const 
     return dispatch_mode<MODE_DGRAD>(p, (hipStream_t)stream);
 }
 
+// ---- data gradient + the backward sums of the normalisation layer in front (include/sscg.h)
+static bool bsums_geometry(const sscg_conv_desc* d, int G, int64_t L, int* bm, int* wm, int* chunks) {
+    if (check_desc(d) || d->pad_mode != 0) return false;
+    if (sscg_thin1x1_dgrad_applies(d, nullptr, SSCG_ACT_NONE)) return false;
+    if (sscg_conv16_dgrad_applies(d)) return sscg_conv16_bsums_geometry(d, G, (long)L, bm, wm, chunks);
+    return sscg_convs_bsums_geometry(d, G, (long)L, bm, wm, chunks);
+}
+
+extern "C" size_t sscg_conv2d_dgrad_bsums_bytes(const sscg_conv_desc* d, int G, int64_t L) {
+    int bm, wm, chunks;
+    if (!d || !bsums_geometry(d, G, L, &bm, &wm, &chunks)) return 0;
+    return (size_t)G * chunks * d->C * 2 * sizeof(double);
+}
+
+extern "C" int sscg_conv2d_dgrad_bsums(const sscg_conv_desc* d, const void* dy, const void* wt, void* dx, const void* nx,
+                                       const float* mean, const float* rstd, const float* gamma, const float* beta, int G, int64_t L,
+                                       int act, float slope, void* sums, size_t sums_bytes, void* ws, size_t ws_bytes, void* stream) {
+    if (!d || !dy || !wt || !dx || !nx || !mean || !rstd || !sums) return SSCG_ERR_BAD_ARG;
+    if ((gamma != nullptr) != (beta != nullptr)) return SSCG_ERR_BAD_ARG;
+    if (act != SSCG_ACT_NONE && act != SSCG_ACT_RELU && act != SSCG_ACT_LRELU) return SSCG_ERR_UNSUPPORTED;      // the mask is recomputed from nx
+    const size_t need = sscg_conv2d_dgrad_bsums_bytes(d, G, L);
+    if (need == 0) return SSCG_ERR_UNSUPPORTED;
+    if (sums_bytes < need) return SSCG_ERR_WORKSPACE;
+    sscg_bsums bs = {nx, mean, rstd, gamma, beta, sums, G, (long)L, act, slope};
+    if (sscg_conv16_dgrad_applies(d)) return sscg_conv16_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, &bs);
+    return sscg_convs_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, &bs);
+}
+
+bool sscg_bsums_records(const sscg_conv_desc* d, int G, int64_t L, int* bm, int* wm, int* chunks) { return d && bsums_geometry(d, G, L, bm, wm, chunks); }
+
 // [K][RS][C] -> [C][RS][K] (weights are a few MB; one pass per optimiser step per conv that needs dgrad)
 template <typename S, typename D>
 __global__ void krsc_to_crsk_kernel(const S* __restrict__ w, D* __restrict__ wt, int K, int RS, int C) {

@@ -70,6 +70,16 @@ struct KsParams {
     double* __restrict__ stats;      // fused normalisation statistics: [tiles_m * WM][2][Ng][2] doubles, or null
     int stat_L;
     double* __restrict__ xstats;     // host side
+    // data gradient only: the backward sums of the normalisation layer whose OUTPUT this launch differentiates (sscg_conv2d_dgrad_bsums).
+    // dst is dz; per channel n and group g:  sum gg,  sum gg * xhat  with  xhat = (nx - mean) * rstd,  gg = act'(gamma xhat + beta) dz
+    const float* __restrict__ bn_x;      // [M][Ng] the layer's input (pre-normalisation), or null
+    const float* __restrict__ bn_mean;   // [G][Ng]
+    const float* __restrict__ bn_rstd;
+    const float* __restrict__ bn_gamma;  // [Ng] or null
+    const float* __restrict__ bn_beta;
+    double* __restrict__ bn_sums;        // [G][bn_chunks][Ng][2]
+    int bn_L, bn_G, bn_chunks, bn_act;
+    float bn_slope;
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -390,8 +400,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
     // Fused statistics of the normalisation layer that follows (conv_igemm.hip): fp64 column sums of y and y^2 over this tile's
     // rows, four rows at a time in fp32 where the tile lies inside one group and inside the tensor.
     const bool want_stats = p.stats != nullptr && !partial;
+    const bool want_bsums = MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (never with split-K: the host plans these launches unsplit)
     int gb = 0x7fffffff;
     if (want_stats) gb = (m0 / p.stat_L + 1) * p.stat_L;
+    int bg = 0;
+    if (want_bsums) { bg = m0 / p.bn_L; gb = (bg + 1) * p.bn_L; }
     // Every element goes to fp64 (as in the exact-fp32 kernel): the 4-rows-in-fp32 shortcut of the bf16 path moves a BatchNorm
     // statistic by 1e-7, which DeepLab's chained losses amplify to the edge of the parity bound.
     const bool slow_stats = want_stats;
@@ -402,6 +415,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
         const bool nok = n < p.Ng;
         const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
         double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+        float mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f, ga = 1.f, be = 0.f, bfa = 0.f, bfb = 0.f;
+        const bool bs_fast = want_bsums && m0 + BM <= gb;
+        if (want_bsums && nok) {
+            mu0 = p.bn_mean[(size_t)bg * p.Ng + n]; rs0 = p.bn_rstd[(size_t)bg * p.Ng + n];
+            if (bg + 1 < p.bn_G) { mu1 = p.bn_mean[(size_t)(bg + 1) * p.Ng + n]; rs1 = p.bn_rstd[(size_t)(bg + 1) * p.Ng + n]; }
+            if (p.bn_gamma) { ga = p.bn_gamma[n]; be = p.bn_beta[n]; }
+        }
         if (fast_stats) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -432,6 +452,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
                             const double d = (double)pre;
                             if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
                         }
+                        if (want_bsums) {       // norm.hip col_reduce_kernel<RM_BWD>, mask recomputed from the layer's input
+                            const bool lo = m < gb;
+                            const float xh = (p.bn_x[(size_t)m * p.Ng + n] - (lo ? mu0 : mu1)) * (lo ? rs0 : rs1);
+                            const float ym = xh * ga + be;
+                            float gg = pre;
+                            if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? pre : 0.f;
+                            else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? pre : pre * p.bn_slope;
+                            if (bs_fast) {          // tile inside one group: four consecutive rows in fp32, the 4-row sums in fp64
+                                bfa += gg; bfb = fmaf(gg, xh, bfb);
+                            } else {
+                                const double d = (double)gg;
+                                if (lo) { s0 += d; q0 += d * (double)xh; } else { s1 += d; q1 += d * (double)xh; }
+                            }
+                        }
                         size_t row = (size_t)m;
                         if (p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
                             const int img = m / (p.OH * p.OW);
@@ -442,6 +476,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
                         }
                         p.dst[row * p.Ng + n] = sscg_act(pre, p.act, p.slope);
                     }
+                }
+                if (want_bsums && bs_fast && (e & 3) == 3) { s0 += (double)bfa; q0 += (double)bfb; bfa = 0.f; bfb = 0.f; }
+            }
+        }
+        if (want_bsums) {
+            s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+            s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+            if (lh == 0 && nok) {
+                // chunk of group g = (tile row - first tile row of g) * WM + wave row: one writer per (g, chunk, n)
+                const int k0 = (tile_m - (int)(((long)bg * p.bn_L) / BM)) * WM + wm;
+                double* r0 = p.bn_sums + (((size_t)bg * p.bn_chunks + k0) * p.Ng + n) * 2;
+                r0[0] = s0; r0[1] = q0;
+                if (m0 + BM > gb && bg + 1 < p.bn_G) {          // the tile straddles into group g + 1: it is that group's first tile
+                    double* r1 = p.bn_sums + (((size_t)(bg + 1) * p.bn_chunks + wm) * p.Ng + n) * 2;
+                    r1[0] = s1; r1[1] = q1;
                 }
             }
         }
@@ -691,9 +740,33 @@ int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const 
     return dispatch_ks<MODE_FWD>(p, d->tuning, st);
 }
 
+// Backward sums of the normalisation layer in front, from this data gradient's epilogue: plain stride-1 / dilated data gradients of the
+// split family, groups at least one tile tall (a tile then meets at most one group boundary).  The launch is planned WITHOUT the
+// tail split-K (its partial tiles would need the sums in the reduction as well).
+bool sscg_convs_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, int* wm, int* chunks) {
+    if (!sscg_convs_dgrad_applies(d) || ks_dgrad_by_parity(d) || d->stride != 1) return false;
+    const long M = (long)d->N * d->H * d->W;
+    if (G <= 0 || L <= 0 || (long)G * L != M) return false;
+    const int cfg = ks_choose(M, d->C, d->R * d->S * d->K, d->tuning);
+    if (L < KS_BM[cfg]) return false;
+    *bm = KS_BM[cfg];
+    *wm = KS_WM[cfg];
+    *chunks = (int)(cdiv(L, (long)KS_BM[cfg]) + 1) * KS_WM[cfg];
+    return true;
+}
+
 int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                     void* ws, size_t ws_bytes, hipStream_t st) {
+                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs) {
     KsParams p = {};
+    bool fused = false;
+    if (bs) {
+        int bm, wm, chunks;
+        if (bias || act != SSCG_ACT_NONE || !sscg_convs_bsums_geometry(d, bs->G, bs->L, &bm, &wm, &chunks)) return SSCG_ERR_UNSUPPORTED;
+        p.bn_x = reinterpret_cast<const float*>(bs->nx); p.bn_mean = bs->mean; p.bn_rstd = bs->rstd; p.bn_gamma = bs->gamma; p.bn_beta = bs->beta;
+        p.bn_sums = reinterpret_cast<double*>(bs->sums); p.bn_L = (int)bs->L; p.bn_G = bs->G; p.bn_chunks = chunks;
+        p.bn_act = bs->act; p.bn_slope = bs->slope;
+        fused = true;
+    }
     p.src = reinterpret_cast<const float*>(dy); p.wgt = reinterpret_cast<const bf16*>(wt); p.wplane = ks_plane(d);
     p.bias = bias; p.dst = reinterpret_cast<float*>(dx);
     p.M = d->N * d->H * d->W; p.Ng = d->C; p.Cs = d->K; p.Ktot = d->R * d->S * d->K;
@@ -728,7 +801,7 @@ int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, co
         }
         return SSCG_OK;
     }
-    KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, d->tuning);
+    KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, fused ? ((d->tuning & 0xff) | 0x100) : d->tuning);     // fused sums: never split
     if (sp.splits > 1 && (!ws || ws_bytes < ks_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);

@@ -316,9 +316,11 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const double* __res
 }
 
 // c1 = sum_g / L, c2 = sum_g_xhat / L  per (g, c);  dgamma/dbeta += sums (over g)
+// rec_bm > 0: `part` was written by a data gradient's epilogue (sscg_conv2d_dgrad_bsums): group g owns the records of the tile rows
+// that overlap it, rec_wm per tile row, `chunks` apart
 __global__ __launch_bounds__(256) void finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ coef,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C,
-                                                            int chunks, long L, int overwrite) {
+                                                            int chunks, long L, int overwrite, int rec_bm = 0, int rec_wm = 0) {
     __shared__ double sm[512];
     const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
     const bool cok = c < C;
@@ -326,7 +328,9 @@ __global__ __launch_bounds__(256) void finalize_bwd_kernel(const double* __restr
     double tg = 0.0, tb = 0.0;
     for (int g = 0; g < G; ++g) {
         double s, sx;
-        chunk_sum16(part, g, chunks, C, c, cok, sm, s, sx);
+        int nvalid = chunks;
+        if (rec_bm > 0) nvalid = (int)((((long)(g + 1) * L + rec_bm - 1) / rec_bm) - ((long)g * L) / rec_bm) * rec_wm;
+        chunk_sum16(part + (size_t)g * (chunks - nvalid) * C * 2, g, nvalid, C, c, cok, sm, s, sx);
         if (lead) {
             coef[((size_t)g * C + c) * 2] = (float)(s / (double)L);
             coef[((size_t)g * C + c) * 2 + 1] = (float)(sx / (double)L);
@@ -768,6 +772,37 @@ extern "C" int sscg_norm_bwd(const void* dy, const void* x, const void* y, const
     q.dy = dy; q.x = x; q.y = y; q.mean = mean; q.rstd = rstd; q.gamma = gamma; q.beta = beta;
     q.coef = stats_grad ? coef : nullptr;
     q.dx = dx; q.dres = dres; q.L = L; q.C = C; q.act = act; q.slope = slope;
+    const int vec = vec_for(C, dtype);
+    if ((size_t)G * L * C / vec >= ((size_t)1 << 31)) return SSCG_ERR_UNSUPPORTED;
+    q.total = (uint32_t)((size_t)G * L * C / vec);
+    q.div_cg = make_fastdiv(C / vec);
+    q.div_l = make_fastdiv((int)L);
+    if (dtype == SSCG_BF16) launch_bwd_apply<__bf16>(q, vec, st);
+    else launch_bwd_apply<float>(q, vec, st);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+// Backward of y = act(norm(x)) (batch statistics, no residual) whose per-channel sums were already taken by the data gradient that
+// produced dy (sscg_conv2d_dgrad_bsums with descriptor d): finalize + apply only - the reduction pass over (dy, x) is gone.
+extern "C" int sscg_norm_bwd_from_sums(const sscg_conv_desc* d, const void* sums, const void* dy, const void* x, const float* mean,
+                                       const float* rstd, const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta,
+                                       int dtype, int G, int64_t L, int C, int act, float slope, int flags, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    if (!d || !sums || !dy || !x || !mean || !rstd || !dx || G <= 0 || L <= 0 || C <= 0 || (dtype != SSCG_F32 && dtype != SSCG_BF16)) return SSCG_ERR_BAD_ARG;
+    if (act != SSCG_ACT_NONE && act != SSCG_ACT_RELU && act != SSCG_ACT_LRELU) return SSCG_ERR_UNSUPPORTED;
+    int bm, wm, chunks;
+    if (!sscg_bsums_records(d, G, L, &bm, &wm, &chunks) || d->C != C) return SSCG_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < (size_t)G * C * 2 * sizeof(float)) return SSCG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(finalize_bwd_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, st, reinterpret_cast<const double*>(sums), coef, dgamma,
+                       dbeta, G, C, chunks, (long)L, (flags >> 1) & 1, bm, wm);
+    SSCG_LAUNCH_CHECK();
+    BwdApplyParams q = {};
+    q.dy = dy; q.x = x; q.y = nullptr; q.mean = mean; q.rstd = rstd; q.gamma = gamma; q.beta = beta;
+    q.coef = coef;
+    q.dx = dx; q.dres = nullptr; q.L = L; q.C = C; q.act = act; q.slope = slope;
     const int vec = vec_for(C, dtype);
     if ((size_t)G * L * C / vec >= ((size_t)1 << 31)) return SSCG_ERR_UNSUPPORTED;
     q.total = (uint32_t)((size_t)G * L * C / vec);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/sscg.h"
 
+struct sscg_bsums;
 // conv_bf16.hip: bf16 MFMA kernels behind sscg_conv2d_{fwd,dgrad,wgrad} (dispatch lives in conv_igemm.hip / conv_wgrad.hip)
 bool sscg_conv16_fwd_applies(const sscg_conv_desc* d);
 bool sscg_conv16_dgrad_applies(const sscg_conv_desc* d);
@@ -13,7 +14,8 @@ size_t sscg_conv16_dgrad_workspace(const sscg_conv_desc* d);
 int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
                     double* xstats, void* ws, size_t ws_bytes, hipStream_t st);
 int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st);
+                      void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs = nullptr);
+bool sscg_conv16_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, int* wm, int* chunks);
 bool sscg_wgrad16_applies(const sscg_conv_desc* d);
 size_t sscg_wgrad16_workspace(const sscg_conv_desc* d);
 int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, size_t ws_bytes, hipStream_t st);
@@ -25,8 +27,24 @@ size_t sscg_convs_fwd_workspace(const sscg_conv_desc* d, long stat_L);
 size_t sscg_convs_dgrad_workspace(const sscg_conv_desc* d);
 int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
                    double* xstats, void* ws, size_t ws_bytes, hipStream_t st);
+// the backward sums of the normalisation layer whose output a data gradient differentiates, taken in that launch's epilogue
+struct sscg_bsums {
+    const void* nx;          // the layer's input [G * L][C]
+    const float* mean;       // [G][C]
+    const float* rstd;
+    const float* gamma;      // [C] or null
+    const float* beta;
+    void* sums;              // [G][chunks][C][2] doubles (sscg_convs_bsums_geometry)
+    int G;
+    long L;
+    int act;
+    float slope;
+};
+bool sscg_convs_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, int* wm, int* chunks);
 int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                     void* ws, size_t ws_bytes, hipStream_t st);
+                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs = nullptr);
+// conv_igemm.hip: record geometry of sscg_conv2d_dgrad_bsums for this descriptor (false = the fusion does not apply)
+bool sscg_bsums_records(const sscg_conv_desc* d, int G, int64_t L, int* bm, int* wm, int* chunks);
 int sscg_krsc_to_crsk_split(const float* w, void* wt, int K, int RS, int C, hipStream_t st);
 // weight gradient by the split contraction on pre-split scratch planes (precision = 2, >= 128 x 128 outputs)
 bool sscg_wgrads_applies(const sscg_conv_desc* d);

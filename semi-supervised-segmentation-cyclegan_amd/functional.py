@@ -354,6 +354,12 @@ def to_nchw(x):
 F32_SPLIT = [os.environ.get("SSCG_F32_SPLIT", "1") == "1"]
 _MODE = ["f32s" if F32_SPLIT[0] else "f32"]
 FUSE_STATS = [os.environ.get("SSCG_FUSE_STATS", "1") != "0"]    # norm statistics from the producing conv's epilogue (K3/K4)
+# The reduction pass of a norm layer's backward from the epilogue of the data gradient that produces its upstream gradient
+# (sscg_conv2d_dgrad_bsums).  Built, tested (fp32 and bf16), and OFF: it removes 260 col_reduce launches per step
+# but loses on the clock - config 2 142.3 -> 143.1 ms, config 3 187.9 -> 189.8 ms (profiles/r04_experiments.txt item 3): the sums'
+# scattered loads of the layer's input and their fp64 tail sit in the epilogue of kernels on the critical lanes, while the streaming
+# reduction pass they replace ran beside them.
+FUSE_BSUMS = [os.environ.get("SSCG_FUSE_BSUMS", "0") == "1"]
 
 
 def set_conv_precision(mode):
@@ -639,19 +645,39 @@ def dgrad_operand(w, xshape, stride, pad, dil, dy_dtype=torch.float32):
     return weight_transposed(w, torch.float32)
 
 
-def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0, out_dtype=torch.float32):
+def _bsums_bytes(d, g, l):
+    key = (id(d), "bsums", g, l)
+    v = _PLAN_SIZES.get(key)
+    if v is None:
+        v = _PLAN_SIZES[key] = lib.sscg_conv2d_dgrad_bsums_bytes(C.byref(d), g, l)
+    return v
+
+
+def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0, out_dtype=torch.float32, bsums=None):
     """dx = act(dgrad(dy, wt) + bias); `wt` is the transposed operand copy [C][R][S][K] (weight_transposed), fp32 for an
-    fp32 dy, bf16 for a bf16 dy."""
+    fp32 dy, bf16 for a bf16 dy.
+    bsums = (nx, mean, rstd, gamma, beta, (G, L, C), act, slope): dx is the gradient at the output of act(norm(nx)); the launch also
+    takes that layer's backward sums in its epilogue.  Returns (dx, records) then - records None where the library does not fuse
+    the geometry (the caller runs the ordinary reduction pass)."""
     wdt = BF16X3 if (wt.dim() == 1 and wt.dtype == torch.bfloat16) else _dt(wt)      # the split copy is a flat tensor of three planes
     d = make_desc(xshape, wshape, stride, pad, dil, xdt=_DT[out_dtype], wdt=wdt, ydt=_dt(dy), prec=_prec("dgrad"))
     dx = empty_nhwc(d.N, d.C, d.H, d.W, dy.device, out_dtype)
     ws = _WS.get(_ws_bytes(d, "dgrad"), dy.device)
+    if bsums is not None:
+        nx, mean, rstd, gamma, beta, (g, l, c), nact, nslope = bsums
+        nb = _bsums_bytes(d, g, l) if (bias is None and act == ACT_NONE and c == d.C and nx.dtype == out_dtype and dy.dtype == out_dtype) else 0
+        if nb:
+            sums = torch.empty(nb, dtype=torch.uint8, device=dy.device)
+            _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad_bsums(
+                C.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), nx.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
+                _ptr(beta), g, l, nact, nslope, sums.data_ptr(), nb, ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_dgrad_bsums"))
+            return dx, (d, sums)
     _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wt.data_ptr(), _ptr(bias), dx.data_ptr(),
                                                            act, slope, ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_dgrad"))
-    return dx
+    return dx if bsums is None else (dx, None)
 
 
-def conv2d_dgrad_param(dy, w, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0, out_dtype=torch.float32):
+def conv2d_dgrad_param(dy, w, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NONE, slope=0.0, out_dtype=torch.float32, bsums=None):
     """conv2d_dgrad with the transposed operand copy of parameter `w` taken from the per-parameter cache, in the element
     type the kernel for dy reads (bf16 tiles for a bf16 dy, fp32 otherwise)."""
     if dy.dtype == torch.bfloat16:
@@ -663,7 +689,7 @@ def conv2d_dgrad_param(dy, w, xshape, wshape, stride, pad, dil, bias=None, act=A
         wt = _cached_wt(w, "x3")
     else:
         wt = _cached_wt(w, torch.float32)
-    return conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias, act, slope, out_dtype)
+    return conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias, act, slope, out_dtype, bsums)
 
 
 def conv2d_wgrad(x, dy, wshape, stride, pad, dil, pad_mode=PAD_ZEROS, out=None, accumulate=False):
@@ -749,6 +775,19 @@ def norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad=Tru
                             dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _same_dtype(x, dy, y), g, l, c, act, slope,
                             (1 if stats_grad else 0) | (2 if overwrite else 0), ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_bwd")
     return dx, dres
+
+
+def norm_bwd_from_sums(rec, dy, x, mean, rstd, gamma, beta, per_sample, act, slope, dgamma=None, dbeta=None):
+    """norm_bwd (batch statistics, mask recomputed from x, gradients of gamma / beta written) for a dy whose backward sums the data
+    gradient that produced it already took (conv2d_dgrad(..., bsums=)): finalize + apply."""
+    d, sums = rec
+    g, l, c = _glc(x, per_sample)
+    dx = torch.empty_like(x, memory_format=CL)
+    ws = _WS.get(g * c * 8, x.device)
+    check(lib.sscg_norm_bwd_from_sums(C.byref(d), sums.data_ptr(), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
+                                      _ptr(beta), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), _same_dtype(x, dy), g, l, c, act, slope, 2,
+                                      ws.data_ptr(), ws.numel(), _stream()), "sscg_norm_bwd_from_sums")
+    return dx
 
 
 def norm_head_applies(c):
@@ -1218,7 +1257,17 @@ def _conv_backward(dy, x, w, wref, bref, geom, want_x, want_w, want_b):
     if want_x:
         if pad_mode == PAD_REFLECT:
             raise _lib.SscgError("input gradient through a reflection-padded conv: use ReflectPadFn + pad=0 conv")
-        dx = conv2d_dgrad_param(dy, wref, x.shape, w.shape, stride, pad, dil, out_dtype=x.dtype)
+        # x is the output of a conv -> norm -> activation unit that left its normalisation context on the tensor (ConvNormActFn):
+        # this data gradient IS that unit's upstream gradient, so its epilogue takes the unit's backward sums and the reduction pass
+        # over (dz, y) never runs.  The records travel on dx and are only honoured if dx arrives unchanged (`_version`): an
+        # accumulation by the autograd engine (a tensor with two consumers) bumps it.
+        info = getattr(x, "_sscg_norm", None) if (FUSE_BSUMS[0] and stride == 1 and x.dtype == dy.dtype) else None
+        if info is not None:
+            dx, rec = conv2d_dgrad_param(dy, wref, x.shape, w.shape, stride, pad, dil, out_dtype=x.dtype, bsums=info)
+            if rec is not None:
+                dx._sscg_bsums = (rec, dx._version)
+        else:
+            dx = conv2d_dgrad_param(dy, wref, x.shape, w.shape, stride, pad, dil, out_dtype=x.dtype)
     wacc = _acc_target(wref) if want_w else None
     bacc = _acc_target(bref) if want_b else None
     n, k, p, q = dy.shape
@@ -1351,8 +1400,12 @@ def _norm_backward(dy, x, y, mean, rstd, gamma, beta, gref, betaref, per_sample,
         if gacc is None or bacc is None:
             gacc = bacc = None
             ret_g, ret_b = dgamma, dbeta
-    dx, dres = norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad,
-                        want_dres=want_dres, dgamma=dgamma, dbeta=dbeta, beta=beta, overwrite=True)
+    rec = getattr(dy, "_sscg_bsums", None)
+    if rec is not None and rec[1] == dy._version and y is None and stats_grad and not want_dres and act in (ACT_NONE, ACT_RELU, ACT_LRELU):
+        dx, dres = norm_bwd_from_sums(rec[0], dy, x, mean, rstd, gamma, beta, per_sample, act, slope, dgamma, dbeta), None
+    else:
+        dx, dres = norm_bwd(dy, x, y, mean, rstd, gamma, per_sample, act, slope, stats_grad,
+                            want_dres=want_dres, dgamma=dgamma, dbeta=dbeta, beta=beta, overwrite=True)
     if gacc is not None:
         # The sums were produced beside dx on this stream; their accumulation into the optimiser's arena runs on the
         # parameter's own side lane, like every other gradient of that parameter (two forward lanes may both reach
@@ -1399,6 +1452,9 @@ class ConvNormActFn(torch.autograd.Function):
         ctx.wref, ctx.bref, ctx.gref, ctx.betaref = w, bias, gamma, beta
         need_z = act != ACT_NONE and (residual is not None or act not in (ACT_RELU, ACT_LRELU))
         ctx.save_for_backward(x, w, y, z if need_z else None, mean, rstd, gamma, beta)
+        if FUSE_BSUMS[0] and not need_z and residual is None:
+            # for the consumer's data gradient (_conv_backward): what this unit's backward reduction needs besides dz
+            z._sscg_norm = (y, mean, rstd, gamma, beta, (g, l, c), act, slope)
         return z
 
     @staticmethod

@@ -101,11 +101,12 @@ def test_deeplab_forward_split_vs_exact_vs_fp64(name, dev):
     _, kind, args, xshape = net
     e = {}
     old = F.get_conv_precision()
+    weights = FX.net_weights(name, kind, args)
     try:
         for mode in ("f32x", "f32s"):
             F.set_conv_precision(mode)
             m = build(kind, args, dev)
-            m.load_state_dict(FX.net_weights(name, kind, args), strict=True)
+            m.load_state_dict(weights, strict=True)
             m.train()
             with torch.no_grad():
                 y = m(FX.net_input(name, xshape).to(dev))

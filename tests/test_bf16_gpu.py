@@ -666,3 +666,54 @@ def test_full_size_bf16_step_agrees_with_fp32(geom, dev):
         print("%-20s bf16 %.6f fp32 %.6f rel %.2e" % (k, a, b, e))
         assert np.isfinite(a) and np.isfinite(b), k
         assert e < (1e-1 if k in ("img_cycle_loss", "gt_cycle_loss", "cycle_img_dis_loss") else 5e-2), k
+
+
+@pytest.mark.parametrize("case", [("instance", 3, 64, 20, 24, 128, 3, 1, 1), ("batch", 2, 128, 33, 33, 128, 1, 0, 1), ("batch2", 4, 64, 17, 19, 256, 3, 2, 2),
+                                  ("batch", 8, 256, 33, 33, 64, 1, 0, 1)], ids=lambda c: "%s_n%d_c%d_%dx%d_k%d_r%d_p%d_d%d" % c)
+def test_norm_backward_sums_fused_into_the_bf16_data_gradient(case, dev, bf16_mode):
+    """tests/test_kernels_gpu.py::test_norm_backward_sums_fused_into_the_data_gradient on bf16 tensors (conv16_kernel's epilogue).  The
+    fused sums are taken from the fp32 accumulators, the reduction pass reads the bf16-rounded dz: the two routes differ by that
+    rounding (|diff| <= 2e-2 of the tensor's scale on dx; the per-channel parameter gradients, sums over thousands of rows, 5e-3)."""
+    F = bf16_mode
+    ops = load_sub("arch.ops")
+    arch = load_sub("arch")
+    norm, n, c, h, w, k, r, pad, dil = case
+    torch.manual_seed(5)
+    stem = ops.Conv2d(3, 64, 3, 1, 1).to(dev)          # fp32 image in, bf16 activations from here on
+    conv_a = ops.Conv2d(64, c, 3, 1, 1, bias=(norm == "instance")).to(dev)
+    nl = ops.InstanceNorm2d(c).to(dev) if norm == "instance" else ops.BatchNorm2d(c).to(dev)
+    conv_b = ops.Conv2d(c, k, r, 1, pad, dilation=dil, bias=False).to(dev)
+    x0 = torch.randn(n, 3, h, w)
+    gy = None
+    outs, used = [], []
+    real = F.norm_bwd_from_sums
+    for fused in (True, False):
+        F.FUSE_BSUMS[0] = fused
+        calls = []
+        F.norm_bwd_from_sums = lambda *aa, **kk: (calls.append(1), real(*aa, **kk))[1]
+        try:
+            for p in list(stem.parameters()) + list(conv_a.parameters()) + list(nl.parameters()) + list(conv_b.parameters()):
+                p.grad = None
+            if norm != "instance":
+                nl.running_mean.zero_(); nl.running_var.fill_(1.0)
+            x = x0.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            with arch.batch_groups(2 if norm == "batch2" else 1):
+                z = ops.conv_norm_act(conv_a, nl, stem(x), F.ACT_RELU)
+            assert z.dtype == torch.bfloat16
+            out = conv_b(z)
+            if gy is None:
+                gy = torch.randn(out.shape).to(dev).contiguous(memory_format=torch.channels_last).to(out.dtype)
+            F.backward((out.float() * gy.float()).sum())
+            F.SideStream.join(dev)
+            torch.cuda.synchronize()
+            outs.append([x.grad.float().clone(), conv_a.weight.grad.float().clone()] +
+                        ([nl.weight.grad.clone(), nl.bias.grad.clone()] if norm != "instance" else []))
+            used.append(len(calls))
+        finally:
+            F.FUSE_BSUMS[0] = True
+            F.norm_bwd_from_sums = real
+    assert used == [1, 0], used
+    for i, (t_f, t_u) in enumerate(zip(*outs)):
+        e = float((t_f.double() - t_u.double()).abs().max()) / (float(t_u.double().abs().max()) + 1e-12)
+        print("tensor %d: fused vs reduction pass %.2e" % (i, e))
+        assert e <= (2e-2 if i < 2 else 5e-3), (i, e)

