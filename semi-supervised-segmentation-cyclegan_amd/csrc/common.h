@@ -156,3 +156,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel that wants more than 64 KB of dynamic LDS: set when the request grows, not on
+// every launch (the call costs the host 1-2 us; the step issues ~1000 such launches).  One static per call site = per template
+// instantiation; two threads racing here set the same value twice.
+#define SSCG_ENSURE_SMEM(kern, smem)                                                                                                   \
+    do {                                                                                                                               \
+        static size_t sscg_attr_smem_ = 64 * 1024;                                                                                     \
+        if ((size_t)(smem) > sscg_attr_smem_) {                                                                                        \
+            hipError_t sscg_e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                     (int)(smem));                                                                     \
+            if (sscg_e_ != hipSuccess) return (int)sscg_e_;                                                                            \
+            sscg_attr_smem_ = (size_t)(smem);                                                                                          \
+        }                                                                                                                              \
+    } while (0)

@@ -673,10 +673,7 @@ int launch16(const K16Params& p0, hipStream_t st) {
     const size_t stage = BN >= 64 ? (size_t)(BM / 2) * (BN + 4) * sizeof(uint32_t) : 0;      // output tile of the staged epilogue (bf16 row pairs)
     if (stage > smem) smem = stage;
     auto kern = conv16_kernel<MODE, WM, WN, TM, TN, NSTAGE>;
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
+    SSCG_ENSURE_SMEM((kern), smem);
     if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);
@@ -1327,10 +1324,7 @@ int launch_wg16(Wg16Params p, int splits, hipStream_t st) {
     p.splits = splits;
     const size_t smem = (size_t)(2 * BM * BKP + 2 * BN * BKP) * sizeof(bf16);
     auto kern = wgrad16_kernel<WM, WN, TM, TN>;
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
+    SSCG_ENSURE_SMEM((kern), smem);
     hipLaunchKernelGGL(kern, dim3(p.tiles * splits), dim3(256), smem, st, p);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
@@ -1346,10 +1340,7 @@ int launch_wg16t(Wg16Params p, int splits, hipStream_t st) {
     const size_t smem = (size_t)NSTAGE * BKP * (BM + BN) * sizeof(bf16);
     constexpr int NT = WM * WN * 64;
     auto kern = wgrad16t_kernel<WM, WN, TM, TN, NSTAGE>;
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
+    SSCG_ENSURE_SMEM((kern), smem);
     hipLaunchKernelGGL(kern, dim3(p.tiles * splits), dim3(NT), smem, st, p);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;

@@ -695,10 +695,7 @@ int launch_kc(const KcParams& p0, hipStream_t st) {
     constexpr int LDR = DMA ? BK : LDK;
     size_t smem = (size_t)(NBUF * BM * LDR + NBUF * BN * LDR) * sizeof(float) + (size_t)(p.R * p.S > 0 ? p.R * p.S : 1) * 8;
     auto kern = conv_kc_kernel<MODE, WM, WN, TM, TN, VEC, FAST, NBUF, DMA, BF16, N4>;
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
+    SSCG_ENSURE_SMEM((kern), smem);
     if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);

@@ -604,10 +604,7 @@ int launch_ks(const KsParams& p0, hipStream_t st) {
     p.tiles = cdiv(p.M, BM) * p.tiles_n;
     const size_t smem = (size_t)2 * (BM * 128 + 3 * BN * 64);
     auto kern = convs_kernel<MODE, WM, WN, TM, TN>;
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
+    SSCG_ENSURE_SMEM((kern), smem);
     if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);

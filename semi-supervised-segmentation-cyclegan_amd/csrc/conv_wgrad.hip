@@ -431,10 +431,7 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
     p.splits = splits;
     size_t smem = (size_t)(2 * BKP * (DMA ? BM : BM + 4) + 2 * BKP * (DMA ? BN : BN + 4)) * sizeof(float);
     auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VA, VB, DMA, BF16, TX, TY>;
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
+    SSCG_ENSURE_SMEM((kern), smem);
     hipLaunchKernelGGL(kern, dim3(p.tiles * splits), dim3(256), smem, st, p);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
@@ -584,10 +581,7 @@ bool thin_wgrad_applies(const sscg_conv_desc* d) {
 
 template <int T, typename TW, typename TT>
 int launch_thin(const ThinParams& p, int blocks, size_t smem, hipStream_t st) {
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(thin_wgrad_kernel<T, TW, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
+    SSCG_ENSURE_SMEM((thin_wgrad_kernel<T, TW, TT>), smem);
     hipLaunchKernelGGL((thin_wgrad_kernel<T, TW, TT>), dim3(blocks), dim3(256), smem, st, p);
     return SSCG_OK;
 }
