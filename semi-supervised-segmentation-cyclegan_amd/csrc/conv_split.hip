@@ -31,6 +31,9 @@ namespace {
 #ifndef KS_ABLATE
 #define KS_ABLATE 0        // tools/: timing ablations of the k-loop (1 = no copies after the prologue, 2 = no operand split, 4 = no barrier / copy wait); WRONG results
 #endif
+#ifndef KS_BUFLD
+#define KS_BUFLD 1         // LDS-DMA copies as `buffer_load_dwordx4 ... offen lds`: per-lane row offset in ONE VGPR (computed once per tap), the k-tile's
+#endif                     // chunk offset in an SGPR - no 64-bit VALU address arithmetic per copy (0 = global_load_lds with 64-bit addresses)
 constexpr int BKS = 32;                    // k per tile
 typedef __bf16 bf16;
 typedef uint32_t u32;
@@ -70,6 +73,7 @@ struct KsParams {
     double* __restrict__ stats;      // fused normalisation statistics: [tiles_m * WM][2][Ng][2] doubles, or null
     int stat_L;
     double* __restrict__ xstats;     // host side
+    unsigned src_bytes, wgt_bytes;   // extents of the two buffer resources (< 2 GB: a masked row's offset 0x80000000 is out of range = zeros)
     // data gradient only: the backward sums of the normalisation layer whose OUTPUT this launch differentiates (sscg_conv2d_dgrad_bsums).
     // dst is dz; per channel n and group g:  sum gg,  sum gg * xhat  with  xhat = (nx - mean) * rstd,  gg = act'(gamma xhat + beta) dz
     const float* __restrict__ bn_x;      // [M][Ng] the layer's input (pre-normalisation), or null
@@ -130,7 +134,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
     const int rb0 = tid >> 2;                                  // B row inside a pass
     const int kqb = (tid & 3) ^ ((rb0 >> 2) & 3);
 
+#if KS_BUFLD
+    unsigned arow[PA];                                         // byte offset of the row's image inside src
+#else
     const float* arow[PA];
+#endif
     int ay0[PA], ax0[PA];
     bool aok[PA];
 #pragma unroll
@@ -142,7 +150,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
         const int rem = mm - img * (p.OH * p.OW);
         const int oy = rem / p.OW;
         const int ox = rem - oy * p.OW;
+#if KS_BUFLD
+        arow[ps] = (unsigned)img * (unsigned)(p.SH * p.SW * p.Cs) * 4u;
+#else
         arow[ps] = p.src + (size_t)img * p.SH * p.SW * p.Cs;
+#endif
         if (MODE == MODE_FWD) {
             ay0[ps] = oy * p.stride - p.pad;
             ax0[ps] = ox * p.stride - p.pad_x;
@@ -152,11 +164,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
         }
     }
     // weight rows past Ng are clamped to the last row: their products land in output columns that are never stored
+#if KS_BUFLD
+    unsigned brow[HB];                                         // byte offset of the lane's 16-byte piece of its weight row (plane 0, k = 0)
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, (short)0, (int)p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, (short)0, (int)p.wgt_bytes, 0x00020000);
+#else
     const bf16* brow[HB];
+#endif
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) {
         const int n = n0 + rb0 + hb * RPB;
+#if KS_BUFLD
+        brow[hb] = ((unsigned)(n < p.Ng ? n : p.Ng - 1) * (unsigned)p.wKtot + kqb * 8) * 2u;
+#else
         brow[hb] = p.wgt + (size_t)(n < p.Ng ? n : p.Ng - 1) * p.wKtot + kqb * 8;
+#endif
     }
 
     const bool reflect = p.pad_mode == 1;
@@ -202,9 +224,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
         f_kx = tap0 - f_ky * p.S;
     }
     int f_k = 0;
+#if KS_BUFLD
+    unsigned aptr[PA];
+#else
     const float* aptr[PA];
-    int dma_stage = 0;
     const float* const zero = sscg_zero_page_s;
+#endif
+    int dma_stage = 0;
 
     auto set_tap = [&]() {
         const int tdy = f_ky * p.dil, tdx = f_kx * p.dil;
@@ -213,7 +239,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
         for (int ps = 0; ps < PA; ++ps) {
             int pix;
             const bool ok = locate(ps, tdy, tdx, pix);
+#if KS_BUFLD
+            aptr[ps] = ok ? arow[ps] + ((unsigned)pix * (unsigned)p.Cs + kqa * 4) * 4u : 0x80000000u;      // out of range: the copy delivers zeros
+#else
             aptr[ps] = ok ? arow[ps] + (size_t)pix * p.Cs + kqa * 4 : zero + kqa * 4;
+#endif
         }
     };
     set_tap();
@@ -231,6 +261,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
             set_tap();
         }
         if ((KS_ABLATE & 1) && f_k > 2 * BKS) { dma_stage ^= 1; ++f_chunk; f_k += BKS; return; }
+#if KS_BUFLD
+        const int so_a = __builtin_amdgcn_readfirstlane(f_chunk * (BKS * 4));
+#pragma unroll
+        for (int q = 0; q < PA; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds0 + dma_stage * A_STAGE + lds_wave + q * (RPA * 128)),
+                                                     16, (int)aptr[q], so_a, 0, 0);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const int so_b = __builtin_amdgcn_readfirstlane((int)((pl * p.wplane + f_k) * 2));
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + dma_stage * B_STAGE +
+                                                                                                        pl * B_PLANE + lds_wave + hb * (RPB * 64)),
+                                                         16, (int)brow[hb], so_b, 0, 0);
+        }
+#else
 #pragma unroll
         for (int q = 0; q < PA; ++q) {
             const float* g = aptr[q] + f_chunk * BKS;
@@ -247,6 +293,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
                                                                                             lds_wave + hb * (RPB * 64)), 16, 0, 0);
             }
         }
+#endif
         dma_stage ^= 1;
         ++f_chunk;
         f_k += BKS;
@@ -686,14 +733,21 @@ __global__ void krsc_to_crsk_split_kernel(const float* __restrict__ w, bf16* __r
 }  // namespace
 
 // ---- entry points used by conv_igemm.hip's dispatch
+// the copies address both operands through 32-bit buffer offsets, a masked row's offset (2 GB) must lie outside the tensor
+static bool ks_extents_ok(const sscg_conv_desc* d, bool dgrad) {
+    const size_t src = (dgrad ? (size_t)d->N * d->P * d->Q * d->K : (size_t)d->N * d->H * d->W * d->C) * sizeof(float);
+    const size_t wgt = ((size_t)2 * ks_plane(d) + (size_t)d->K * d->R * d->S * d->C) * sizeof(bf16);
+    return src < ((size_t)1 << 31) && wgt < ((size_t)1 << 31);
+}
+
 bool sscg_convs_fwd_applies(const sscg_conv_desc* d) {
     return d->x_dtype == SSCG_F32 && d->w_dtype == SSCG_BF16X3 && d->y_dtype == SSCG_F32 && d->C % BKS == 0 && d->C <= 4096 &&
-           d->K >= 32 && d->K % 4 == 0;
+           d->K >= 32 && d->K % 4 == 0 && ks_extents_ok(d, false);
 }
 
 bool sscg_convs_dgrad_applies(const sscg_conv_desc* d) {
     return d->y_dtype == SSCG_F32 && d->w_dtype == SSCG_BF16X3 && d->x_dtype == SSCG_F32 && d->K % BKS == 0 && d->K <= 4096 && d->C >= 32 && d->C % 4 == 0 &&
-           d->pad_mode == 0;
+           d->pad_mode == 0 && ks_extents_ok(d, true);
 }
 
 bool sscg_convs_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* wm, int* tiles_n, int* splits, int* full_tiles, int* m_tail0) {
@@ -729,6 +783,8 @@ int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const 
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = d->pad_mode; p.act = d->act; p.slope = d->slope;
     p.stats = stats; p.stat_L = (int)stat_L; p.xstats = xstats;
+    p.src_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->C * sizeof(float));
+    p.wgt_bytes = (unsigned)(((size_t)2 * p.wplane + (size_t)d->K * d->R * d->S * d->C) * sizeof(bf16));
     ks_dense_taps(p);
     KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, d->tuning, stats ? stat_L : 0);
     if (sp.splits > 1 && (!ws || ws_bytes < ks_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
@@ -770,6 +826,8 @@ int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, co
     p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.pad_mode = 0; p.act = act; p.slope = slope;
+    p.src_bytes = (unsigned)((size_t)d->N * d->P * d->Q * d->K * sizeof(float));
+    p.wgt_bytes = (unsigned)(((size_t)2 * p.wplane + (size_t)d->K * d->R * d->S * d->C) * sizeof(bf16));
     ks_dense_taps(p);
     if (ks_dgrad_by_parity(d)) {
         // stride 2: four parity classes, each a stride-1 data gradient over its sub-lattice of taps (conv_igemm.hip)

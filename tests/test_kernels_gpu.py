@@ -926,7 +926,7 @@ def test_norm_backward_sums_fused_into_the_data_gradient(case, act, dev):
     x0 = torch.randn(n, 32, h, w)
     gy = None
     outs, used = [], []
-    real = F.norm_bwd_from_sums
+    real, was = F.norm_bwd_from_sums, F.FUSE_BSUMS[0]
     for fused in (True, False):
         F.FUSE_BSUMS[0] = fused
         calls = []
@@ -949,7 +949,7 @@ def test_norm_backward_sums_fused_into_the_data_gradient(case, act, dev):
             outs.append([x.grad.clone(), conv_a.weight.grad.clone()] + ([nl.weight.grad.clone(), nl.bias.grad.clone()] if norm != "instance" else []))
             used.append(len(calls))
         finally:
-            F.FUSE_BSUMS[0] = True
+            F.FUSE_BSUMS[0] = was
             F.norm_bwd_from_sums = real
     assert used == [1, 0], used          # the fused route was taken exactly when it was on
     for t_f, t_u in zip(*outs):

@@ -39,8 +39,11 @@ for n, c, h, w, k in SHAPES:
     flops = 2.0 * n * h * w * c * k
     row = "%-28s" % ("%dx%dx%d c%d k%d" % (n, h, w, c, k))
     ref = None
-    for name, cls in (("fused", None), ("on-the-fly", 2), ("planes", 3)):
-        old = F.tuning(wgrad_class=cls)
+    variants = (("fused", None, 0), ("on-the-fly", 2, 0), ("planes", 3, 0))
+    if os.environ.get("WGF_SPLITS"):        # sweep of the fused kernel's pixel splits
+        variants = tuple(("fused/%s" % sp, None, int(sp)) for sp in os.environ["WGF_SPLITS"].split(","))
+    for name, cls, nsplit in variants:
+        old = F.tuning(wgrad_class=cls, wgrad_splits=nsplit)
         try:
             dw = F.conv2d_wgrad(x, dy, (k, c, 1, 1), 1, 0, 1)
             t = timeit(lambda: F.conv2d_wgrad(x, dy, (k, c, 1, 1), 1, 0, 1))
