@@ -33,6 +33,9 @@ __device__ float sscg_zero_page16[64];
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
+#ifndef K16_BUFLD
+#define K16_BUFLD 1        // LDS-DMA copies as buffer loads: row offset in one VGPR per copy row (per tap), chunk offset in an SGPR (conv_split.hip KS_BUFLD)
+#endif
 struct K16Params {
     const bf16* __restrict__ src;    // A source (input for fwd, dy for dgrad), NHWC bf16
     const bf16* __restrict__ wgt;    // [Ng][wKtot] bf16
@@ -55,6 +58,7 @@ struct K16Params {
     double* __restrict__ stats;
     int stat_L;                      // rows per normalisation group (a tile spans at most two groups: stat_L >= BM)
     double* __restrict__ xstats;     // host side: records of the split rows ([blocks][Ng][2]), written by the split reduction
+    unsigned src_bytes, wgt_bytes;   // extents of the two buffer resources (< 2 GB: offset 0x80000000 = out of range = zeros)
     // data gradient only: the backward sums of the normalisation layer whose OUTPUT this launch differentiates (conv_split.hip KsParams)
     const bf16* __restrict__ bn_x;       // [M][Ng] the layer's input (pre-normalisation), or null
     const float* __restrict__ bn_mean;   // [G][Ng]
@@ -115,7 +119,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
     const int kq = (tid & 7) ^ swz(r0);             // 16-byte k slot this lane fetches: lands at LDS slot tid & 7 of row r0
     const int wave_id = tid >> 6;
 
+#if K16_BUFLD
+    unsigned arow[PA];
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, (short)0, (int)p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, (short)0, (int)p.wgt_bytes, 0x00020000);
+#else
     const bf16* arow[PA];
+#endif
     int ay0[PA], ax0[PA];
     bool aok[PA];
 #pragma unroll
@@ -127,7 +137,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         const int rem = mm - img * (p.OH * p.OW);
         const int oy = rem / p.OW;
         const int ox = rem - oy * p.OW;
+#if K16_BUFLD
+        arow[ps] = (unsigned)img * (unsigned)(p.SH * p.SW * p.Cs) * 2u;
+#else
         arow[ps] = p.src + (size_t)img * p.SH * p.SW * p.Cs;
+#endif
         if (MODE == MODE_FWD) {
             ay0[ps] = oy * p.stride - p.pad;
             ax0[ps] = ox * p.stride - p.pad_x;
@@ -136,13 +150,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             ax0[ps] = ox + p.pad_x;
         }
     }
+#if K16_BUFLD
+    unsigned brow[PB];
+#else
     const bf16* brow[PB];
+#endif
     bool bok[PB];
 #pragma unroll
     for (int ps = 0; ps < PB; ++ps) {
         const int n = n0 + r0 + ps * RP;
         bok[ps] = n < p.Ng;
+#if K16_BUFLD
+        brow[ps] = bok[ps] ? ((unsigned)n * (unsigned)p.wKtot + kq * 8) * 2u : 0x80000000u;       // rows past Ng: zeros
+#else
         brow[ps] = p.wgt + (size_t)(bok[ps] ? n : 0) * p.wKtot + kq * 8;
+#endif
     }
 
     const bool reflect = p.pad_mode == 1;
@@ -189,10 +211,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         f_kx = tap0 - f_ky * p.S;
     }
     int f_k = 0;
+#if K16_BUFLD
+    unsigned aptr[PA];
+#else
     const bf16* aptr[PA];
+    const bf16* zero = reinterpret_cast<const bf16*>(sscg_zero_page16);
+#endif
     unsigned f_okbits = 0;
     int dma_stage = 0;
-    const bf16* zero = reinterpret_cast<const bf16*>(sscg_zero_page16);
 
     auto set_tap = [&]() {
         const int tdy = f_ky * p.dil, tdx = f_kx * p.dil;
@@ -203,7 +229,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             int pix;
             const bool ok = locate(ps, tdy, tdx, pix);
             f_okbits |= ok ? (1u << ps) : 0u;
+#if K16_BUFLD
+            aptr[ps] = ok ? arow[ps] + ((unsigned)pix * (unsigned)p.Cs + kq * 8) * 2u : 0x80000000u;        // out of range: zeros
+#else
             aptr[ps] = arow[ps] + (size_t)pix * p.Cs + kq * 8;
+#endif
         }
     };
     set_tap();
@@ -225,6 +255,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         }
     };
     auto piece = [&](int q) {
+#if K16_BUFLD
+        if (q < PA) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds0 + dma_stage * A_STAGE + lds_wave + q * (RP * 128)),
+                                                     16, (int)aptr[q], __builtin_amdgcn_readfirstlane(f_chunk * (BK * 2)), 0, 0);
+        } else {
+            const int ps = q - PA;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + dma_stage * B_STAGE + lds_wave +
+                                                                                                    ps * (RP * 128)),
+                                                     16, (int)brow[ps], __builtin_amdgcn_readfirstlane(f_k * 2), 0, 0);
+        }
+#else
         if (q < PA) {
             const bf16* g = ((f_okbits >> q) & 1u) ? aptr[q] + f_chunk * BK : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -235,6 +276,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + dma_stage * B_STAGE + lds_wave + ps * (RP * 128)), 16, 0, 0);
         }
+#endif
     };
     auto tile_end = [&]() {
         dma_stage = dma_stage + 1 == NSTAGE ? 0 : dma_stage + 1;
@@ -715,12 +757,18 @@ bool dgrad16_by_parity(const sscg_conv_desc* d) { return d->stride == 2 && d->di
 }  // namespace
 
 // ---- entry points used by conv_igemm.hip's dispatch (same argument meaning as the public sscg_conv2d_* functions)
+// (the copies address both operands through 32-bit buffer offsets; a masked row's offset, 2 GB, must lie outside the tensor)
+static bool k16_extents_ok(const sscg_conv_desc* d, bool dgrad) {
+    const size_t src = (dgrad ? (size_t)d->N * d->P * d->Q * d->K : (size_t)d->N * d->H * d->W * d->C) * sizeof(bf16);
+    return src < ((size_t)1 << 31) && (size_t)d->K * d->R * d->S * d->C * sizeof(bf16) < ((size_t)1 << 31);
+}
+
 bool sscg_conv16_fwd_applies(const sscg_conv_desc* d) {
-    return d->x_dtype == SSCG_BF16 && d->w_dtype == SSCG_BF16 && d->C % BK == 0;
+    return d->x_dtype == SSCG_BF16 && d->w_dtype == SSCG_BF16 && d->C % BK == 0 && k16_extents_ok(d, false);
 }
 
 bool sscg_conv16_dgrad_applies(const sscg_conv_desc* d) {
-    return d->y_dtype == SSCG_BF16 && d->w_dtype == SSCG_BF16 && d->K % BK == 0;
+    return d->y_dtype == SSCG_BF16 && d->w_dtype == SSCG_BF16 && d->K % BK == 0 && k16_extents_ok(d, true);
 }
 
 // geometry of the statistics records of a forward launch (records = [tiles_m * wm][2 groups][K][2] doubles)
@@ -751,6 +799,8 @@ int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const
                     double* xstats, void* ws, size_t ws_bytes, hipStream_t st) {
     K16Params p = {};
     p.src = reinterpret_cast<const bf16*>(x); p.wgt = reinterpret_cast<const bf16*>(w); p.bias = bias; p.dst = y;
+    p.src_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->C * sizeof(bf16));
+    p.wgt_bytes = (unsigned)((size_t)d->K * d->R * d->S * d->C * sizeof(bf16));
     p.out_bf16 = d->y_dtype == SSCG_BF16;
     p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Cs = d->C; p.Ktot = d->R * d->S * d->C;
     p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
@@ -791,6 +841,8 @@ int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, c
         fused = true;
     }
     p.src = reinterpret_cast<const bf16*>(dy); p.wgt = reinterpret_cast<const bf16*>(wt); p.bias = bias; p.dst = dx;
+    p.src_bytes = (unsigned)((size_t)d->N * d->P * d->Q * d->K * sizeof(bf16));
+    p.wgt_bytes = (unsigned)((size_t)d->K * d->R * d->S * d->C * sizeof(bf16));
     p.out_bf16 = d->x_dtype == SSCG_BF16;
     p.M = d->N * d->H * d->W; p.Ng = d->C; p.Cs = d->K; p.Ktot = d->R * d->S * d->K;
     p.SH = d->P; p.SW = d->Q; p.OH = d->H; p.OW = d->W;

@@ -1171,7 +1171,6 @@ __global__ __launch_bounds__(256, 2) void wgradf_kernel(WgfParams p) {
     const int p_end = min(p.npix, p_begin + p.chunk);
     const int wave_id = tid >> 6;
     const int lane = tid & 63;
-    const float* const zero = sscg_zero_page_s;
 
     // ---- copy side: a wave instruction moves two pixel rows (1 KB); wave w owns rows 4 w .. 4 w + 3 of both operands.  LDS unit
     // u = lane & 31 of a row holds the 16-byte source unit 2 (u & 15) + (u >> 4): the two halves of an 8-channel group sit 256 bytes
@@ -1180,22 +1179,30 @@ __global__ __launch_bounds__(256, 2) void wgradf_kernel(WgfParams p) {
     const int c_g = 2 * (c_u & 15) + (c_u >> 4);              // source 16-byte unit (4 channels)
     const bool a_colok = m0 + 4 * c_g < p.Kc;
     const bool b_colok = n0 + 4 * c_g < p.C;
-    const float* const a_src = p.dy + (a_colok ? m0 + 4 * c_g : 0);
-    const float* const b_src = p.x + (b_colok ? n0 + 4 * c_g : 0);
+    // buffer loads (KS_BUFLD): the lane's offset inside a k-tile in one VGPR per copy, the k-tile's first pixel in an SGPR offset; a
+    // masked lane (column past the tensor, pixel past this split) asks for offset 2 GB = out of range = zeros
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, (short)0, (int)((unsigned)p.npix * (unsigned)p.Kc * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)((unsigned)p.npix * (unsigned)p.C * 4u), 0x00020000);
+    unsigned a_vo[2], b_vo[2];
+    int c_row[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        c_row[j] = wave_id * 4 + 2 * j + (lane >> 5);
+        a_vo[j] = a_colok ? ((unsigned)c_row[j] * (unsigned)p.Kc + m0 + 4 * c_g) * 4u : 0x80000000u;
+        b_vo[j] = b_colok ? ((unsigned)c_row[j] * (unsigned)p.C + n0 + 4 * c_g) * 4u : 0x80000000u;
+    }
     int f_pix = p_begin;
     int dma_stage = 0;
     const int lds_wave = __builtin_amdgcn_readfirstlane(wave_id * 2048);      // rows 4 w .. 4 w + 3
     auto request_tile = [&]() {
+        const int so_a = __builtin_amdgcn_readfirstlane(f_pix * p.Kc * 4), so_b = __builtin_amdgcn_readfirstlane(f_pix * p.C * 4);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int pix = f_pix + wave_id * 4 + 2 * j + (lane >> 5);
-            const bool pok = pix < p_end;
-            const float* ga = (a_colok && pok) ? a_src + (size_t)pix * p.Kc : zero;
-            const float* gb = (b_colok && pok) ? b_src + (size_t)pix * p.C : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
-                                             (__attribute__((address_space(3))) void*)(lds0 + dma_stage * WF_RAW_STAGE + lds_wave + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
-                                             (__attribute__((address_space(3))) void*)(lds0 + dma_stage * WF_RAW_STAGE + WF_RAW_OP + lds_wave + j * 1024), 16, 0, 0);
+            const bool pok = f_pix + c_row[j] < p_end;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds0 + dma_stage * WF_RAW_STAGE + lds_wave + j * 1024),
+                                                     16, (int)(pok ? a_vo[j] : 0x80000000u), so_a, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(lds0 + dma_stage * WF_RAW_STAGE + WF_RAW_OP + lds_wave + j * 1024),
+                                                     16, (int)(pok ? b_vo[j] : 0x80000000u), so_b, 0, 0);
         }
         dma_stage = dma_stage + 1 == WF_NRAW ? 0 : dma_stage + 1;
         f_pix += WS_BKP;
@@ -1421,8 +1428,10 @@ bool wgf_applies(const sscg_conv_desc* d) {
     // 2 M outputs and more (1024 <-> 2048): every element meets enough output columns for the split PASS of the planes kernel to pay
     // (tools/wgrad1x1_bench.py: 228 vs 261 us)
     if ((long)d->K * d->C >= (1L << 21)) return false;
+    const long npix = (long)d->N * d->P * d->Q;
+    if (npix * (d->K > d->C ? d->K : d->C) * 4 >= (1L << 31)) return false;      // 32-bit buffer offsets, 2 GB = the out-of-range marker
     return d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->K >= 128 && d->C >= 128 && d->K % 8 == 0 && d->C % 8 == 0 &&
-           (long)d->N * d->P * d->Q >= 1024;
+           npix >= 1024;
 }
 
 int launch_wgf(const sscg_conv_desc* d, const void* x, const void* dy, float* dw, float beta, void* ws, size_t ws_bytes, hipStream_t st) {
