@@ -454,8 +454,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
     if (want_bsums) { bg = m0 / p.bn_L; gb = (bg + 1) * p.bn_L; }
     // Every element goes to fp64 (as in the exact-fp32 kernel): the 4-rows-in-fp32 shortcut of the bf16 path moves a BatchNorm
     // statistic by 1e-7, which DeepLab's chained losses amplify to the edge of the parity bound.
-    const bool slow_stats = want_stats;
-    const bool fast_stats = false;
+#ifndef KS_FAST_STATS
+#define KS_FAST_STATS 1
+#endif
+    const bool slow_stats = want_stats && (!KS_FAST_STATS || m0 + BM > gb || m0 + BM > p.M);
+    const bool fast_stats = want_stats && !slow_stats;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + col_w + j * 32 + li;

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+O=gpurun_out/r4p15; mkdir -p $O
+python -m pytest tests/test_kernels_gpu.py tests/test_nets_gpu.py tests/test_parity_gpu.py tests/test_accuracy_gpu.py -m gpu -q -x > $O/tests.txt 2>&1; tail -4 $O/tests.txt
+SL=$PWD/semi-supervised-segmentation-cyclegan_amd/libsscg_slowstats.so
+B="python bench.py --no-cpu-baseline --no-elided --no-bf16 --no-roofline --no-small --steps 8 --warmup 3"
+for v in "SSCG_LIB=$SL" "" "SSCG_LIB=$SL" ""; do echo -n "[${v:0:12}]: "; env $v $B 2>/dev/null | python -c "
+import sys, json
+t = sys.stdin.read(); i = t.index('{\"metric\"'); d = json.JSONDecoder().raw_decode(t[i:])[0]; print(d['ms_per_step'], d['host_issue_ms_per_step'], 'finite' if d['config']['losses_finite'] else 'NON-FINITE')"; done 2>&1 | tee $O/bench.txt
