@@ -452,8 +452,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
     if (want_stats) gb = (m0 / p.stat_L + 1) * p.stat_L;
     int bg = 0;
     if (want_bsums) { bg = m0 / p.bn_L; gb = (bg + 1) * p.bn_L; }
-    // Every element goes to fp64 (as in the exact-fp32 kernel): the 4-rows-in-fp32 shortcut of the bf16 path moves a BatchNorm
-    // statistic by 1e-7, which DeepLab's chained losses amplify to the edge of the parity bound.
+    // Tiles inside one group and inside the tensor (nearly all): four consecutive rows are summed in fp32, the 4-row sums in fp64 (as the
+    // bf16 kernel does); tiles that straddle a group boundary or the tensor's end take every element to fp64.  Round 3 took EVERY
+    // element to fp64 because the shortcut moves a BatchNorm statistic by ~1e-7 and the chained-loss bound then sat at 1e-3; round 4
+    // measured those losses as noise of several 1e-3 in every fp32 arithmetic, the reference's included (tests/test_accuracy_gpu.py),
+    // and the whole golden suite passes either way: -0.5 ... -0.9 ms per config-2 step (KS_FAST_STATS=0 restores the old epilogue).
 #ifndef KS_FAST_STATS
 #define KS_FAST_STATS 1
 #endif
