@@ -170,3 +170,37 @@ __device__ __forceinline__ float wave_sum(float v) {
             sscg_attr_smem_ = (size_t)(smem);                                                                                          \
         }                                                                                                                              \
     } while (0)
+
+// A BM x BN fp32 result tile held in MFMA accumulators (wave (wm, wn) owns TM x TN blocks of 32 x 32; a lane owns single elements of
+// 16 rows per block) leaves through LDS: staged as [row][BN + 4] floats - `ot`, BM * (BN + 4) * 4 bytes, the k-loop's LDS is dead -
+// every thread then writes 16 bytes = four consecutive columns of a row: 4x fewer store instructions than the four-byte stores of the
+// MFMA layout, each a full row segment.  Ng % 4 == 0.  beta != 0: out = tile + beta * out.  Rows >= Mlim / columns >= Ng are dropped.
+template <int BM, int BN, int NT, int TM, int TN>
+__device__ __forceinline__ void sscg_stage_store_tile(const f32x16 (&acc)[TM][TN], float* ot, float* __restrict__ out, int m0, int n0, int Mlim,
+                                                      int Ng, int row_w, int col_w, int li, int lh, int tid, float beta) {
+    constexpr int OLD = BN + 4;
+    __syncthreads();                        // every wave has read its last fragments
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                ot[(row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OLD + col_w + j * 32 + li] = acc[i][j][e];
+    __syncthreads();
+    constexpr int TPR = BN / 4;             // threads per row
+    constexpr int RPP = NT / TPR;           // rows per pass
+    const int c4 = (tid % TPR) * 4;
+    const int n = n0 + c4;
+    if (n >= Ng) return;
+#pragma unroll
+    for (int ps = 0; ps < BM / RPP; ++ps) {
+        const int r = tid / TPR + ps * RPP;
+        const int m = m0 + r;
+        if (m >= Mlim) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
+        float* o = out + (size_t)m * Ng + n;
+        if (beta != 0.f) v += beta * *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = v;
+    }
+}

@@ -1322,24 +1322,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
 
     float* out = p.out + (size_t)split * p.Kc * p.Ng;
     const bool direct = (p.splits == 1);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + col_w + j * 32 + li;
-        if (n >= p.Ng) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < p.Kc) {
-                    const size_t o = (size_t)m * p.Ng + n;
-                    float v = acc[i][j][e];
-                    if (direct && p.beta != 0.f) v += p.beta * out[o];
-                    out[o] = v;
-                }
-            }
-        }
-    }
+    // the result tile leaves through LDS as 16-byte row segments (common.h): Ng = R * S * C with C % 8 == 0
+    sscg_stage_store_tile<BM, BN, NW * 64, TM, TN>(acc, reinterpret_cast<float*>(smem_raw), out, m0, n0, p.Kc, p.Ng, row_w, col_w, li, lh, tid,
+                                                   direct ? p.beta : 0.f);
 }
 
 struct Wg16Plan { int cfg, bm, bn, splits, chunk; };
@@ -1389,7 +1374,8 @@ int launch_wg16t(Wg16Params p, int splits, hipStream_t st) {
     p.tiles_n = cdiv(p.Ng, BN);
     p.tiles = cdiv(p.Kc, BM) * p.tiles_n;
     p.splits = splits;
-    const size_t smem = (size_t)NSTAGE * BKP * (BM + BN) * sizeof(bf16);
+    size_t smem = (size_t)NSTAGE * BKP * (BM + BN) * sizeof(bf16);
+    if (smem < (size_t)BM * (BN + 4) * sizeof(float)) smem = (size_t)BM * (BN + 4) * sizeof(float);      // the staged result tile
     constexpr int NT = WM * WN * 64;
     auto kern = wgrad16t_kernel<WM, WN, TM, TN, NSTAGE>;
     SSCG_ENSURE_SMEM((kern), smem);

@@ -462,6 +462,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
 #endif
     const bool slow_stats = want_stats && (!KS_FAST_STATS || m0 + BM > gb || m0 + BM > p.M);
     const bool fast_stats = want_stats && !slow_stats;
+    // Results leave through LDS (whole tiles; the k-loop's images are dead): in the MFMA layout a lane owns single elements of 16 rows -
+    // 32 four-byte stores per lane of a 128x64 tile, each wave-instruction touching 2 x 128 bytes, ~2000 cycles of the store path
+    // against 6000 cycles of MFMAs when the reduction is 256 long.  Staged as [row][BN + 4] floats, every thread then writes 16 bytes =
+    // four consecutive channels of a row: 4x fewer store instructions, full-width (conv_bf16.hip's epilogue does the same for bf16).
+#ifndef KS_STAGE_OUT
+#define KS_STAGE_OUT 1
+#endif
+    constexpr int OLD = BN + 4;
+    const bool staged = KS_STAGE_OUT && !partial;
+    float* const ot = reinterpret_cast<float*>(smem_raw);
+    if (staged) __syncthreads();           // every wave has read its last fragments
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + col_w + j * 32 + li;
@@ -519,15 +530,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
                                 if (lo) { s0 += d; q0 += d * (double)xh; } else { s1 += d; q1 += d * (double)xh; }
                             }
                         }
-                        size_t row = (size_t)m;
-                        if (p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
-                            const int img = m / (p.OH * p.OW);
-                            const int rem = m - img * (p.OH * p.OW);
-                            const int oi = rem / p.OW;
-                            const int oj = rem - oi * p.OW;
-                            row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+                        if (staged) {
+                            ot[(row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OLD + col_w + j * 32 + li] = sscg_act(pre, p.act, p.slope);
+                        } else {
+                            size_t row = (size_t)m;
+                            if (p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
+                                const int img = m / (p.OH * p.OW);
+                                const int rem = m - img * (p.OH * p.OW);
+                                const int oi = rem / p.OW;
+                                const int oj = rem - oi * p.OW;
+                                row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+                            }
+                            p.dst[row * p.Ng + n] = sscg_act(pre, p.act, p.slope);
                         }
-                        p.dst[row * p.Ng + n] = sscg_act(pre, p.act, p.slope);
                     }
                 }
                 if (want_bsums && bs_fast && (e & 3) == 3) { s0 += (double)bfa; q0 += (double)bfb; bfa = 0.f; bfb = 0.f; }
@@ -554,6 +569,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
                 double* rec = p.stats + ((size_t)(tile_m * WM + wm) * 2) * p.Ng * 2;
                 rec[(size_t)n * 2] = s0; rec[(size_t)n * 2 + 1] = q0;
                 rec[((size_t)p.Ng + n) * 2] = s1; rec[((size_t)p.Ng + n) * 2 + 1] = q1;
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        constexpr int TPR = BN / 4;             // threads per row (four channels = 16 bytes each)
+        constexpr int RPP = NT / TPR;           // rows per pass
+        const int c4 = (tid % TPR) * 4;
+        const int n = n0 + c4;
+        if (n < p.Ng) {                         // (Ng % 4 == 0: a 16-byte piece is inside the row or outside it)
+#pragma unroll
+            for (int ps = 0; ps < BM / RPP; ++ps) {
+                const int r = tid / TPR + ps * RPP;
+                const int m = m0 + r;
+                if (m >= p.M) break;
+                size_t row = (size_t)m;
+                if (p.o_step != 1) {            // parity class of a strided data gradient: rows interleave into dx
+                    const int img = m / (p.OH * p.OW);
+                    const int rem = m - img * (p.OH * p.OW);
+                    const int oi = rem / p.OW;
+                    const int oj = rem - oi * p.OW;
+                    row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+                }
+                *reinterpret_cast<f32x4*>(p.dst + row * p.Ng + n) = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
             }
         }
     }
@@ -929,6 +968,37 @@ struct WgsParams {
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4s;
 __device__ __forceinline__ int ws_sw(int pixel) { return (pixel & 3) << 2; }      // chunk swizzle of a 256-byte pixel row (wgrad16t_kernel)
 
+// The 128 x 128 result tile of the weight-gradient kernels (4 waves of 64 x 64) leaves through LDS: in the MFMA layout the tile costs
+// 64 four-byte stores per lane (256 wave-instructions of 2 x 128 bytes: ~4000 cycles of the store path against 13000 cycles of MFMAs
+// in a 17-k-tile workgroup of the 1x1 kernel); staged as [row][132] floats (the k-loop's LDS is dead) every thread writes 16 bytes.
+// Ng % 4 == 0 (the callers require C % 8 == 0).  beta != 0: out = tile + beta * out (single-split launches accumulate in place).
+__device__ __forceinline__ void ws_store_tile(const f32x16 (&acc)[2][2], float* ot, float* __restrict__ out, int m0, int n0, int Kc, int Ng,
+                                              int row_w, int col_w, int li, int lh, int tid, float beta) {
+    constexpr int OLD = 132;
+    __syncthreads();                        // every wave has read its last fragments
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                ot[(row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OLD + col_w + j * 32 + li] = acc[i][j][e];
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    const int n = n0 + c4;
+    if (n >= Ng) return;
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+        const int r = (tid >> 5) + ps * 8;
+        const int m = m0 + r;
+        if (m >= Kc) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
+        float* o = out + (size_t)m * Ng + n;
+        if (beta != 0.f) v += beta * *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = v;
+    }
+}
+
 template <int NSTAGE>
 __global__ __launch_bounds__(256, 2) void wgrads_kernel(WgsParams p) {
     constexpr int TM = 2, TN = 2, WN = 2;
@@ -1110,24 +1180,7 @@ __global__ __launch_bounds__(256, 2) void wgrads_kernel(WgsParams p) {
 
     float* out = p.out + (size_t)split * p.Kc * p.Ng;
     const bool direct = (p.splits == 1);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + col_w + j * 32 + li;
-        if (n >= p.Ng) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < p.Kc) {
-                    const size_t o = (size_t)m * p.Ng + n;
-                    float v = acc[i][j][e];
-                    if (direct && p.beta != 0.f) v += p.beta * out[o];
-                    out[o] = v;
-                }
-            }
-        }
-    }
+    ws_store_tile(acc, reinterpret_cast<float*>(smem_raw), out, m0, n0, p.Kc, p.Ng, row_w, col_w, li, lh, tid, direct ? p.beta : 0.f);
 }
 
 // =====================================================================================================================
@@ -1368,24 +1421,7 @@ __global__ __launch_bounds__(256, 2) void wgradf_kernel(WgfParams p) {
 
     float* out = p.out + (size_t)split * p.Kc * p.C;
     const bool direct = (p.splits == 1);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + col_w + j * 32 + li;
-        if (n >= p.C) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < p.Kc) {
-                    const size_t o = (size_t)m * p.C + n;
-                    float v = acc[i][j][e];
-                    if (direct && p.beta != 0.f) v += p.beta * out[o];
-                    out[o] = v;
-                }
-            }
-        }
-    }
+    ws_store_tile(acc, reinterpret_cast<float*>(smem_raw), out, m0, n0, p.Kc, p.C, row_w, col_w, li, lh, tid, direct ? p.beta : 0.f);
 }
 
 struct WgsPlan { int splits, chunk; };
@@ -1515,7 +1551,9 @@ int sscg_wgrads(const sscg_conv_desc* d, const void* x, const void* dy, float* d
     p.div_pq = make_fastdiv(d->P * d->Q);
     p.div_q = make_fastdiv(d->Q);
     if ((d->wgrad_tuning >> 24) & 1) {
-        hipLaunchKernelGGL(wgrads_kernel<2>, dim3(p.tiles * pl.splits), dim3(256), 2 * WS_STAGE, st, p);
+        const size_t smem2 = (size_t)128 * 132 * sizeof(float);      // the staged result tile (> the two copy stages' 48 KB)
+        SSCG_ENSURE_SMEM(wgrads_kernel<2>, smem2);
+        hipLaunchKernelGGL(wgrads_kernel<2>, dim3(p.tiles * pl.splits), dim3(256), smem2, st, p);
     } else {
         const size_t smem = (size_t)3 * WS_STAGE;      // 72 KB
         static bool attr_set = false;
