@@ -217,7 +217,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
     const bf16* aptr[PA];
     const bf16* zero = reinterpret_cast<const bf16*>(sscg_zero_page16);
 #endif
-    unsigned f_okbits = 0;
+    [[maybe_unused]] unsigned f_okbits = 0;
     int dma_stage = 0;
 
     auto set_tap = [&]() {
@@ -1322,9 +1322,33 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
 
     float* out = p.out + (size_t)split * p.Kc * p.Ng;
     const bool direct = (p.splits == 1);
+#ifndef K16_STAGE_WG
+#define K16_STAGE_WG 1
+#endif
+#if K16_STAGE_WG
     // the result tile leaves through LDS as 16-byte row segments (common.h): Ng = R * S * C with C % 8 == 0
     sscg_stage_store_tile<BM, BN, NW * 64, TM, TN>(acc, reinterpret_cast<float*>(smem_raw), out, m0, n0, p.Kc, p.Ng, row_w, col_w, li, lh, tid,
                                                    direct ? p.beta : 0.f);
+#else
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + col_w + j * 32 + li;
+        if (n >= p.Ng) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.Kc) {
+                    const size_t o = (size_t)m * p.Ng + n;
+                    float v = acc[i][j][e];
+                    if (direct && p.beta != 0.f) v += p.beta * out[o];
+                    out[o] = v;
+                }
+            }
+        }
+    }
+#endif
 }
 
 struct Wg16Plan { int cfg, bm, bn, splits, chunk; };

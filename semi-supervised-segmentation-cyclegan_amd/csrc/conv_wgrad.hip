@@ -309,6 +309,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
 
     float* out = p.out + (size_t)split * p.Kc * p.Ng;
     const bool direct = (p.splits == 1);
+    if constexpr (VB == 4) {            // VB == 4 <=> C % 4 == 0 <=> Ng % 4 == 0: the tile leaves through LDS as 16-byte row segments (common.h)
+        sscg_stage_store_tile<BM, BN, 256, TM, TN>(acc, reinterpret_cast<float*>(smem_raw), out, m0, n0, p.Kc, p.Ng, row_w, col_w, li, lh, tid,
+                                                   direct ? p.beta : 0.f);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + col_w + j * 32 + li;
@@ -430,6 +435,7 @@ int launch_wg(WgParams p, int splits, hipStream_t st) {
     p.tiles = tiles_m * p.tiles_n;
     p.splits = splits;
     size_t smem = (size_t)(2 * BKP * (DMA ? BM : BM + 4) + 2 * BKP * (DMA ? BN : BN + 4)) * sizeof(float);
+    if (VB == 4 && smem < (size_t)BM * (BN + 4) * sizeof(float)) smem = (size_t)BM * (BN + 4) * sizeof(float);      // the staged result tile
     auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VA, VB, DMA, BF16, TX, TY>;
     SSCG_ENSURE_SMEM((kern), smem);
     hipLaunchKernelGGL(kern, dim3(p.tiles * splits), dim3(256), smem, st, p);
