@@ -479,13 +479,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
         const bool nok = n < p.Ng;
         const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
         double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
-        float mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f, ga = 1.f, be = 0.f, bfa = 0.f, bfb = 0.f;
-        const bool bs_fast = want_bsums && m0 + BM <= gb;
-        if (want_bsums && nok) {
-            mu0 = p.bn_mean[(size_t)bg * p.Ng + n]; rs0 = p.bn_rstd[(size_t)bg * p.Ng + n];
-            if (bg + 1 < p.bn_G) { mu1 = p.bn_mean[(size_t)(bg + 1) * p.Ng + n]; rs1 = p.bn_rstd[(size_t)(bg + 1) * p.Ng + n]; }
-            if (p.bn_gamma) { ga = p.bn_gamma[n]; be = p.bn_beta[n]; }
-        }
         if (fast_stats) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -516,20 +509,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
                             const double d = (double)pre;
                             if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
                         }
-                        if (want_bsums) {       // norm.hip col_reduce_kernel<RM_BWD>, mask recomputed from the layer's input
-                            const bool lo = m < gb;
-                            const float xh = (p.bn_x[(size_t)m * p.Ng + n] - (lo ? mu0 : mu1)) * (lo ? rs0 : rs1);
-                            const float ym = xh * ga + be;
-                            float gg = pre;
-                            if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? pre : 0.f;
-                            else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? pre : pre * p.bn_slope;
-                            if (bs_fast) {          // tile inside one group: four consecutive rows in fp32, the 4-row sums in fp64
-                                bfa += gg; bfb = fmaf(gg, xh, bfb);
-                            } else {
-                                const double d = (double)gg;
-                                if (lo) { s0 += d; q0 += d * (double)xh; } else { s1 += d; q1 += d * (double)xh; }
-                            }
-                        }
                         if (staged) {
                             ot[(row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OLD + col_w + j * 32 + li] = sscg_act(pre, p.act, p.slope);
                         } else {
@@ -544,21 +523,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
                             p.dst[row * p.Ng + n] = sscg_act(pre, p.act, p.slope);
                         }
                     }
-                }
-                if (want_bsums && bs_fast && (e & 3) == 3) { s0 += (double)bfa; q0 += (double)bfb; bfa = 0.f; bfb = 0.f; }
-            }
-        }
-        if (want_bsums) {
-            s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
-            s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-            if (lh == 0 && nok) {
-                // chunk of group g = (tile row - first tile row of g) * WM + wave row: one writer per (g, chunk, n)
-                const int k0 = (tile_m - (int)(((long)bg * p.bn_L) / BM)) * WM + wm;
-                double* r0 = p.bn_sums + (((size_t)bg * p.bn_chunks + k0) * p.Ng + n) * 2;
-                r0[0] = s0; r0[1] = q0;
-                if (m0 + BM > gb && bg + 1 < p.bn_G) {          // the tile straddles into group g + 1: it is that group's first tile
-                    double* r1 = p.bn_sums + (((size_t)(bg + 1) * p.bn_chunks + wm) * p.Ng + n) * 2;
-                    r1[0] = s1; r1[1] = q1;
                 }
             }
         }
@@ -578,6 +542,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
         constexpr int RPP = NT / TPR;           // rows per pass
         const int c4 = (tid % TPR) * 4;
         const int n = n0 + c4;
+        // Backward sums of the normalisation layer in front (norm.hip col_reduce_kernel<RM_BWD>, mask recomputed from the layer's input
+        // nx): taken HERE, where a thread holds four consecutive channels of whole rows - nx arrives as 16-byte row segments like the
+        // result leaves - over the thread's <= BM / RPP rows in fp32 (per group: a tile meets at most one group boundary), then in
+        // fp64 across the RPP row lanes.  One record per tile and group.
+        f32x4 mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f, ga = 1.f, be = 0.f, sl = 0.f, ql = 0.f, sh = 0.f, qh = 0.f;
+        if (want_bsums && n < p.Ng) {
+            mu0 = *reinterpret_cast<const f32x4*>(p.bn_mean + (size_t)bg * p.Ng + n);
+            rs0 = *reinterpret_cast<const f32x4*>(p.bn_rstd + (size_t)bg * p.Ng + n);
+            if (bg + 1 < p.bn_G) {
+                mu1 = *reinterpret_cast<const f32x4*>(p.bn_mean + (size_t)(bg + 1) * p.Ng + n);
+                rs1 = *reinterpret_cast<const f32x4*>(p.bn_rstd + (size_t)(bg + 1) * p.Ng + n);
+            }
+            if (p.bn_gamma) { ga = *reinterpret_cast<const f32x4*>(p.bn_gamma + n); be = *reinterpret_cast<const f32x4*>(p.bn_beta + n); }
+        }
         if (n < p.Ng) {                         // (Ng % 4 == 0: a 16-byte piece is inside the row or outside it)
 #pragma unroll
             for (int ps = 0; ps < BM / RPP; ++ps) {
@@ -592,7 +570,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
                     const int oj = rem - oi * p.OW;
                     row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
                 }
-                *reinterpret_cast<f32x4*>(p.dst + row * p.Ng + n) = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
+                *reinterpret_cast<f32x4*>(p.dst + row * p.Ng + n) = v;
+                if (want_bsums) {
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(p.bn_x + (size_t)m * p.Ng + n);
+                    const bool lo = m < gb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (y[e] - (lo ? mu0[e] : mu1[e])) * (lo ? rs0[e] : rs1[e]);
+                        const float ym = xh * ga[e] + be[e];
+                        float gg = v[e];
+                        if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? gg : 0.f;
+                        else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? gg : gg * p.bn_slope;
+                        if (lo) { sl[e] += gg; ql[e] = fmaf(gg, xh, ql[e]); } else { sh[e] += gg; qh[e] = fmaf(gg, xh, qh[e]); }
+                    }
+                }
+            }
+        }
+        if (want_bsums) {
+            __syncthreads();                    // the staged tile is dead: its LDS takes the row lanes' partial sums [RPP][BN][4]
+            f32x4* ps4 = reinterpret_cast<f32x4*>(smem_raw);
+            if (n < p.Ng) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ps4[(tid / TPR) * BN + c4 + e] = f32x4{sl[e], ql[e], sh[e], qh[e]};
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.Ng) {
+                double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+#pragma unroll 4
+                for (int rl = 0; rl < RPP; ++rl) {
+                    const f32x4 t = ps4[rl * BN + tid];
+                    a += (double)t[0]; b += (double)t[1]; c += (double)t[2]; d += (double)t[3];
+                }
+                const int nn = n0 + tid;
+                const int k0 = tile_m - (int)(((long)bg * p.bn_L) / BM);          // chunk of group g = tile row - first tile row of g
+                double* r0 = p.bn_sums + (((size_t)bg * p.bn_chunks + k0) * p.Ng + nn) * 2;
+                r0[0] = a; r0[1] = b;
+                if (m0 + BM > gb && bg + 1 < p.bn_G) {          // the tile straddles into group g + 1: it is that group's first tile
+                    double* r1 = p.bn_sums + ((size_t)(bg + 1) * p.bn_chunks * p.Ng + nn) * 2;
+                    r1[0] = c; r1[1] = d;
+                }
             }
         }
     }
@@ -848,8 +865,8 @@ bool sscg_convs_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, 
     const int cfg = ks_choose(M, d->C, d->R * d->S * d->K, d->tuning);
     if (L < KS_BM[cfg]) return false;
     *bm = KS_BM[cfg];
-    *wm = KS_WM[cfg];
-    *chunks = (int)(cdiv(L, (long)KS_BM[cfg]) + 1) * KS_WM[cfg];
+    *wm = 1;                                // one record per tile and group (the sums are taken in the store phase, per workgroup)
+    *chunks = (int)(cdiv(L, (long)KS_BM[cfg]) + 1);
     return true;
 }
 

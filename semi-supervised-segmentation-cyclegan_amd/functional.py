@@ -355,11 +355,14 @@ F32_SPLIT = [os.environ.get("SSCG_F32_SPLIT", "1") == "1"]
 _MODE = ["f32s" if F32_SPLIT[0] else "f32"]
 FUSE_STATS = [os.environ.get("SSCG_FUSE_STATS", "1") != "0"]    # norm statistics from the producing conv's epilogue (K3/K4)
 # The reduction pass of a norm layer's backward from the epilogue of the data gradient that produces its upstream gradient
-# (sscg_conv2d_dgrad_bsums).  Built, tested (fp32 and bf16), and OFF: it removes 260 col_reduce launches per step
-# but loses on the clock - config 2 142.3 -> 143.1 ms, config 3 187.9 -> 189.8 ms (profiles/r04_experiments.txt item 3): the sums'
-# scattered loads of the layer's input and their fp64 tail sit in the epilogue of kernels on the critical lanes, while the streaming
-# reduction pass they replace ran beside them.
-FUSE_BSUMS = [os.environ.get("SSCG_FUSE_BSUMS", "0") == "1"]
+# (sscg_conv2d_dgrad_bsums): ~260 col_reduce launches fewer per step.  fp32 tensors: ON - the split kernel takes
+# the sums in its coalesced store phase (config 2 134.4 -> 134.0 ms, host issue time -2 ms per step; the first version, sums in the
+# MFMA layout, LOST 0.7 ms).  bf16 tensors: off - conv16_kernel takes them in the MFMA layout (config 3 +1.9 ms); a store-phase
+# version of it was tried too and still lost (+0.5..1.9 ms, and 64 -> 111 VGPRs in the 64x64 class), so it was not kept.
+# SSCG_FUSE_BSUMS=1 / 0 forces both on / off (profiles/r04_experiments.txt items 3, 11 and 12).
+_FB = os.environ.get("SSCG_FUSE_BSUMS", "f32")
+FUSE_BSUMS = [_FB != "0"]            # master switch (tests flip it)
+FUSE_BSUMS_BF16 = [_FB == "1"]
 
 
 def set_conv_precision(mode):
@@ -1261,7 +1264,8 @@ def _conv_backward(dy, x, w, wref, bref, geom, want_x, want_w, want_b):
         # this data gradient IS that unit's upstream gradient, so its epilogue takes the unit's backward sums and the reduction pass
         # over (dz, y) never runs.  The records travel on dx and are only honoured if dx arrives unchanged (`_version`): an
         # accumulation by the autograd engine (a tensor with two consumers) bumps it.
-        info = getattr(x, "_sscg_norm", None) if (FUSE_BSUMS[0] and stride == 1 and x.dtype == dy.dtype) else None
+        info = getattr(x, "_sscg_norm", None) if (FUSE_BSUMS[0] and stride == 1 and x.dtype == dy.dtype
+                                                  and (x.dtype == torch.float32 or FUSE_BSUMS_BF16[0])) else None
         if info is not None:
             dx, rec = conv2d_dgrad_param(dy, wref, x.shape, w.shape, stride, pad, dil, out_dtype=x.dtype, bsums=info)
             if rec is not None:

@@ -686,9 +686,9 @@ def test_norm_backward_sums_fused_into_the_bf16_data_gradient(case, dev, bf16_mo
     x0 = torch.randn(n, 3, h, w)
     gy = None
     outs, used = [], []
-    real, was = F.norm_bwd_from_sums, F.FUSE_BSUMS[0]
+    real, was, was16 = F.norm_bwd_from_sums, F.FUSE_BSUMS[0], F.FUSE_BSUMS_BF16[0]
     for fused in (True, False):
-        F.FUSE_BSUMS[0] = fused
+        F.FUSE_BSUMS[0] = F.FUSE_BSUMS_BF16[0] = fused
         calls = []
         F.norm_bwd_from_sums = lambda *aa, **kk: (calls.append(1), real(*aa, **kk))[1]
         try:
@@ -710,7 +710,7 @@ def test_norm_backward_sums_fused_into_the_bf16_data_gradient(case, dev, bf16_mo
                         ([nl.weight.grad.clone(), nl.bias.grad.clone()] if norm != "instance" else []))
             used.append(len(calls))
         finally:
-            F.FUSE_BSUMS[0] = was
+            F.FUSE_BSUMS[0], F.FUSE_BSUMS_BF16[0] = was, was16
             F.norm_bwd_from_sums = real
     assert used == [1, 0], used
     for i, (t_f, t_u) in enumerate(zip(*outs)):
