@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 11
+#define SSCG_ABI_VERSION 12
 
 /* element types of activation / weight tensors */
 #define SSCG_F32 0
@@ -112,6 +112,18 @@ int sscg_conv2d_wgrad(const sscg_conv_desc* d, const void* x, const void* dy, fl
 
 /* [K][RS][C] -> [C][RS][K]; source and destination dtypes may differ (fp32 master weight -> bf16 operand copy) */
 int sscg_weight_krsc_to_crsk(const void* w, int w_dtype, void* wt, int wt_dtype, int K, int RS, int C, void* stream);
+/* The same re-layout of MANY weights in one launch (the operand copies of every conv that sees a backward pass are rebuilt after each
+ * optimiser step: ~230 launches of a few microseconds each at the top of the step otherwise).  `jobs` is a table IN DEVICE MEMORY;
+ * job i covers the 32x32 tiles [block0, block0 of job i+1) in the order (c-tile fastest, then k-tile, then tap) - block0 ascending,
+ * job 0 at 0, `n_blocks` the total.  Same dtype pairs and bit-identical results as sscg_weight_krsc_to_crsk. */
+typedef struct sscg_wt_job {
+    const void* w;
+    void* wt;
+    int32_t w_dtype, wt_dtype;
+    int32_t K, RS, C;
+    int32_t block0;
+} sscg_wt_job;
+int sscg_weight_krsc_to_crsk_batch(const sscg_wt_job* jobs, int n_jobs, int n_blocks, void* stream);
 /* The "split" contraction (fp32 accuracy on the bf16 matrix cores): dst = three bfloat16 planes h, m, l (each n elements,
  * `plane_stride` elements apart) with src[i] = h[i] + m[i] + l[i] to 2^-24 (round to nearest at every step).  A conv weight in
  * this form is passed with w_dtype = SSCG_BF16X3 (forward: planes of [K][R][S][C]; dgrad: planes of [C][R][S][K], which

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 F32, BF16, BF16X3 = 0, 1, 2     # SSCG_F32 / SSCG_BF16 / SSCG_BF16X3 (split weight operand)
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "sscg_conv2d_wgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_wgrad": (_i, [_dp, _p, _p, _p, _f, _p, _sz, _p]),
     "sscg_weight_krsc_to_crsk": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "sscg_weight_krsc_to_crsk_batch": (_i, [_p, _i, _i, _p]),
     "sscg_split3": (_i, [_p, _p, _i64, _i64, _p]),
     "sscg_conv2d_split_applies": (_i, [_dp, _i]),
     "sscg_cast": (_i, [_p, _i, _p, _i, _i64, _p]),

@@ -1006,6 +1006,56 @@ __global__ void krsc_to_crsk_kernel(const S* __restrict__ w, D* __restrict__ wt,
     }
 }
 
+// every stale operand copy of a step in ONE launch: a block finds its job by bisection over the table's first-block column
+__global__ __launch_bounds__(256) void krsc_to_crsk_batch_kernel(const sscg_wt_job* __restrict__ jobs, int n_jobs) {
+    __shared__ float t[32][33];
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const sscg_wt_job j = jobs[lo];
+    int b = (int)blockIdx.x - j.block0;
+    const int K = j.K, RS = j.RS, C = j.C;
+    const int tc = (C + 31) >> 5, tk = (K + 31) >> 5;
+    const int c0 = (b % tc) * 32; b /= tc;
+    const int k0 = (b % tk) * 32;
+    const int rs = b / tk;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (k < K && c < C) {
+            const size_t i = ((size_t)k * RS + rs) * C + c;
+            v = j.w_dtype == SSCG_F32 ? reinterpret_cast<const float*>(j.w)[i] : ld1<__bf16>(reinterpret_cast<const __bf16*>(j.w) + i);
+        }
+        t[r][tx] = v;
+    }
+    __syncthreads();
+    const size_t plane = (size_t)K * RS * C;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, k = k0 + tx;
+        if (k < K && c < C) {
+            const size_t o = ((size_t)c * RS + rs) * K + k;
+            const float v = t[tx][r];
+            if (j.wt_dtype == SSCG_F32) reinterpret_cast<float*>(j.wt)[o] = v;
+            else if (j.wt_dtype == SSCG_BF16) st1<__bf16>(reinterpret_cast<__bf16*>(j.wt) + o, v);
+            else {
+                const sscg_bf3 s3 = sscg_split3(v);
+                __bf16* wt = reinterpret_cast<__bf16*>(j.wt);
+                wt[o] = s3.h; wt[plane + o] = s3.m; wt[2 * plane + o] = s3.l;
+            }
+        }
+    }
+}
+
+extern "C" int sscg_weight_krsc_to_crsk_batch(const sscg_wt_job* jobs, int n_jobs, int n_blocks, void* stream) {
+    if (!jobs || n_jobs <= 0 || n_blocks <= 0) return SSCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(krsc_to_crsk_batch_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
 extern "C" int sscg_weight_krsc_to_crsk(const void* w, int w_dtype, void* wt, int wt_dtype, int K, int RS, int C, void* stream) {
     if (!w || !wt || K <= 0 || RS <= 0 || C <= 0 || !dt_ok(w_dtype) || !wdt_ok(wt_dtype)) return SSCG_ERR_BAD_ARG;
     if (wt_dtype == SSCG_BF16X3) {      // three dense planes of [C][RS][K] bf16

@@ -574,13 +574,16 @@ struct ConvStatParams {
 // block = 1024 threads = 16 channels x 64 record lanes (a 16-channel row segment of a record is 256 contiguous bytes);
 // grid (C / 16, G or 1).  This kernel is a serial link (conv -> statistics -> normalise) in front of EVERY normalisation layer:
 // with 16 record lanes a thread walked ~34 dependent-latency loads (29 us per launch, 16 ms per Cityscapes step); 64 lanes and
-// four loads in flight per thread bring it to a handful of memory latencies.
-constexpr int FCS_LANES = 64;
+// four loads in flight per thread bring it to a handful of memory latencies.  CPB = 4 (256 record lanes, grid C / 4): few channels and
+// many records - the 64-channel BatchNorm layers of DeepLab's stem and layer1 are 4 blocks of CPB = 16 walking 4096-8192 records,
+// 47 us per launch 35 times per step (profiles/r04_experiments.txt item 14).
+template <int CPB>
 __global__ __launch_bounds__(1024) void finalize_conv_stats_kernel(ConvStatParams p) {
-    __shared__ double sm[FCS_LANES][16][2];
-    const int cl = threadIdx.x & 15;
-    const int w = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    constexpr int FCS_LANES = 1024 / CPB;
+    __shared__ double sm[FCS_LANES][CPB][2];
+    const int cl = threadIdx.x % CPB;
+    const int w = threadIdx.x / CPB;
+    const int c = blockIdx.x * CPB + cl;
     const bool cok = c < p.C;
     const int g0 = p.rmean ? 0 : blockIdx.y;
     const int g1 = p.rmean ? p.G : blockIdx.y + 1;
@@ -692,7 +695,15 @@ int sscg_finalize_conv_stats(const double* stats, int valid_tiles, int rows_per_
     p.rec = stats; p.xrecs = xrecs; p.mean = mean; p.rstd = rstd; p.rmean = running_mean; p.rvar = running_var;
     p.valid_tiles = valid_tiles; p.BMT = rows_per_tile; p.RPT = records_per_tile; p.xrec = xrec; p.xgroup = xgroup;
     p.G = G; p.C = C; p.L = L; p.eps = eps; p.momentum = momentum;
-    hipLaunchKernelGGL(finalize_conv_stats_kernel, dim3(cdiv(C, 16), running_mean ? 1 : G), dim3(1024), 0, st, p);
+    const int gy = running_mean ? 1 : G;
+    const long recs = (L / rows_per_tile + 1) * records_per_tile;       // records per channel and group
+#ifndef FCS_NARROW
+#define FCS_NARROW 1      // (0: kernel-ablation build)
+#endif
+    if (FCS_NARROW && cdiv(C, 16) * gy < 64 && recs >= 512)
+        hipLaunchKernelGGL(finalize_conv_stats_kernel<4>, dim3(cdiv(C, 4), gy), dim3(1024), 0, st, p);
+    else
+        hipLaunchKernelGGL(finalize_conv_stats_kernel<16>, dim3(cdiv(C, 16), gy), dim3(1024), 0, st, p);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

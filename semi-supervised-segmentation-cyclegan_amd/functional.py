@@ -1064,34 +1064,131 @@ def refresh_transposed_weights(weights=(), all_users=True):
 
 def _refresh_all(weights, all_users):
     bf16 = _MODE[0] == "bf16"
+    jobs = []
     if _MODE[0] != "f32s":       # (split mode: which copy a weight needs depends on its geometry - the registry below knows)
         for w in weights:
-            _cached_wt(w, torch.bfloat16 if (bf16 and w.shape[0] % 64 == 0) else torch.float32)
+            kind = "t16" if (bf16 and w.shape[0] % 64 == 0) else "t32"
+            _note_user(w, kind)
+            if not all_users:
+                _refresh_kinds(w, (kind,), jobs)
     if not all_users:
         if _MODE[0] == "f32s":
             for w in weights:
                 ent = _WT_USERS.get(id(w))
                 if ent is not None:
-                    _refresh_kinds(w, ent[1])
+                    _refresh_kinds(w, ent[1], jobs)
+        _transpose_batch(jobs)
         return
     for r, kinds in list(_WT_USERS.values()):
         w = r()
         if w is None:
             continue
-        _refresh_kinds(w, kinds)
+        _refresh_kinds(w, kinds, jobs)
+    _transpose_batch(jobs)
 
 
-def _refresh_kinds(w, kinds):
-    if "t32" in kinds:
-        _cached_wt(w, torch.float32)
-    if "t16" in kinds:
-        _cached_wt(w, torch.bfloat16)
-    if "tx3" in kinds:
-        _cached_wt(w, "x3")
+_WT_ATTR = {"tx3": "_sscg_wtx3", "t16": "_sscg_wt16", "t32": "_sscg_wt"}
+BATCH_TRANSPOSES = [os.environ.get("SSCG_BATCH_TRANSPOSES", "1") != "0"]
+
+
+def _refresh_kinds(w, kinds, jobs=None):
+    """Bring the operand copies `kinds` of weight w up to date.  With `jobs` (a list), a stale TRANSPOSED copy is not rebuilt here:
+    the weight is appended and `_transpose_batch` rebuilds all of them in one launch."""
+    for kind, dtype in (("t32", torch.float32), ("t16", torch.bfloat16), ("tx3", "x3")):
+        if kind in kinds:
+            if jobs is not None and BATCH_TRANSPOSES[0]:
+                ent = getattr(w, _WT_ATTR[kind], None)
+                tag = _wtag(w)
+                if ent is None or ent.tag != tag:
+                    jobs.append((w, kind, ent, tag))
+            else:
+                _cached_wt(w, dtype)
     if "w16" in kinds:
         weight_bf16(w)
     if "wx3" in kinds:
         weight_split(w)
+
+
+class _WtJob(C.Structure):          # include/sscg.h: sscg_wt_job
+    _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("w_dtype", C.c_int32), ("wt_dtype", C.c_int32),
+                ("K", C.c_int32), ("RS", C.c_int32), ("C", C.c_int32), ("block0", C.c_int32)]
+
+
+_WT_TABLES = {}      # (source, destination) pointers of a batch -> (device table, blocks): the same weights come back every step
+
+
+def _transpose_batch(jobs):
+    """The stale transposed operand copies of a whole step in ONE launch (sscg_weight_krsc_to_crsk_batch; 234 launches of ~6 us at the
+    top of a config-2 step otherwise).  A copy that exists is rewritten IN PLACE - `refresh_transposed_weights` runs ordered behind
+    every reader of the stale copies, which is also what freeing them (the per-weight path) needs - so the pointers, and with them
+    the job table in device memory, are the same from the second step on."""
+    assert _IN_REFRESH[0]
+    if len(jobs) < 2:
+        for w, kind, _, _ in jobs:
+            _cached_wt(w, {"t32": torch.float32, "t16": torch.bfloat16, "tx3": "x3"}[kind])
+        return
+    rows = []
+    blocks = 0
+    keep = []
+    fast = not hasattr(lib, "note_batch")       # (racecheck.py wants every buffer's extent: it sees them in data_ptr())
+    cur = _stream()
+    for w, kind, ent, tag in jobs:
+        src = weight_bf16(w) if kind == "t16" else w
+        row = getattr(ent, "row", None) if (fast and ent is not None) else None
+        if row is not None and ent.ev is None and row[0] == (tag[2] if src is w else src.data_ptr()):
+            rows.append(row + (blocks,))        # same source, same destination as the last time: rewritten in place
+            blocks += ent.nblk
+            ent.tag, ent.stream = tag, cur
+            continue
+        k, c, r, s = w.shape
+        temp = not src.is_contiguous(memory_format=CL)
+        if temp:
+            src = src.contiguous(memory_format=CL)
+            keep.append(src)
+        t = None
+        if ent is not None:
+            if ent.ev is None and ent.t.device == w.device:
+                t = ent.t               # built by a refresh: its readers are the ones our caller is ordered behind
+            else:
+                ent.retire()            # built lazily (a model's first step): the allocator keeps the block for its readers
+        if t is None:
+            t = (torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=w.device) if kind == "tx3" else
+                 torch.empty((c, k, r, s), dtype=torch.bfloat16 if kind == "t16" else torch.float32, device=w.device, memory_format=CL))
+        wt_dtype = {"t32": F32, "t16": BF16, "tx3": BF16X3}[kind]
+        row = (src.data_ptr(), t.data_ptr(), _dt(src), wt_dtype, k, r * s, c)
+        rows.append(row + (blocks,))
+        copy = _Copy.__new__(_Copy)
+        copy.tag, copy.t, copy.stream, copy.ev, copy.readers = tag, t, cur, None, None
+        copy.nblk = -(-c // 32) * -(-k // 32) * r * s
+        copy.row = None if temp else row
+        blocks += copy.nblk
+        keep.append((w, kind, copy))
+    key = tuple(rows)
+    tab = _WT_TABLES.get(key)
+    if tab is None:
+        if len(_WT_TABLES) >= 16:           # (a table may still be in use on another stream)
+            torch.cuda.synchronize()
+            _WT_TABLES.clear()
+        host = (_WtJob * len(rows))(*[_WtJob(*row) for row in rows])
+        dev_t = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(jobs[0][0].device)
+        torch.cuda.current_stream().synchronize()       # once per table: later steps launch it from whichever lane refreshes
+        tab = _WT_TABLES[key] = (dev_t, rows)
+    _note_batch(tab)
+    check(lib.sscg_weight_krsc_to_crsk_batch(tab[0].data_ptr(), len(rows), blocks, _stream()), "sscg_weight_krsc_to_crsk_batch")
+    for item in keep:
+        if isinstance(item, tuple):
+            w, kind, copy = item
+            try:
+                setattr(w, _WT_ATTR[kind], copy)
+            except AttributeError:
+                pass
+
+
+def _note_batch(tab):
+    """racecheck.py sees pointers in argument lists; the batch's buffers sit in a device table - announce them."""
+    note = getattr(lib, "note_batch", None)
+    if note is not None:
+        note(tab[0].data_ptr(), [(row[0], row[1]) for row in tab[1]])
 
 
 def _wtag(w):
@@ -1109,7 +1206,7 @@ class _Copy(object):
     (`record_stream`) when the copy is replaced, so that the block is not handed out while a reader is still in flight.  (Round 3
     had neither: at a model's first step - empty registry, nothing prebuilt - the copies were built by whichever of the two forward
     lanes reached a layer first and read by the other unsynchronised; racecheck.py reports exactly these launches.)"""
-    __slots__ = ("tag", "t", "ev", "stream", "readers")
+    __slots__ = ("tag", "t", "ev", "stream", "readers", "row", "nblk")
 
     def __init__(self, tag, build):
         self.tag = tag

@@ -326,12 +326,17 @@ class _Checked(object):
     def __init__(self, lib):
         self._lib = lib
         self._cache = {}
+        self._batches = {}
 
     def __getattr__(self, name):
         fn = self._cache.get(name)
         if fn is None:
             fn = self._cache[name] = self._wrap(name, getattr(self._lib, name))
         return fn
+
+    def note_batch(self, table_ptr, pairs):
+        """functional._transpose_batch: the (source, destination) pointers behind a job table in device memory."""
+        self._batches[table_ptr] = pairs
 
     def _wrap(self, name, fn):
         row = _STATE["table"].get(name)
@@ -345,6 +350,11 @@ class _Checked(object):
                 v = core.tick(s)
                 where = None
                 ext = _STATE["extent"]
+                if name == "sscg_weight_krsc_to_crsk_batch":
+                    where = "%s(%s)" % (name, _where())
+                    for src, dst in self._batches.get(a[0], ()):
+                        core.access(v, s, src, ext.get(src, 4), False, where + ".w")
+                        core.access(v, s, dst, ext.get(dst, 4), True, where + ".wt")
                 for (arg, kind), val in zip(row, a):
                     if kind not in ("r", "w") or val is None:
                         continue

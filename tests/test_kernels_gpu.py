@@ -954,3 +954,49 @@ def test_norm_backward_sums_fused_into_the_data_gradient(case, act, dev):
     assert used == [1, 0], used          # the fused route was taken exactly when it was on
     for t_f, t_u in zip(*outs):
         assert float((t_f.double() - t_u.double()).abs().max()) <= 1e-5 * float(t_u.double().abs().max()) + 1e-9
+
+
+def test_operand_copies_of_many_weights_in_one_launch_are_bit_identical(F, dev):
+    """sscg_weight_krsc_to_crsk_batch (one launch for every stale transposed operand copy of a step) against the per-weight
+    sscg_weight_krsc_to_crsk: the three destination forms, ragged channel counts, and the in-place rewrite of the second refresh."""
+    shapes = [(64, 3, 7, 7), (256, 256, 3, 3), (21, 2048, 3, 3), (1024, 256, 1, 1), (40, 24, 3, 3), (128, 64, 4, 4), (33, 65, 1, 1)]
+    kinds = {"t32": torch.float32, "t16": torch.bfloat16, "tx3": "x3"}
+    g = torch.Generator().manual_seed(5)
+    ws = [gpu(torch.randn(s, generator=g), dev) for s in shapes]
+    was, mode = F.BATCH_TRANSPOSES[0], F.get_conv_precision()
+    ptrs = None
+    try:
+        F.set_conv_precision("f32x")        # (weight_bf16 then reads a cached cast of the weight, not an optimiser's shadow arena)
+        F.BATCH_TRANSPOSES[0] = True
+        for rnd in range(2):
+            for w in ws:
+                w.mul_(1.25)                # a new version: every copy is stale
+            F._IN_REFRESH[0] = True
+            try:
+                jobs = []
+                for w in ws:
+                    F._refresh_kinds(w, tuple(kinds), jobs)
+                assert len(jobs) == 3 * len(ws)
+                F._transpose_batch(jobs)
+            finally:
+                F._IN_REFRESH[0] = False
+            now = [[getattr(w, F._WT_ATTR[k]).t.data_ptr() for k in kinds] for w in ws]
+            assert ptrs is None or ptrs == now      # the second refresh rewrote the copies of the first in place
+            ptrs = now
+            for w in ws:
+                for k, dtype in kinds.items():
+                    ta, tb = getattr(w, F._WT_ATTR[k]).t, F.weight_transposed(w, dtype)
+                    assert ta.dtype == tb.dtype and ta.shape == tb.shape and ta.stride() == tb.stride()
+                    bits = torch.int16 if ta.dtype == torch.bfloat16 else torch.int32
+                    assert torch.equal(ta.view(bits), tb.view(bits)), (tuple(w.shape), k)
+            jobs = []
+            F._IN_REFRESH[0] = True
+            try:
+                for w in ws:
+                    F._refresh_kinds(w, tuple(kinds), jobs)
+            finally:
+                F._IN_REFRESH[0] = False
+            assert jobs == []               # everything is fresh now
+    finally:
+        F.BATCH_TRANSPOSES[0] = was
+        F.set_conv_precision(mode)
