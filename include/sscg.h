@@ -265,6 +265,21 @@ int sscg_ce_fwd(const float* logits, const int64_t* labels, int64_t rows, int C,
                 size_t ws_bytes, void* stream);
 int sscg_ce_bwd(const float* logits, const int64_t* labels, int64_t rows, int C, const float* gscale, float w,
                 const float* valid, float* dx, void* stream);
+/* The head of the segmentation generator without the resized logits in memory (ABI v12): x = low-resolution logits [N][H][W][C]
+ * (C <= 64), resized to [OH][OW] by bilinear interpolation with align_corners=True (model.py:390-392, the arithmetic of
+ * sscg_upsample_bilinear_fwd), then
+ *   labels != NULL ([N][OH][OW]): nn.CrossEntropyLoss of the resized logits (model.py:398, :455; sscg_ce_fwd's label rules) into
+ *     `loss` / `valid`, and `dlogits` [N][H][W][C] = sum over the counted pixels of d(their loss term) / dx - the gradient with
+ *     respect to x up to the factor g / valid, which sscg_upsample_head_bwd applies;
+ *   y_soft != NULL ([N][OH][OW][C]): softmax over C of the resized logits (model.py:401-402).
+ * sscg_upsample_head_bwd: dx = adjoint of the resize applied to softmax_bwd(dy_soft, y_soft) (dy_soft NULL: that branch is unused)
+ * + dlogits * g_ce / valid (dlogits NULL: no cross-entropy branch; g_ce NULL = 1).  Gather form, fixed summation order.
+ * ws: sscg_upsample_head_workspace bytes (cross-entropy branch only). */
+size_t sscg_upsample_head_workspace(int N, int H, int W);
+int sscg_upsample_head_fwd(const float* x, const int64_t* labels, float* y_soft, float* loss, float* valid, float* dlogits, int N, int H,
+                           int W, int C, int OH, int OW, void* ws, size_t ws_bytes, void* stream);
+int sscg_upsample_head_bwd(const float* x, const float* dy_soft, const float* dlogits, const float* g_ce, const float* valid, float* dx,
+                           int N, int H, int W, int C, int OH, int OW, void* stream);
 /* nn.MSELoss against a constant target map of ones/zeros (LSGAN; model.py:445-446,452,521-528) */
 int sscg_mse_const_fwd(const float* x, int64_t n, float target, float* loss, void* ws, size_t ws_bytes, void* stream);
 int sscg_mse_const_bwd(const float* x, int64_t n, float target, const float* gscale, float w, float* dx, void* stream);

@@ -96,6 +96,9 @@ SIGNATURES = {
     "sscg_loss_workspace": (_sz, [_i64]),
     "sscg_ce_fwd": (_i, [_p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
     "sscg_ce_bwd": (_i, [_p, _p, _i64, _i, _p, _f, _p, _p, _p]),
+    "sscg_upsample_head_workspace": (_sz, [_i, _i, _i]),
+    "sscg_upsample_head_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "sscg_upsample_head_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sscg_mse_const_fwd": (_i, [_p, _i64, _f, _p, _p, _sz, _p]),
     "sscg_mse_const_bwd": (_i, [_p, _i64, _f, _p, _f, _p, _p]),
     "sscg_mse_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),

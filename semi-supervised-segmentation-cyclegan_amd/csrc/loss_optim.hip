@@ -155,6 +155,156 @@ __global__ void ce_bwd_kernel(const float* __restrict__ x, const int64_t* __rest
     }
 }
 
+// ---------------------------------------------------------------- upsample -> {softmax, cross entropy} from the low-resolution logits
+// model.py:390-392 (interp = bilinear, align_corners=True, to the crop size), :398 / :455 (CrossEntropyLoss on the resized logits),
+// :401-402 (softmax of the resized logits).  The resized [N][OH][OW][C] logits are never written: one block per SOURCE pixel walks
+// the output pixels whose bilinear stencil touches it (gather form: deterministic, no atomics), interpolates their logits from the
+// low-resolution map (L2-resident: N x 33 x 33 x 21 fp32 = 0.7 MB), and
+//   * the block that owns an output pixel (its stencil's top-left corner) adds its loss term / writes its softmax row,
+//   * every block sums weight * d(loss)/d(resized logit) of its output pixels: the gradient with respect to the low-resolution
+//     logits, which for the cross entropy depends on nothing but logits and labels - so the FORWARD pass already leaves it
+//     (unscaled; the backward is an elementwise scale by g / valid).
+struct HeadGeom { int N, H, W, C, OH, OW; float sh, sw, inv_sh, inv_sw; };
+
+template <int CT>
+__device__ __forceinline__ void head_logits(const float* __restrict__ xn, const HeadGeom& g, int oy, int ox, int C, float* v,
+                                            int* y0o, int* x0o) {
+    // the arithmetic of upsample_fwd_kernel (pointwise.hip)
+    const float fy = g.sh * oy, fx = g.sw * ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int yp = y0 < g.H - 1 ? 1 : 0, xp = x0 < g.W - 1 ? 1 : 0;
+    const float ly = fy - y0, lx = fx - x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* r00 = xn + ((size_t)y0 * g.W + x0) * C;
+    const float* r01 = r00 + (size_t)xp * C;
+    const float* r10 = r00 + (size_t)yp * g.W * C;
+    const float* r11 = r10 + (size_t)xp * C;
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : MAXC); ++c) {
+        if (CT == 0 && c >= C) break;
+        v[c] = hy * (hx * r00[c] + lx * r01[c]) + ly * (hx * r10[c] + lx * r11[c]);
+    }
+    *y0o = y0; *x0o = x0;
+}
+
+// weight of source row / column `i` in the stencil of output row / column `o` (upsample_bwd_kernel's)
+__device__ __forceinline__ float head_weight(float scale, int o, int i, int n_src) {
+    const float f = scale * o;
+    const int i0 = (int)f;
+    const int ip = i0 < n_src - 1 ? 1 : 0;
+    const float l = f - i0;
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l;
+    if (i0 + ip == i) w += l;
+    return w;
+}
+
+// MODE 0: forward (labels and / or softmax output); MODE 1: backward of the softmax output (dy_soft), plus the scaled
+// cross-entropy gradient the forward left
+template <int CT, int MODE>
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const int64_t* __restrict__ lab, float* __restrict__ y_soft,
+                                                   const float* __restrict__ dy_soft, float* __restrict__ dlo, const float* __restrict__ dl_ce,
+                                                   const float* __restrict__ g_ce, const float* __restrict__ valid,
+                                                   double* __restrict__ part, int nparts, HeadGeom g) {
+    __shared__ float red[4][MAXC];
+    const int C = CT ? CT : g.C;
+    const int b = blockIdx.x;
+    const int ix = b % g.W, iy = (b / g.W) % g.H, n = b / (g.W * g.H);
+    int oy_lo = (int)floorf((iy - 1) * g.inv_sh) - 1, oy_hi = (int)ceilf((iy + 1) * g.inv_sh) + 1;
+    int ox_lo = (int)floorf((ix - 1) * g.inv_sw) - 1, ox_hi = (int)ceilf((ix + 1) * g.inv_sw) + 1;
+    oy_lo = max(oy_lo, 0); ox_lo = max(ox_lo, 0);
+    oy_hi = min(oy_hi, g.OH - 1); ox_hi = min(ox_hi, g.OW - 1);
+    const int nx = ox_hi - ox_lo + 1, cand = (oy_hi - oy_lo + 1) * nx;
+    const float* xn = x + (size_t)n * g.H * g.W * C;
+    float acc[CT ? CT : MAXC];
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : MAXC); ++c) acc[c] = 0.f;
+    double loss = 0.0, cnt = 0.0;
+    for (int t = threadIdx.x; t < cand; t += 256) {
+        const int oy = oy_lo + t / nx, ox = ox_lo + t % nx;
+        const float wy = head_weight(g.sh, oy, iy, g.H);
+        if (wy == 0.f) continue;
+        const float wx = head_weight(g.sw, ox, ix, g.W);
+        if (wx == 0.f) continue;
+        const float w = wy * wx;
+        float v[CT ? CT : MAXC];
+        int y0, x0;
+        head_logits<CT>(xn, g, oy, ox, C, v, &y0, &x0);
+        const bool owner = y0 == iy && x0 == ix;
+        const size_t o = ((size_t)n * g.OH + oy) * g.OW + ox;
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < (CT ? CT : MAXC); ++c) { if (CT == 0 && c >= C) break; m = fmaxf(m, v[c]); }
+        int l = -1;
+        float vl = 0.f;
+        if (MODE == 0 && lab) {
+            const int64_t l64 = lab[o];
+            l = (l64 < 0 || l64 >= C) ? -1 : (int)l64;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < (CT ? CT : MAXC); ++c) {
+            if (CT == 0 && c >= C) break;
+            if (c == l) vl = v[c];
+            v[c] = expf(v[c] - m);
+            s += v[c];
+        }
+        const float inv = 1.f / s;
+        if (MODE == 0) {
+            if (owner && l >= 0) { loss += (double)(logf(s) + m - vl); cnt += 1.0; }
+            if (owner && y_soft) {
+                float* yr = y_soft + o * C;
+#pragma unroll
+                for (int c = 0; c < (CT ? CT : MAXC); ++c) { if (CT == 0 && c >= C) break; yr[c] = v[c] * inv; }
+            }
+            if (l >= 0) {
+#pragma unroll
+                for (int c = 0; c < (CT ? CT : MAXC); ++c) { if (CT == 0 && c >= C) break; acc[c] += w * (v[c] * inv - (c == l ? 1.f : 0.f)); }
+            }
+        } else {
+            const float* gr = dy_soft + o * C;
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < (CT ? CT : MAXC); ++c) { if (CT == 0 && c >= C) break; v[c] *= inv; dot += v[c] * gr[c]; }
+#pragma unroll
+            for (int c = 0; c < (CT ? CT : MAXC); ++c) { if (CT == 0 && c >= C) break; acc[c] += w * (v[c] * (gr[c] - dot)); }
+        }
+    }
+    const bool want_sum = MODE == 1 || (lab && dlo);
+    if (want_sum) {
+#pragma unroll
+        for (int c = 0; c < (CT ? CT : MAXC); ++c) {
+            if (CT == 0 && c >= C) break;
+            const float r = wave_sum(acc[c]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = r;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            const int c = threadIdx.x;
+            float r = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            if (MODE == 1 && dl_ce) {
+                const float nv = valid ? *valid : 0.f;
+                r += dl_ce[(size_t)b * C + c] * ((g_ce ? *g_ce : 1.f) * (nv > 0.f ? 1.f / nv : 0.f));
+            }
+            dlo[(size_t)b * C + c] = r;
+        }
+    }
+    if (MODE == 0 && lab && part) {
+        __syncthreads();
+        block_sum_to(loss, part + b);
+        __syncthreads();
+        block_sum_to(cnt, part + nparts + b);
+    }
+}
+
+// backward of the cross entropy alone: dx = dl * g / valid
+__global__ void head_scale_kernel(const float* __restrict__ dl, const float* __restrict__ g_ce, const float* __restrict__ valid,
+                                  float* __restrict__ dx, size_t n) {
+    const float nv = valid ? *valid : 0.f;
+    const float k = (g_ce ? *g_ce : 1.f) * (nv > 0.f ? 1.f / nv : 0.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dx[i] = dl[i] * k;
+}
+
 // ---------------------------------------------------------------- MSE vs constant, L1
 __global__ void mse_const_fwd_kernel(const float* __restrict__ x, size_t n, float target, double* __restrict__ part) {
     double acc = 0.0;
@@ -322,6 +472,63 @@ extern "C" int sscg_ce_fwd(const float* logits, const int64_t* labels, int64_t r
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, labels, (size_t)rows, C, part, nb);
     hipLaunchKernelGGL(finish_ce_kernel, dim3(1), dim3(256), 0, st, part, nb, loss, valid);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+static bool head_geom(HeadGeom* g, int N, int H, int W, int C, int OH, int OW) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C > MAXC || OH <= 0 || OW <= 0) return false;
+    if ((size_t)N * H * W >= ((size_t)1 << 31)) return false;
+    g->N = N; g->H = H; g->W = W; g->C = C; g->OH = OH; g->OW = OW;
+    g->sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    g->sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    g->inv_sh = g->sh > 0.f ? 1.f / g->sh : (float)OH;
+    g->inv_sw = g->sw > 0.f ? 1.f / g->sw : (float)OW;
+    return true;
+}
+
+template <int MODE>
+static void launch_head(const HeadGeom& g, hipStream_t st, const float* x, const int64_t* lab, float* y_soft, const float* dy_soft,
+                        float* dlo, const float* dl_ce, const float* g_ce, const float* valid, double* part, int nparts) {
+    const dim3 grid(nparts), blk(256);
+    if (g.C == 21) hipLaunchKernelGGL((head_kernel<21, MODE>), grid, blk, 0, st, x, lab, y_soft, dy_soft, dlo, dl_ce, g_ce, valid, part, nparts, g);
+    else if (g.C == 20) hipLaunchKernelGGL((head_kernel<20, MODE>), grid, blk, 0, st, x, lab, y_soft, dy_soft, dlo, dl_ce, g_ce, valid, part, nparts, g);
+    else if (g.C == 4) hipLaunchKernelGGL((head_kernel<4, MODE>), grid, blk, 0, st, x, lab, y_soft, dy_soft, dlo, dl_ce, g_ce, valid, part, nparts, g);
+    else hipLaunchKernelGGL((head_kernel<0, MODE>), grid, blk, 0, st, x, lab, y_soft, dy_soft, dlo, dl_ce, g_ce, valid, part, nparts, g);
+}
+
+extern "C" size_t sscg_upsample_head_workspace(int N, int H, int W) {
+    return (size_t)2 * (size_t)(N > 0 ? N : 0) * (size_t)(H > 0 ? H : 0) * (size_t)(W > 0 ? W : 0) * sizeof(double);
+}
+
+extern "C" int sscg_upsample_head_fwd(const float* x, const int64_t* labels, float* y_soft, float* loss, float* valid, float* dlogits,
+                                      int N, int H, int W, int C, int OH, int OW, void* ws, size_t ws_bytes, void* stream) {
+    HeadGeom g;
+    if (!x || !head_geom(&g, N, H, W, C, OH, OW) || (!labels && !y_soft)) return SSCG_ERR_BAD_ARG;
+    if (labels && (!loss || !valid || !dlogits)) return SSCG_ERR_BAD_ARG;
+    if (labels && (!ws || ws_bytes < sscg_upsample_head_workspace(N, H, W))) return SSCG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nparts = N * H * W;
+    double* part = labels ? reinterpret_cast<double*>(ws) : nullptr;
+    launch_head<0>(g, st, x, labels, y_soft, nullptr, labels ? dlogits : nullptr, nullptr, nullptr, nullptr, part, nparts);
+    if (labels) hipLaunchKernelGGL(finish_ce_kernel, dim3(1), dim3(256), 0, st, part, nparts, loss, valid);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
+extern "C" int sscg_upsample_head_bwd(const float* x, const float* dy_soft, const float* dlogits, const float* g_ce, const float* valid,
+                                      float* dx, int N, int H, int W, int C, int OH, int OW, void* stream) {
+    HeadGeom g;
+    if (!x || !dx || !head_geom(&g, N, H, W, C, OH, OW) || (!dy_soft && !dlogits)) return SSCG_ERR_BAD_ARG;
+    if (dlogits && !valid) return SSCG_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nparts = N * H * W;
+    if (dy_soft)
+        launch_head<1>(g, st, x, nullptr, nullptr, dy_soft, dx, dlogits, g_ce, valid, nullptr, nparts);
+    else {
+        const size_t n = (size_t)nparts * C;
+        hipLaunchKernelGGL(head_scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, dlogits, g_ce, valid, dx, n);
+    }
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

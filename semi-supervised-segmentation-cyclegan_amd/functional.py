@@ -1876,6 +1876,67 @@ class CrossEntropyFn(torch.autograd.Function):
         return dx, None
 
 
+FUSE_HEAD = [os.environ.get("SSCG_FUSE_HEAD", "1") != "0"]      # interp -> {softmax, cross entropy} without the resized logits in memory
+
+
+def _head_applies(x, oh, ow):
+    """One block per source pixel gathers the output pixels around it: worth it when the map grows (DeepLab's 33x33 -> the crop)."""
+    return (FUSE_HEAD[0] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 64
+            and oh * ow >= 16 * x.shape[2] * x.shape[3])
+
+
+class UpsampleHeadFn(torch.autograd.Function):
+    """interp (bilinear, align_corners=True) -> softmax2d and / or nn.CrossEntropyLoss, from the LOW-resolution logits (model.py:390-392,
+    398, 401-402, 455).  Returns (softmax map or None, loss or None).  The forward of the cross-entropy branch already leaves the
+    gradient with respect to the low-resolution logits (it depends on logits and labels only); the backward scales it."""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow, labels, want_soft):
+        _need_hip(x, f32_only=True)
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, oh, ow, x.device) if want_soft else None
+        loss = valid = dl = ws = None
+        if labels is not None:
+            labels = labels.contiguous()
+            if labels.numel() != n * oh * ow or labels.dtype != torch.int64:
+                raise _lib.SscgError("labels must be int64 with N*OH*OW elements")
+            loss, valid = _scalar(x.device), _scalar(x.device)
+            dl = empty_nhwc(n, c, h, w, x.device)
+            ws = torch.empty(lib.sscg_upsample_head_workspace(n, h, w), dtype=torch.uint8, device=x.device)
+        check(lib.sscg_upsample_head_fwd(x.data_ptr(), _ptr(labels), _ptr(y), _ptr(loss), _ptr(valid), _ptr(dl), n, h, w, c, oh, ow,
+                                         _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "sscg_upsample_head_fwd")
+        ctx.geom = (oh, ow)
+        ctx.save_for_backward(x, dl, valid)
+        return y, loss
+
+    @staticmethod
+    def backward(ctx, dy, g):
+        x, dl, valid = ctx.saved_tensors
+        oh, ow = ctx.geom
+        n, c, h, w = x.shape
+        if dy is None and (g is None or dl is None):
+            return None, None, None, None, None
+        if dy is not None:
+            dy = to_nhwc(dy)
+        use_ce = g is not None and dl is not None
+        dx = empty_nhwc(n, c, h, w, x.device)
+        check(lib.sscg_upsample_head_bwd(x.data_ptr(), _ptr(dy), _ptr(dl if use_ce else None), _ptr(g if use_ce else None),
+                                         _ptr(valid if use_ce else None), dx.data_ptr(), n, h, w, c, oh, ow, _stream()),
+              "sscg_upsample_head_bwd")
+        return dx, None, None, None, None
+
+
+def upsample_softmax_ce(x, size, labels=None, want_soft=True):
+    """(softmax2d(interp(x)) or None, CrossEntropyLoss(interp(x), labels) or None) - fused when the resize grows the map, else the
+    three separate passes."""
+    oh, ow = int(size[0]), int(size[1])
+    if _head_applies(x, oh, ow):
+        return UpsampleHeadFn.apply(x, oh, ow, labels, want_soft)
+    up = upsample_bilinear(x, size)
+    return (softmax2d(up) if want_soft else None), (cross_entropy(up, labels) if labels is not None else None)
+
+
 class MSEConstFn(torch.autograd.Function):
     """nn.MSELoss()(x, full_like(x, target)) - the LSGAN terms."""
 

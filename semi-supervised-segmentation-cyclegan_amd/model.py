@@ -186,16 +186,16 @@ class semisuper_cycleGAN(object):
             with arch.batch_groups(2):
                 both = self.Gsi(torch.cat([unl_img, l_img], 0))
             fake_logits, lab_logits = F.split_batch(both, 2)
-            fake_gt, lab_gt = self.interp(fake_logits), self.interp(lab_logits)     # :391-392
         else:
-            fake_gt = self.interp(self.Gsi(unl_img))                                 # :386,391
-            lab_gt = self.interp(self.Gsi(l_img))                                    # :387,392
+            fake_logits = self.Gsi(unl_img)                                          # :386
+            lab_logits = self.Gsi(l_img)                                             # :387
         if fork:
             gsi_second = torch.cuda.Event()
             gsi_second.record(main)
-        lab_loss_CE = F.cross_entropy(lab_gt, labels)                                # :398
-        lab_gt = F.softmax2d(lab_gt)                                                 # :401
-        fake_gt = F.softmax2d(fake_gt)                                               # :402
+        # :391-392 (interp), :398 (CE of the resized logits), :401-402 (their softmax) from the low-resolution logits in one pass each:
+        # the resized [B, C, crop] logits are never written (functional.UpsampleHeadFn)
+        lab_gt, lab_loss_CE = F.upsample_softmax_ce(lab_logits, self.crop, labels)
+        fake_gt, _ = F.upsample_softmax_ce(fake_logits, self.crop)
         if fork:
             main.wait_event(gis_first)
         if self.stack_gis:
@@ -222,13 +222,13 @@ class semisuper_cycleGAN(object):
             with torch.cuda.stream(lane):
                 lane.wait_event(gsi_second)
                 fake_img, fake_img_d, fake_img_l1 = F.split(fake_img, 3)             # consumers: Gsi, Di, L1
-                recon_gt = self.interp(self.Gsi(fake_img))                           # :410,415
+                recon_logits = self.Gsi(fake_img)                                    # :410
             main.wait_stream(lane)
             fake_img.record_stream(main)
-            recon_gt.record_stream(main)
+            recon_logits.record_stream(main)
         else:
             fake_img, fake_img_d, fake_img_l1 = F.split(fake_img, 3)                 # consumers: Gsi, Di, L1
-            recon_gt = self.interp(self.Gsi(fake_img))                               # :410,415
+            recon_logits = self.Gsi(fake_img)                                        # :410
         extra_terms, extra_weights, extras = [], [], {}
         if "l1_cycle" in self.variants:                                              # :453 (commented out in the reference)
             recon_img, recon_img_l1 = F.split(recon_img, 2)
@@ -258,7 +258,7 @@ class semisuper_cycleGAN(object):
         img_gen_loss = F.mse_const(fake_img_dis, 1.0)                                # :445
         gt_gen_loss = F.mse_const(fake_gt_dis, 1.0)                                  # :446
         img_cycle_loss = F.mse_const(resnet_fake_img_dis, 1.0)                       # :452
-        gt_cycle_loss = F.cross_entropy(recon_gt, labels)                            # :455
+        _, gt_cycle_loss = F.upsample_softmax_ce(recon_logits, self.crop, labels, want_soft=False)    # :415 (interp), :455
         lab_loss_MSE = F.l1_loss(fake_img_l1, l_img)                                 # :461
         # :464-468  gen_loss = CE_w*CE + MSE_w*L1 + adv_w*(img_gen + gt_gen) + img_cycle + lamda_gt*gt_cycle
         gen_loss = F.weighted_sum(
@@ -467,8 +467,8 @@ class supervised_model(object):
     def step(self, l_img, l_gt):
         """model.py:120-143."""
         self.gsi_optimizer.zero_grad()
-        out = F.upsample_bilinear(self.Gsi(l_img), self.crop)
-        loss = F.cross_entropy(out, l_gt.reshape(l_gt.shape[0], l_gt.shape[2], l_gt.shape[3]))
+        _, loss = F.upsample_softmax_ce(self.Gsi(l_img), self.crop, l_gt.reshape(l_gt.shape[0], l_gt.shape[2], l_gt.shape[3]),
+                                        want_soft=False)
         F.backward(loss)
         if self.dp is not None:
             F.SideStream.join(l_img.device)

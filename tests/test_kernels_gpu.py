@@ -285,6 +285,62 @@ def test_softmax_ce_losses(C, F, dev):
     assert rel_err(xg2.grad, xr2.grad) < 1e-5
 
 
+@pytest.mark.parametrize("branches", ["ce", "soft", "both"])
+@pytest.mark.parametrize("geom", [(2, 21, 33, 33, 256, 256), (2, 4, 9, 9, 64, 64), (1, 20, 17, 33, 128, 256), (2, 21, 1, 1, 8, 8),
+                                  (1, 7, 5, 3, 40, 37)])
+def test_upsample_head_fused(geom, branches, F, dev):
+    """interp -> {softmax2d, CrossEntropyLoss} from the low-resolution logits (model.py:390-392, 398, 401-402, 455;
+    sscg_upsample_head_fwd / _bwd: the resized logits are never written) against torch in fp64, and against the three separate HIP
+    passes; out-of-range labels are ignored as nn.CrossEntropyLoss ignores ignore_index."""
+    N, C, H, W, OH, OW = geom
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64) * 2
+    lab = torch.randint(0, C, (N, OH, OW), generator=g)
+    lab[0, :3] = 255
+    lab[-1, OH // 2, :] = -100
+    ref_lab = lab.clone()
+    ref_lab[(lab < 0) | (lab >= C)] = -100
+    gy = torch.randn(N, C, OH, OW, generator=g, dtype=torch.float64)
+    want_ce, want_soft = branches in ("ce", "both"), branches in ("soft", "both")
+
+    xr = x.clone().requires_grad_(True)
+    up = TF.interpolate(xr, size=(OH, OW), mode="bilinear", align_corners=True)
+    lr_ = TF.cross_entropy(up, ref_lab, ignore_index=-100) if want_ce else None
+    sr = torch.softmax(up, 1) if want_soft else None
+    ((lr_ * 0.37 if want_ce else 0) + ((sr * gy).sum() if want_soft else 0)).backward()
+
+    def run(fused):
+        was = F.FUSE_HEAD[0]
+        F.FUSE_HEAD[0] = fused
+        try:
+            xg = gpu(x, dev).requires_grad_(True)
+            assert F._head_applies(xg, OH, OW) == fused
+            sg, lg = F.upsample_softmax_ce(xg, (OH, OW), lab.to(dev) if want_ce else None, want_soft=want_soft)
+            assert (sg is not None) == want_soft and (lg is not None) == want_ce
+            terms, wts = [], []
+            if want_ce:
+                terms.append(lg); wts.append(0.37)
+            if want_soft:
+                terms.append((sg * gpu(gy, dev)).sum()); wts.append(1.0)
+            F.weighted_sum(terms, wts).backward() if len(terms) > 1 or want_ce else terms[0].backward()
+            return sg, lg, xg.grad
+        finally:
+            F.FUSE_HEAD[0] = was
+
+    sg, lg, dx = run(True)
+    if want_ce:
+        assert rel_err(lg, lr_) < 1e-6
+    if want_soft:
+        assert rel_err(sg, sr) < 2e-5       # fp32 interpolation weights (test_upsample: 1e-5 on the resized logits themselves)
+    assert rel_err(dx, xr.grad) < 3e-5
+    sg0, lg0, dx0 = run(False)          # the separate passes (upsample, softmax, cross entropy) agree to fp32 rounding
+    if want_ce:
+        assert rel_err(lg, lg0) < 1e-6
+    if want_soft:
+        assert rel_err(sg, sg0) < 1e-6
+    assert rel_err(dx, dx0) < 1e-5
+
+
 def test_cross_entropy_ignores_out_of_range_labels(F, dev):
     """Labels outside [0, C) (255 'void', -100) follow nn.CrossEntropyLoss's ignore_index semantics: excluded from the mean,
     zero gradient, no out-of-bounds read.  label_onehot writes an all-zero row for them."""
