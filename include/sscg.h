@@ -157,22 +157,31 @@ int sscg_norm_apply(const void* x, const float* mean, const float* rstd, const f
                     const void* residual, void* y, int dtype, int G, int64_t L, int C, int act, float slope, void* stream);
 /* eval-mode BatchNorm: mean = running_mean, rstd = 1/sqrt(running_var + eps) */
 /* The reduction pass of a normalisation layer's backward, fused into the data gradient that produces its upstream gradient
- * ("Conv -> norm -> ReLU -> Conv" chains: arch/ops.py:40-57, the Bottleneck's conv1-bn1-relu-conv2-bn2-relu-conv3,
- * arch/generators.py:345-365; autograd of model.py:472,539).  sscg_conv2d_dgrad_bsums is sscg_conv2d_dgrad (no bias, no
- * activation) of the CONSUMER convolution; its result dx is the gradient at the output of act(norm(nx)) with nx [G * L][C]
- * (C = d->C), and its epilogue also leaves, per tile row and channel, the fp64 sums of gg and gg * xhat (gg = act'(...) dx,
- * xhat = (nx - mean) * rstd; the ReLU / LeakyReLU mask recomputed as the sign of gamma * xhat + beta: layers without a residual
- * only) in `sums`.  sscg_norm_bwd_from_sums (same descriptor d) then finishes that layer's backward - finalize + apply, no
- * pass over (dx, nx) for the sums.  sscg_conv2d_dgrad_bsums_bytes returns 0 when the fusion does not apply to the geometry
- * (strided / few-channel / bf16 data gradients, groups shorter than a tile): use sscg_conv2d_dgrad + sscg_norm_bwd. */
+ * ("Conv -> norm -> ReLU -> Conv" chains: arch/ops.py:40-57, the Bottleneck's conv1-bn1-relu-conv2-bn2-relu-conv3 and the
+ * bn3 + residual -> relu -> next block's conv1 link, arch/generators.py:345-365; autograd of model.py:472,539).
+ * sscg_conv2d_dgrad_bsums is sscg_conv2d_dgrad (no bias, no activation) of the CONSUMER convolution; its result dx
+ * (+ addend, below) is the gradient at the output of act(norm(nx) [+ residual]) with nx [G * L][C] (C = d->C), and its epilogue
+ * also leaves, per tile row and channel, the fp64 sums of gg and gg * xhat (gg = act'(...) dx, xhat = (nx - mean) * rstd) in `sums`.
+ * The ReLU / LeakyReLU mask is the sign of gamma * xhat + beta for a unit without a residual (nz NULL), and the sign of the unit's
+ * forward output nz ([G * L][C]; this conv's own input) for a unit a residual joined (fp32 tensors only).
+ * addend (nullable, [N][H][W][C] like dx; fp32 tensors only): dx = dgrad(dy, wt) + addend - the gradient another consumer of the
+ * same tensor left (a residual block's input feeds conv1 and the shortcut): the fan-in joins in the store phase, the sums see the
+ * total.  sscg_norm_bwd_from_sums (same descriptor d) then finishes that layer's backward - finalize + apply, no pass over
+ * (dx, nx) for the sums; y / dres (nullable): the unit's forward output and the residual's gradient, for a unit a residual joined.
+ * sscg_conv2d_dgrad_bsums_bytes returns 0 when the fusion does not apply to the geometry (strided / few-channel data gradients,
+ * groups shorter than a tile): use sscg_conv2d_dgrad + sscg_norm_bwd.
+ * sscg_conv2d_dgrad_add: the addend alone (no sums), wherever sscg_conv2d_dgrad_add_applies (the split family, any stride). */
 size_t sscg_conv2d_dgrad_bsums_bytes(const sscg_conv_desc* d, int G, int64_t L);
-int sscg_conv2d_dgrad_bsums(const sscg_conv_desc* d, const void* dy, const void* wt, void* dx, const void* nx, const float* mean,
-                            const float* rstd, const float* gamma, const float* beta, int G, int64_t L, int act, float slope,
-                            void* sums, size_t sums_bytes, void* ws, size_t ws_bytes, void* stream);
+int sscg_conv2d_dgrad_bsums(const sscg_conv_desc* d, const void* dy, const void* wt, void* dx, const void* nx, const void* nz,
+                            const void* addend, const float* mean, const float* rstd, const float* gamma, const float* beta, int G,
+                            int64_t L, int act, float slope, void* sums, size_t sums_bytes, void* ws, size_t ws_bytes, void* stream);
+int sscg_conv2d_dgrad_add_applies(const sscg_conv_desc* d);
+int sscg_conv2d_dgrad_add(const sscg_conv_desc* d, const void* dy, const void* wt, const void* addend, void* dx, void* ws,
+                          size_t ws_bytes, void* stream);
 /* flags: bit 1 = dgamma / dbeta are written (else accumulated); ws: G * C * 2 floats */
-int sscg_norm_bwd_from_sums(const sscg_conv_desc* d, const void* sums, const void* dy, const void* x, const float* mean,
-                            const float* rstd, const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, int dtype,
-                            int G, int64_t L, int C, int act, float slope, int flags, void* ws, size_t ws_bytes, void* stream);
+int sscg_norm_bwd_from_sums(const sscg_conv_desc* d, const void* sums, const void* dy, const void* x, const void* y, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta,
+                            int dtype, int G, int64_t L, int C, int act, float slope, int flags, void* ws, size_t ws_bytes, void* stream);
 
 int sscg_rstd_from_var(const float* var, float* rstd, int n, float eps, void* stream);
 /* backward of norm_apply (+ of the statistics): dx always; dres (= masked dy) if non-NULL;

@@ -50,8 +50,10 @@ SIGNATURES = {
     "sscg_conv2d_dgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_dgrad": (_i, [_dp, _p, _p, _p, _p, _i, _f, _p, _sz, _p]),
     "sscg_conv2d_dgrad_bsums_bytes": (_sz, [_dp, _i, _i64]),
-    "sscg_conv2d_dgrad_bsums": (_i, [_dp, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p, _sz, _p, _sz, _p]),
-    "sscg_norm_bwd_from_sums": (_i, [_dp, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
+    "sscg_conv2d_dgrad_bsums": (_i, [_dp, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p, _sz, _p, _sz, _p]),
+    "sscg_conv2d_dgrad_add_applies": (_i, [_dp]),
+    "sscg_conv2d_dgrad_add": (_i, [_dp, _p, _p, _p, _p, _p, _sz, _p]),
+    "sscg_norm_bwd_from_sums": (_i, [_dp, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
     "sscg_conv2d_wgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_wgrad": (_i, [_dp, _p, _p, _p, _f, _p, _sz, _p]),
     "sscg_weight_krsc_to_crsk": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),

@@ -972,18 +972,36 @@ extern "C" size_t sscg_conv2d_dgrad_bsums_bytes(const sscg_conv_desc* d, int G, 
     return (size_t)G * chunks * d->C * 2 * sizeof(double);
 }
 
-extern "C" int sscg_conv2d_dgrad_bsums(const sscg_conv_desc* d, const void* dy, const void* wt, void* dx, const void* nx,
-                                       const float* mean, const float* rstd, const float* gamma, const float* beta, int G, int64_t L,
-                                       int act, float slope, void* sums, size_t sums_bytes, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int sscg_conv2d_dgrad_bsums(const sscg_conv_desc* d, const void* dy, const void* wt, void* dx, const void* nx, const void* nz,
+                                       const void* addend, const float* mean, const float* rstd, const float* gamma, const float* beta, int G,
+                                       int64_t L, int act, float slope, void* sums, size_t sums_bytes, void* ws, size_t ws_bytes,
+                                       void* stream) {
     if (!d || !dy || !wt || !dx || !nx || !mean || !rstd || !sums) return SSCG_ERR_BAD_ARG;
     if ((gamma != nullptr) != (beta != nullptr)) return SSCG_ERR_BAD_ARG;
-    if (act != SSCG_ACT_NONE && act != SSCG_ACT_RELU && act != SSCG_ACT_LRELU) return SSCG_ERR_UNSUPPORTED;      // the mask is recomputed from nx
+    if (act != SSCG_ACT_NONE && act != SSCG_ACT_RELU && act != SSCG_ACT_LRELU) return SSCG_ERR_UNSUPPORTED;      // the mask is recomputed from nx / read off nz
     const size_t need = sscg_conv2d_dgrad_bsums_bytes(d, G, L);
     if (need == 0) return SSCG_ERR_UNSUPPORTED;
     if (sums_bytes < need) return SSCG_ERR_WORKSPACE;
-    sscg_bsums bs = {nx, mean, rstd, gamma, beta, sums, G, (long)L, act, slope};
-    if (sscg_conv16_dgrad_applies(d)) return sscg_conv16_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, &bs);
-    return sscg_convs_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, &bs);
+    sscg_bsums bs = {nx, nz, mean, rstd, gamma, beta, sums, G, (long)L, act, slope};
+    if (sscg_conv16_dgrad_applies(d)) {
+        if (nz || addend) return SSCG_ERR_UNSUPPORTED;          // (the bf16 kernel: sums of residual-free units only)
+        return sscg_conv16_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, &bs);
+    }
+    return sscg_convs_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, &bs, addend);
+}
+
+// dx = dgrad(dy, wt) + addend: the fan-in of a tensor with two consumers (a residual block's input: conv1 and the shortcut) joins in
+// the data gradient's store phase instead of a separate add pass.  The split family only (fp32 tensors).
+extern "C" int sscg_conv2d_dgrad_add_applies(const sscg_conv_desc* d) {
+    return (d && check_desc(d) == SSCG_OK && d->pad_mode == 0 && !sscg_thin1x1_dgrad_applies(d, nullptr, SSCG_ACT_NONE) && !sscg_conv16_dgrad_applies(d) &&
+            sscg_convs_dgrad_applies(d)) ? 1 : 0;
+}
+
+extern "C" int sscg_conv2d_dgrad_add(const sscg_conv_desc* d, const void* dy, const void* wt, const void* addend, void* dx, void* ws,
+                                     size_t ws_bytes, void* stream) {
+    if (!d || !dy || !wt || !addend || !dx) return SSCG_ERR_BAD_ARG;
+    if (!sscg_conv2d_dgrad_add_applies(d)) return SSCG_ERR_UNSUPPORTED;
+    return sscg_convs_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, nullptr, addend);
 }
 
 bool sscg_bsums_records(const sscg_conv_desc* d, int G, int64_t L, int* bm, int* wm, int* chunks) { return d && bsums_geometry(d, G, L, bm, wm, chunks); }

@@ -77,6 +77,8 @@ struct KsParams {
     // data gradient only: the backward sums of the normalisation layer whose OUTPUT this launch differentiates (sscg_conv2d_dgrad_bsums).
     // dst is dz; per channel n and group g:  sum gg,  sum gg * xhat  with  xhat = (nx - mean) * rstd,  gg = act'(gamma xhat + beta) dz
     const float* __restrict__ bn_x;      // [M][Ng] the layer's input (pre-normalisation), or null
+    const float* __restrict__ bn_z;      // [M][Ng] the layer's OUTPUT act(norm(bn_x) + residual): the mask source of a unit a residual joined, or null
+    const float* __restrict__ addend;    // [M][Ng] added to the result (the gradient another consumer of the same tensor left), or null
     const float* __restrict__ bn_mean;   // [G][Ng]
     const float* __restrict__ bn_rstd;
     const float* __restrict__ bn_gamma;  // [Ng] or null
@@ -570,15 +572,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
                     const int oj = rem - oi * p.OW;
                     row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
                 }
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
+                f32x4 v = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
+                if (MODE == MODE_DGRAD && p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + row * p.Ng + n);
                 *reinterpret_cast<f32x4*>(p.dst + row * p.Ng + n) = v;
                 if (want_bsums) {
                     const f32x4 y = *reinterpret_cast<const f32x4*>(p.bn_x + (size_t)m * p.Ng + n);
+                    f32x4 z = 0.f;
+                    if (p.bn_z) z = *reinterpret_cast<const f32x4*>(p.bn_z + (size_t)m * p.Ng + n);
                     const bool lo = m < gb;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float xh = (y[e] - (lo ? mu0[e] : mu1[e])) * (lo ? rs0[e] : rs1[e]);
-                        const float ym = xh * ga[e] + be[e];
+                        const float ym = p.bn_z ? z[e] : xh * ga[e] + be[e];       // (sign of the output = sign of the pre-activation)
                         float gg = v[e];
                         if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? gg : 0.f;
                         else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? gg : gg * p.bn_slope;
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
 
 // y[i] = act(sum_s part[s][i] + bias[i % Ng])   (fixed order => deterministic); 4 floats per thread (Ng % 4 == 0)
 __global__ __launch_bounds__(256) void ks_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
-                                                         size_t n, int Ng, int splits, int act, float slope) {
+                                                         size_t n, int Ng, int splits, int act, float slope, const float* __restrict__ addend) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     f32x4 s = 0.f;
@@ -627,8 +632,14 @@ __global__ __launch_bounds__(256) void ks_reduce_kernel(const float* __restrict_
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = sscg_act(s[e] + (bias ? bias[c + e] : 0.f), act, slope);
+    if (addend) o += *reinterpret_cast<const f32x4*>(addend + i);
     *reinterpret_cast<f32x4*>(y + i) = o;
 }
+
+#ifndef KS_STAGE_OUT
+#define KS_STAGE_OUT 1
+#endif
+constexpr bool KS_STAGE_OUT_HOST = KS_STAGE_OUT != 0;      // the addend joins in the staged store phase
 
 // ---- host side: tile classes and the split-K plan of the tail (same policy as conv_igemm.hip)
 enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_NCFG = 5 };
@@ -724,7 +735,7 @@ int launch_ks(const KsParams& p0, hipStream_t st) {
         if (p.xstats)
             return launch_split_reduce_stats(p.part, p.bias, yt, 0, p.M - p.m_tail0, p.Ng, p.splits, p.act, p.slope, p.xstats, st);
         hipLaunchKernelGGL(ks_reduce_kernel, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st, p.part, p.bias, yt, n, p.Ng, p.splits, p.act,
-                           p.slope);
+                           p.slope, p.addend ? p.addend + (size_t)p.m_tail0 * p.Ng : nullptr);
         SSCG_LAUNCH_CHECK();
     }
     return SSCG_OK;
@@ -871,15 +882,20 @@ bool sscg_convs_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, 
 }
 
 int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs) {
+                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs, const void* addend) {
     KsParams p = {};
     bool fused = false;
+    if (addend) {
+        if (bias || act != SSCG_ACT_NONE || !KS_STAGE_OUT_HOST) return SSCG_ERR_UNSUPPORTED;
+        p.addend = reinterpret_cast<const float*>(addend);
+    }
     if (bs) {
         int bm, wm, chunks;
         if (bias || act != SSCG_ACT_NONE || !sscg_convs_bsums_geometry(d, bs->G, bs->L, &bm, &wm, &chunks)) return SSCG_ERR_UNSUPPORTED;
         p.bn_x = reinterpret_cast<const float*>(bs->nx); p.bn_mean = bs->mean; p.bn_rstd = bs->rstd; p.bn_gamma = bs->gamma; p.bn_beta = bs->beta;
         p.bn_sums = reinterpret_cast<double*>(bs->sums); p.bn_L = (int)bs->L; p.bn_G = bs->G; p.bn_chunks = chunks;
         p.bn_act = bs->act; p.bn_slope = bs->slope;
+        p.bn_z = reinterpret_cast<const float*>(bs->nz);
         fused = true;
     }
     p.src = reinterpret_cast<const float*>(dy); p.wgt = reinterpret_cast<const bf16*>(wt); p.wplane = ks_plane(d);

@@ -794,14 +794,16 @@ extern "C" int sscg_norm_bwd(const void* dy, const void* x, const void* y, const
     return SSCG_OK;
 }
 
-// Backward of y = act(norm(x)) (batch statistics, no residual) whose per-channel sums were already taken by the data gradient that
+// Backward of y = act(norm(x) [+ residual]) (batch statistics) whose per-channel sums were already taken by the data gradient that
 // produced dy (sscg_conv2d_dgrad_bsums with descriptor d): finalize + apply only - the reduction pass over (dy, x) is gone.
-extern "C" int sscg_norm_bwd_from_sums(const sscg_conv_desc* d, const void* sums, const void* dy, const void* x, const float* mean,
-                                       const float* rstd, const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta,
-                                       int dtype, int G, int64_t L, int C, int act, float slope, int flags, void* ws, size_t ws_bytes,
-                                       void* stream) {
+// y / dres: the unit's forward output (mask source) and the residual's gradient, for a unit a residual joined (sums taken with nz).
+extern "C" int sscg_norm_bwd_from_sums(const sscg_conv_desc* d, const void* sums, const void* dy, const void* x, const void* y,
+                                       const float* mean, const float* rstd, const float* gamma, const float* beta, void* dx, void* dres,
+                                       float* dgamma, float* dbeta, int dtype, int G, int64_t L, int C, int act, float slope, int flags,
+                                       void* ws, size_t ws_bytes, void* stream) {
     if (!d || !sums || !dy || !x || !mean || !rstd || !dx || G <= 0 || L <= 0 || C <= 0 || (dtype != SSCG_F32 && dtype != SSCG_BF16)) return SSCG_ERR_BAD_ARG;
     if (act != SSCG_ACT_NONE && act != SSCG_ACT_RELU && act != SSCG_ACT_LRELU) return SSCG_ERR_UNSUPPORTED;
+    if (act != SSCG_ACT_NONE && !y && dres) return SSCG_ERR_BAD_ARG;      // a residual joined the forward: the mask needs y
     int bm, wm, chunks;
     if (!sscg_bsums_records(d, G, L, &bm, &wm, &chunks) || d->C != C) return SSCG_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < (size_t)G * C * 2 * sizeof(float)) return SSCG_ERR_WORKSPACE;
@@ -811,9 +813,9 @@ extern "C" int sscg_norm_bwd_from_sums(const sscg_conv_desc* d, const void* sums
                        dbeta, G, C, chunks, (long)L, (flags >> 1) & 1, bm, wm);
     SSCG_LAUNCH_CHECK();
     BwdApplyParams q = {};
-    q.dy = dy; q.x = x; q.y = nullptr; q.mean = mean; q.rstd = rstd; q.gamma = gamma; q.beta = beta;
+    q.dy = dy; q.x = x; q.y = y; q.mean = mean; q.rstd = rstd; q.gamma = gamma; q.beta = beta;
     q.coef = coef;
-    q.dx = dx; q.dres = nullptr; q.L = L; q.C = C; q.act = act; q.slope = slope;
+    q.dx = dx; q.dres = dres; q.L = L; q.C = C; q.act = act; q.slope = slope;
     const int vec = vec_for(C, dtype);
     if ((size_t)G * L * C / vec >= ((size_t)1 << 31)) return SSCG_ERR_UNSUPPORTED;
     q.total = (uint32_t)((size_t)G * L * C / vec);

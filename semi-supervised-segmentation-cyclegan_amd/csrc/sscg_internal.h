@@ -30,6 +30,7 @@ int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const 
 // the backward sums of the normalisation layer whose output a data gradient differentiates, taken in that launch's epilogue
 struct sscg_bsums {
     const void* nx;          // the layer's input [G * L][C]
+    const void* nz;          // the layer's OUTPUT (mask source of a unit a residual joined), or null: the mask is recomputed from nx
     const float* mean;       // [G][C]
     const float* rstd;
     const float* gamma;      // [C] or null
@@ -42,7 +43,7 @@ struct sscg_bsums {
 };
 bool sscg_convs_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, int* wm, int* chunks);
 int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs = nullptr);
+                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs = nullptr, const void* addend = nullptr);
 // conv_igemm.hip: record geometry of sscg_conv2d_dgrad_bsums for this descriptor (false = the fusion does not apply)
 bool sscg_bsums_records(const sscg_conv_desc* d, int G, int64_t L, int* bm, int* wm, int* chunks);
 int sscg_krsc_to_crsk_split(const float* w, void* wt, int K, int RS, int C, hipStream_t st);

@@ -244,7 +244,7 @@ def test_maxpool(hw, F, dev):
 
 
 @pytest.mark.parametrize("geom", [(2, 21, 33, 33, 256, 256), (2, 3, 9, 9, 64, 64), (1, 4, 17, 17, 128, 128),
-                                  (2, 20, 5, 9, 32, 64), (1, 3, 1, 1, 8, 8)])
+                                  (2, 20, 5, 9, 32, 64), (1, 3, 1, 1, 8, 8), (2, 3, 16, 24, 16, 24)])
 def test_upsample(geom, F, dev):
     N, C, H, W, OH, OW = geom
     g = torch.Generator().manual_seed(4)
@@ -1008,6 +1008,55 @@ def test_norm_backward_sums_fused_into_the_data_gradient(case, act, dev):
             F.FUSE_BSUMS[0] = was
             F.norm_bwd_from_sums = real
     assert used == [1, 0], used          # the fused route was taken exactly when it was on
+    for t_f, t_u in zip(*outs):
+        assert float((t_f.double() - t_u.double()).abs().max()) <= 1e-5 * float(t_u.double().abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("geom", [(2, 64, 33, 33, 1), (8, 32, 17, 19, 1), (2, 64, 16, 16, 2)], ids=lambda g: "n%d_p%d_%dx%d_groups%d" % g)
+def test_residual_fan_in_joins_in_the_data_gradient(geom, dev):
+    """Bottleneck chain (arch/generators.py:345-365): a block's input feeds conv1 and the shortcut.  The shortcut's gradient (the masked
+    gradient the bn3 + residual -> ReLU unit leaves) joins in conv1's data gradient (sscg_conv2d_dgrad_bsums / _add with `addend`) - no
+    add pass - and that launch also takes the backward sums of the PREVIOUS block's bn3 unit, its mask read off the unit's output
+    (`nz`) - no reduction pass.  Input gradient and every weight gradient agree with the separate passes to 1e-5 of the tensor's scale."""
+    F = load_sub("functional")
+    gen = load_sub("arch.generators")
+    arch = load_sub("arch")
+    n, planes, h, w, groups = geom
+    torch.manual_seed(11)
+    blocks = [gen.Bottleneck(4 * planes, planes).to(dev) for _ in range(3)]
+    x0 = torch.randn(n, 4 * planes, h, w)
+    gy = None
+    outs, adds, sums = [], [], []
+    real_sums, real_add, was = F.norm_bwd_from_sums, F.add, (F.FUSE_JOIN[0], F.FUSE_BSUMS[0])
+    for fused in (True, False):
+        F.FUSE_JOIN[0], F.FUSE_BSUMS[0] = fused, True
+        c_sums, c_add = [], []
+        F.norm_bwd_from_sums = lambda *aa, **kk: (c_sums.append(1), real_sums(*aa, **kk))[1]
+        F.add = lambda *aa, **kk: (c_add.append(1), real_add(*aa, **kk))[1]
+        try:
+            params = [p for b in blocks for p in b.parameters() if p.requires_grad]
+            for p in params:
+                p.grad = None
+            for b in blocks:
+                for bn in (b.bn1, b.bn2, b.bn3):
+                    bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+            x = gpu(x0, dev).requires_grad_(True)
+            y = x
+            with arch.batch_groups(groups):
+                for b in blocks:
+                    y = b(y)
+            if gy is None:
+                gy = gpu(torch.randn(y.shape), dev)
+            F.backward((y * gy).sum())
+            F.SideStream.join(dev)
+            torch.cuda.synchronize()
+            outs.append([x.grad.clone()] + [p.grad.clone() for p in params])
+            adds.append(len(c_add)); sums.append(len(c_sums))
+        finally:
+            F.FUSE_JOIN[0], F.FUSE_BSUMS[0] = was
+            F.norm_bwd_from_sums, F.add = real_sums, real_add
+    assert adds == [0, 3], adds          # three fan-ins: joined in conv1's data gradient / three add passes
+    assert sums == [8, 6], sums          # bn1, bn2 of every block either way; bn3 of blocks 1 and 2 only when their consumer joins the fan-in
     for t_f, t_u in zip(*outs):
         assert float((t_f.double() - t_u.double()).abs().max()) <= 1e-5 * float(t_u.double().abs().max()) + 1e-9
 
