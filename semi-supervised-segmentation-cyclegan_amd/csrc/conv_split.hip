@@ -558,36 +558,64 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
             }
             if (p.bn_gamma) { ga = *reinterpret_cast<const f32x4*>(p.bn_gamma + n); be = *reinterpret_cast<const f32x4*>(p.bn_beta + n); }
         }
-        if (n < p.Ng) {                         // (Ng % 4 == 0: a 16-byte piece is inside the row or outside it)
+        auto out_row = [&](int m) -> size_t {
+            if (p.o_step == 1) return (size_t)m;
+            const int img = m / (p.OH * p.OW);      // parity class of a strided data gradient: rows interleave into dx
+            const int rem = m - img * (p.OH * p.OW);
+            const int oi = rem / p.OW;
+            const int oj = rem - oi * p.OW;
+            return (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+        };
+        const bool joins = MODE == MODE_DGRAD && (want_bsums || p.addend != nullptr);
+        if (n < p.Ng && !joins) {               // (Ng % 4 == 0: a 16-byte piece is inside the row or outside it)
 #pragma unroll
             for (int ps = 0; ps < BM / RPP; ++ps) {
                 const int r = tid / TPR + ps * RPP;
                 const int m = m0 + r;
                 if (m >= p.M) break;
-                size_t row = (size_t)m;
-                if (p.o_step != 1) {            // parity class of a strided data gradient: rows interleave into dx
-                    const int img = m / (p.OH * p.OW);
-                    const int rem = m - img * (p.OH * p.OW);
-                    const int oi = rem / p.OW;
-                    const int oj = rem - oi * p.OW;
-                    row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
-                }
-                f32x4 v = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
-                if (MODE == MODE_DGRAD && p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + row * p.Ng + n);
-                *reinterpret_cast<f32x4*>(p.dst + row * p.Ng + n) = v;
-                if (want_bsums) {
-                    const f32x4 y = *reinterpret_cast<const f32x4*>(p.bn_x + (size_t)m * p.Ng + n);
-                    f32x4 z = 0.f;
-                    if (p.bn_z) z = *reinterpret_cast<const f32x4*>(p.bn_z + (size_t)m * p.Ng + n);
-                    const bool lo = m < gb;
+                *reinterpret_cast<f32x4*>(p.dst + out_row(m) * p.Ng + n) = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
+            }
+        }
+        if (n < p.Ng && joins) {
+            // the addend, the layer's input and the mask source of FOUR rows are requested before the first is used: taken row by
+            // row the store phase waited one memory latency per row (the 128x64 data-gradient class went from 88 to 107 us)
+            constexpr int PSN = BM / RPP;
+            static_assert(PSN % 4 == 0, "rows per thread");
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float xh = (y[e] - (lo ? mu0[e] : mu1[e])) * (lo ? rs0[e] : rs1[e]);
-                        const float ym = p.bn_z ? z[e] : xh * ga[e] + be[e];       // (sign of the output = sign of the pre-activation)
-                        float gg = v[e];
-                        if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? gg : 0.f;
-                        else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? gg : gg * p.bn_slope;
-                        if (lo) { sl[e] += gg; ql[e] = fmaf(gg, xh, ql[e]); } else { sh[e] += gg; qh[e] = fmaf(gg, xh, qh[e]); }
+            for (int h = 0; h < PSN; h += 4) {
+                f32x4 av[4], yv[4], zv[4];
+                size_t rows[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + tid / TPR + (h + q) * RPP;
+                    av[q] = 0.f; yv[q] = 0.f; zv[q] = 0.f; rows[q] = 0;
+                    if (m < p.M) {
+                        rows[q] = out_row(m);
+                        if (p.addend) av[q] = *reinterpret_cast<const f32x4*>(p.addend + rows[q] * p.Ng + n);
+                        if (want_bsums) {
+                            yv[q] = *reinterpret_cast<const f32x4*>(p.bn_x + (size_t)m * p.Ng + n);
+                            if (p.bn_z) zv[q] = *reinterpret_cast<const f32x4*>(p.bn_z + (size_t)m * p.Ng + n);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = tid / TPR + (h + q) * RPP;
+                    const int m = m0 + r;
+                    if (m >= p.M) break;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4) + av[q];
+                    *reinterpret_cast<f32x4*>(p.dst + rows[q] * p.Ng + n) = v;
+                    if (want_bsums) {
+                        const bool lo = m < gb;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float xh = (yv[q][e] - (lo ? mu0[e] : mu1[e])) * (lo ? rs0[e] : rs1[e]);
+                            const float ym = p.bn_z ? zv[q][e] : xh * ga[e] + be[e];       // (sign of the output = sign of the pre-activation)
+                            float gg = v[e];
+                            if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? gg : 0.f;
+                            else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? gg : gg * p.bn_slope;
+                            if (lo) { sl[e] += gg; ql[e] = fmaf(gg, xh, ql[e]); } else { sh[e] += gg; qh[e] = fmaf(gg, xh, qh[e]); }
+                        }
                     }
                 }
             }

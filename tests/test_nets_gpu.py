@@ -157,7 +157,7 @@ def test_training_steps_vs_reference_golden(tag, gold, dev):
                 # two chained DeepLab passes with an argmax one-hot in between: discrete flips.  App. D.2: k = 4 times the
                 # reference's own fp32-vs-fp64 distance; our distance is taken to the nearer of the reference's two runs
                 # (its fp32 result is as legitimate a sample of that noise as its fp64 one).
-                assert min(e64, e32) < max(4 * noise, FX.CHAINED_LOSS_FLOOR), (s, k)
+                assert min(e64, e32) < FX.chained_loss_bound(k, noise), (s, k)
             else:
                 assert e64 < max(4 * step_noise, 1e-3), (s, k)
     # post-step state against the fp64 trajectory
