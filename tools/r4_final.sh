@@ -3,6 +3,7 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 tools/profile_round.sh r04 2 split > gpurun_out/r04_profile.log 2>&1; tail -3 gpurun_out/r04_profile.log | cut -c1-600
-tools/round_lines.sh r04 > gpurun_out/r04_lines.log 2>&1; tail -6 gpurun_out/r04_lines.log
+tools/profile_round.sh r04 3 bf16 > gpurun_out/r04_profile_c3.log 2>&1; tail -2 gpurun_out/r04_profile_c3.log | cut -c1-300
+SKIP_C3=1 tools/round_lines.sh r04 > gpurun_out/r04_lines.log 2>&1; tail -6 gpurun_out/r04_lines.log
 python -c 'import __graft_entry__ as g; g.smoke()' > gpurun_out/r04_smoke.txt 2>&1; tail -1 gpurun_out/r04_smoke.txt | cut -c1-400
 cd /root/repo; python -m pytest tests -m gpu -q -x --durations=15 > gpurun_out/r04_gpu_suite.txt 2>&1; tail -20 gpurun_out/r04_gpu_suite.txt

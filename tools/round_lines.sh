@@ -3,7 +3,7 @@
 # plain step, and the D-step kernel time with / without the fused PixelDiscriminator tail.  usage: tools/round_lines.sh <tag>
 TAG=$1
 ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT; cd $ROOT
-python bench.py --config 3 > $OUT/${TAG}_bench_line_c3.json 2> $OUT/${TAG}_c3.err
+[ -n "$SKIP_C3" ] || python bench.py --config 3 > $OUT/${TAG}_bench_line_c3.json 2> $OUT/${TAG}_c3.err
 python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_line_c5_per_rank.json 2> $OUT/${TAG}_c5.err
 Q="--no-cpu-baseline --no-elided --no-bf16 --no-small --no-roofline --steps 12 --warmup 4"
 python bench.py $Q > $OUT/${TAG}_bench_no_dp_same_box.json 2>/dev/null
