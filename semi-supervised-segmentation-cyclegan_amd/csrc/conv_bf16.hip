@@ -60,6 +60,7 @@ struct K16Params {
     double* __restrict__ xstats;     // host side: records of the split rows ([blocks][Ng][2]), written by the split reduction
     unsigned src_bytes, wgt_bytes;   // extents of the two buffer resources (< 2 GB: offset 0x80000000 = out of range = zeros)
     // data gradient only: the backward sums of the normalisation layer whose OUTPUT this launch differentiates (conv_split.hip KsParams)
+    const bf16* __restrict__ addend;     // [M][Ng] added to the bf16 result (the gradient another consumer of the same tensor left), or null
     const bf16* __restrict__ bn_x;       // [M][Ng] the layer's input (pre-normalisation), or null
     const float* __restrict__ bn_mean;   // [G][Ng]
     const float* __restrict__ bn_rstd;
@@ -528,8 +529,32 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             const int oj = rem - oi * p.OW;
             return (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
         };
+        // dx = dgrad + addend (conv_split.hip's store phase): the two rows' 16-byte segments of every pass are requested up front
+        constexpr int NPS = (BM / 2 + RPP - 1) / RPP;
+        constexpr bool CAN_JOIN = NPS <= 2;     // the classes the plan uses (64x64, 128x64, 128x128 of 8 waves); host: sscg_conv16_dgrad_add_applies
+        constexpr int NAD = CAN_JOIN ? NPS : 1;
+        uint4 ad0[NAD], ad1[NAD];
+        const bool joins = CAN_JOIN && MODE == MODE_DGRAD && p.addend != nullptr;      // (host: Ng % 8 == 0)
+        if (joins) {
 #pragma unroll
-        for (int ps = 0; ps < (BM / 2 + RPP - 1) / RPP; ++ps) {
+            for (int ps = 0; ps < NAD; ++ps) {
+                const int m = m0 + 2 * (tid / TPR + ps * RPP);
+                ad0[ps] = uint4{0u, 0u, 0u, 0u}; ad1[ps] = uint4{0u, 0u, 0u, 0u};
+                if ((tid / TPR + ps * RPP) < BM / 2 && n < p.Ng) {
+                    if (m < p.M) ad0[ps] = *reinterpret_cast<const uint4*>(p.addend + out_row(m) * p.Ng + n);
+                    if (m + 1 < p.M) ad1[ps] = *reinterpret_cast<const uint4*>(p.addend + out_row(m + 1) * p.Ng + n);
+                }
+            }
+        }
+        auto add2 = [](uint32_t v, uint32_t a) -> uint32_t {       // two bf16 sums, each rounded to nearest even (= the add kernel's)
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t sm = {__uint_as_float(v << 16) + __uint_as_float(a << 16),
+                                __uint_as_float(v & 0xffff0000u) + __uint_as_float(a & 0xffff0000u)};
+            return __builtin_bit_cast(uint32_t, __builtin_convertvector(sm, bf16x2_t));
+        };
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
             const int pr = tid / TPR + ps * RPP;
             if ((BM / 2) % RPP != 0 && pr >= BM / 2) continue;
             const int m = m0 + 2 * pr;
@@ -541,6 +566,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             lo.y = __builtin_amdgcn_perm(w0.w, w0.z, 0x05040100u); hi.y = __builtin_amdgcn_perm(w0.w, w0.z, 0x07060302u);
             lo.z = __builtin_amdgcn_perm(w1.y, w1.x, 0x05040100u); hi.z = __builtin_amdgcn_perm(w1.y, w1.x, 0x07060302u);
             lo.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x05040100u); hi.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x07060302u);
+            if (joins) {
+                lo.x = add2(lo.x, ad0[ps % NAD].x); lo.y = add2(lo.y, ad0[ps % NAD].y); lo.z = add2(lo.z, ad0[ps % NAD].z); lo.w = add2(lo.w, ad0[ps % NAD].w);
+                hi.x = add2(hi.x, ad1[ps % NAD].x); hi.y = add2(hi.y, ad1[ps % NAD].y); hi.z = add2(hi.z, ad1[ps % NAD].z); hi.w = add2(hi.w, ad1[ps % NAD].w);
+            }
             const bool full = n + 8 <= p.Ng;
             bf16* r0 = out + out_row(m) * p.Ng + n;
             if (full) {
@@ -828,10 +857,23 @@ bool sscg_conv16_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm,
     return true;
 }
 
+// dx = dgrad + addend in the bf16 store phase: bf16 result tiles of at least 64 columns, whole 16-byte row segments
+bool sscg_conv16_dgrad_add_applies(const sscg_conv_desc* d) {
+    if (!sscg_conv16_dgrad_applies(d) || d->x_dtype != SSCG_BF16 || d->C <= 32 || d->C % 8 != 0) return false;
+    const long M = dgrad16_by_parity(d) ? (long)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) : (long)d->N * d->H * d->W;
+    const int cfg = choose16(M, d->C, d->R * d->S * d->K, d->tuning);
+    return cfg == CFG_64x64 || cfg == CFG_128x64 || cfg == CFG_128x128_W8;
+}
+
 int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs) {
+                      void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs, const void* addend) {
     K16Params p = {};
     bool fused = false;
+    if (addend) {
+        if (bs || bias || act != SSCG_ACT_NONE || !sscg_conv16_dgrad_add_applies(d)) return SSCG_ERR_UNSUPPORTED;
+        p.addend = reinterpret_cast<const bf16*>(addend);
+        fused = true;           // (never split: the partial tiles' reduction does not know the addend)
+    }
     if (bs) {
         int bm, wm, chunks;
         if (bias || act != SSCG_ACT_NONE || !sscg_conv16_bsums_geometry(d, bs->G, bs->L, &bm, &wm, &chunks)) return SSCG_ERR_UNSUPPORTED;

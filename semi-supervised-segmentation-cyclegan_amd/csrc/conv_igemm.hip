@@ -991,16 +991,19 @@ extern "C" int sscg_conv2d_dgrad_bsums(const sscg_conv_desc* d, const void* dy, 
 }
 
 // dx = dgrad(dy, wt) + addend: the fan-in of a tensor with two consumers (a residual block's input: conv1 and the shortcut) joins in
-// the data gradient's store phase instead of a separate add pass.  The split family only (fp32 tensors).
+// the data gradient's store phase instead of a separate add pass.  The split family (fp32 tensors) and the bf16 family.
 extern "C" int sscg_conv2d_dgrad_add_applies(const sscg_conv_desc* d) {
-    return (d && check_desc(d) == SSCG_OK && d->pad_mode == 0 && !sscg_thin1x1_dgrad_applies(d, nullptr, SSCG_ACT_NONE) && !sscg_conv16_dgrad_applies(d) &&
-            sscg_convs_dgrad_applies(d)) ? 1 : 0;
+    if (!d || check_desc(d) != SSCG_OK || d->pad_mode != 0 || sscg_thin1x1_dgrad_applies(d, nullptr, SSCG_ACT_NONE)) return 0;
+    if (sscg_conv16_dgrad_applies(d)) return sscg_conv16_dgrad_add_applies(d) ? 1 : 0;
+    return sscg_convs_dgrad_applies(d) ? 1 : 0;
 }
 
 extern "C" int sscg_conv2d_dgrad_add(const sscg_conv_desc* d, const void* dy, const void* wt, const void* addend, void* dx, void* ws,
                                      size_t ws_bytes, void* stream) {
     if (!d || !dy || !wt || !addend || !dx) return SSCG_ERR_BAD_ARG;
     if (!sscg_conv2d_dgrad_add_applies(d)) return SSCG_ERR_UNSUPPORTED;
+    if (sscg_conv16_dgrad_applies(d))
+        return sscg_conv16_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, nullptr, addend);
     return sscg_convs_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, nullptr, addend);
 }
 

@@ -14,7 +14,8 @@ size_t sscg_conv16_dgrad_workspace(const sscg_conv_desc* d);
 int sscg_conv16_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
                     double* xstats, void* ws, size_t ws_bytes, hipStream_t st);
 int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs = nullptr);
+                      void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs = nullptr, const void* addend = nullptr);
+bool sscg_conv16_dgrad_add_applies(const sscg_conv_desc* d);
 bool sscg_conv16_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, int* wm, int* chunks);
 bool sscg_wgrad16_applies(const sscg_conv_desc* d);
 size_t sscg_wgrad16_workspace(const sscg_conv_desc* d);

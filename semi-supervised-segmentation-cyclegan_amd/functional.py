@@ -682,10 +682,12 @@ def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NO
     want3 = bsums is not None or addend is not None
     plain = bias is None and act == ACT_NONE
     f32 = out_dtype == torch.float32 and dy.dtype == torch.float32
-    if addend is not None and not (plain and f32 and addend.dtype == torch.float32 and tuple(addend.shape) == tuple(dx.shape)
+    if addend is not None and not (plain and addend.dtype == out_dtype == dy.dtype and tuple(addend.shape) == tuple(dx.shape)
                                    and addend.stride() == dx.stride() and _dgrad_add_applies(d)):
         addend = None
     joinable = addend is not None
+    if joinable and not f32:
+        bsums = None            # (bf16 tensors: the addend joins, the sums of a joined gradient are not taken - conv16_kernel)
     if bsums is not None:
         nx, mean, rstd, gamma, beta, (g, l, c), nact, nslope = bsums[:8]
         res = len(bsums) > 8 and bsums[8]

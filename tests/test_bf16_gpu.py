@@ -717,3 +717,50 @@ def test_norm_backward_sums_fused_into_the_bf16_data_gradient(case, dev, bf16_mo
         e = float((t_f.double() - t_u.double()).abs().max()) / (float(t_u.double().abs().max()) + 1e-12)
         print("tensor %d: fused vs reduction pass %.2e" % (i, e))
         assert e <= (2e-2 if i < 2 else 5e-3), (i, e)
+
+
+@pytest.mark.parametrize("geom", [(2, 64, 33, 33), (8, 64, 17, 19)], ids=lambda g: "n%d_p%d_%dx%d" % g)
+def test_residual_fan_in_joins_in_the_bf16_data_gradient(geom, dev, bf16_mode):
+    """tests/test_kernels_gpu.py::test_residual_fan_in_joins_in_the_data_gradient on bf16 tensors: the shortcut's gradient is added to
+    the bf16-rounded data gradient in conv16_kernel's store phase with the add kernel's own rounding - the joined result and every
+    weight gradient are BIT-identical to the separate add pass (no backward sums of joined gradients on bf16 tensors)."""
+    F = bf16_mode
+    ops = load_sub("arch.ops")
+    gen = load_sub("arch.generators")
+    n, planes, h, w = geom
+    torch.manual_seed(11)
+    stem = ops.Conv2d(3, 4 * planes, 3, 1, 1).to(dev)          # fp32 image in, bf16 activations from here on
+    blocks = [gen.Bottleneck(4 * planes, planes).to(dev) for _ in range(3)]
+    x0 = torch.randn(n, 3, h, w)
+    gy = None
+    outs, adds = [], []
+    real_add, was = F.add, F.FUSE_JOIN[0]
+    for fused in (True, False):
+        F.FUSE_JOIN[0] = fused
+        c_add = []
+        F.add = lambda *aa, **kk: (c_add.append(1), real_add(*aa, **kk))[1]
+        try:
+            params = [p for m in [stem] + blocks for p in m.parameters() if p.requires_grad]
+            for p in params:
+                p.grad = None
+            for b in blocks:
+                for bn in (b.bn1, b.bn2, b.bn3):
+                    bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+            x = x0.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            y = stem(x)
+            assert y.dtype == torch.bfloat16
+            for b in blocks:
+                y = b(y)
+            if gy is None:
+                gy = torch.randn(y.shape).to(dev).contiguous(memory_format=torch.channels_last)
+            F.backward((y.float() * gy).sum())
+            F.SideStream.join(dev)
+            torch.cuda.synchronize()
+            outs.append([x.grad.float().clone()] + [p.grad.float().clone() for p in params])
+            adds.append(len(c_add))
+        finally:
+            F.FUSE_JOIN[0] = was
+            F.add = real_add
+    assert adds == [0, 3], adds
+    for t_f, t_u in zip(*outs):
+        assert torch.equal(t_f, t_u)
