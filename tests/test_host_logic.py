@@ -286,3 +286,49 @@ def test_pixel_discriminator_tail_is_recognised_and_lane_priority_follows_the_co
     assert F.side_priority() == 0 and F.side_priority_for(8 * 256 * 256) == 0
     monkeypatch.setenv("SSCG_SIDE_PRIORITY", "1")
     assert F.side_priority_for(2 * 64 * 64) == 1
+
+
+def test_fan_in_bookkeeping_never_counts_a_gradient_twice(monkeypatch):
+    """functional._Join / SplitFn.backward (the residual fan-in that joins in a data gradient's store phase): the second consumer takes
+    the first one's gradient only on the stream it was produced on and only for a two-way fan-out; a gradient that was folded is
+    returned alone, one that was not is summed; an alias with two consumers, or a folded gradient that arrives changed, is refused
+    loudly rather than counted twice.  (Host logic only: the tensors stay on the CPU, the add is patched.)"""
+    F = load_sub("functional")
+    lane = [7]
+    monkeypatch.setattr(F, "_stream", lambda: lane[0])
+    monkeypatch.setattr(F, "to_nhwc", lambda t: t)
+    monkeypatch.setattr(F, "add", lambda a, b: a + b)
+
+    class Ctx(object):
+        pass
+
+    g0, g1 = torch.ones(2, 3), torch.full((2, 3), 2.0)
+    j = F._Join(2, None)
+    assert j.take(0) is None                      # nothing deposited yet
+    j.deposit(1, g1)
+    lane[0] = 8
+    assert j.take(0) is None                      # deposited on another lane: would be read unordered
+    lane[0] = 7
+    assert j.take(0) is g1
+    total = g0 + g1                               # what the joined data gradient returns
+    j.folded = (0, total)
+    ctx = Ctx(); ctx.join = j
+    out = F.SplitFn.backward(ctx, total, g1)
+    assert out[0] is total and out[1] is None and j.folded is None and j.slots == [None, None]      # nothing added again; state cleared
+    # not folded: the plain sum, in consumer order
+    j.deposit(0, g0); j.deposit(1, g1)
+    out = F.SplitFn.backward(ctx, g0, g1)
+    assert torch.equal(out[0], g0 + g1) and j.slots == [None, None]
+    # three consumers: never folded
+    j3 = F._Join(3, None)
+    j3.deposit(1, g1)
+    assert j3.take(0) is None
+    # an alias with two consumers deposits twice: nothing may be taken any more
+    j.deposit(1, g1); j.deposit(1, g1)
+    assert j.broken and j.take(0) is None
+    j.clear()
+    # a folded gradient that arrives changed (e.g. accumulated by the engine) is an error, not a silent double count
+    j.deposit(1, g1)
+    j.folded = (0, total)
+    with pytest.raises(Exception):
+        F.SplitFn.backward(ctx, total.clone(), g1)
