@@ -187,6 +187,45 @@ class SemiSupOracle:
         return out
 
 
+    # ------------------------------------------------------------------ teacher-forced second pass
+    def first_pass(self, l_img, l_gt, unl_img):
+        """The first-pass outputs the second pass consumes (model.py:385-387,390-392,401-402), without a graph:
+        fake_img = interp(Gis(onehot(l_gt))), fake_gt = softmax(interp(Gsi(unl_img))), lab_gt = softmax(interp(Gsi(l_img)))."""
+        C, sd, q = self.C, self.sd, self.q
+        with torch.no_grad():
+            fake_img = self.interp(nets.deeplab(sd["Gis"], one_hot(l_gt, C, l_img.dtype), True, q=q))     # :385,390
+            fake_gt = torch.softmax(self.interp(nets.deeplab(sd["Gsi"], unl_img, True, q=q)), 1)           # :386,391,402
+            lab_gt = torch.softmax(self.interp(nets.deeplab(sd["Gsi"], l_img, True, q=q)), 1)              # :387,392,401
+        return fake_img, fake_gt, lab_gt
+
+    def second_pass(self, fake_img, fake_gt, l_gt, unl_img):
+        """The part of the step that sits TWO DeepLab passes deep, fed GIVEN first-pass outputs (teacher forcing: the chaos of the
+        first pass cannot compound, so each quantity below is one DeepLab pass deep and can be held to north_star's 1e-3):
+          recon_img = interp(Gis(fake_gt)) (model.py:408,413) -> old_Di (:432) -> img_cycle_loss (:452)
+          recon_gt  = interp(Gsi(fake_img)) (:410,415)        -> gt_cycle_loss (:455)
+          cycle_img_dis_loss = MSE(old_Di(old_Gis(softmax(old_Gsi(unl_img)))), 1) + MSE(old_Di(recon_img), 0) (:418-422,501-502,527-528,534;
+          the pool hands back the current item while it fills, :490)
+        Returns the three losses and d(img_cycle_loss)/d(fake_gt), d(gt_cycle_loss)/d(fake_img).  tests/test_oracle_golden.py checks
+        that, fed the step's own first-pass outputs, this reproduces the pinned `step`'s three chained losses."""
+        sd, q = self.sd, self.q
+        mse = lambda x, t: ((x - t) ** 2).mean()
+        fake_gt = fake_gt.detach().clone().requires_grad_(True)
+        fake_img = fake_img.detach().clone().requires_grad_(True)
+        recon_img = self.interp(nets.deeplab(sd["Gis"], fake_gt, True, q=q))                               # :408,413
+        recon_gt = self.interp(nets.deeplab(sd["Gsi"], fake_img, True, q=q))                               # :410,415
+        img_cycle_loss = mse(self._dis("old_Di", recon_img), 1.0)                                          # :432,452
+        gt_cycle_loss = TF.cross_entropy(recon_gt, l_gt.squeeze(1))                                        # :455
+        d_fake_gt, = torch.autograd.grad(img_cycle_loss, fake_gt)
+        d_fake_img, = torch.autograd.grad(gt_cycle_loss, fake_img)
+        with torch.no_grad():
+            resnet_fake_gt = torch.softmax(self._old_g("old_Gsi", unl_img, False), 1)                      # :418,421
+            resnet_recon_img = self._old_g("old_Gis", resnet_fake_gt, True)                                # :422
+            cycle_img_dis_loss = mse(self._dis("old_Di", resnet_recon_img), 1.0) + mse(self._dis("old_Di", recon_img.detach()), 0.0)
+        return dict(img_cycle_loss=float(img_cycle_loss.detach()), gt_cycle_loss=float(gt_cycle_loss.detach()),
+                    cycle_img_dis_loss=float(cycle_img_dis_loss), d_fake_gt=d_fake_gt, d_fake_img=d_fake_img,
+                    recon_img=recon_img.detach())
+
+
 class SupervisedOracle:
     """supervised_model step (model.py:120-143): DeepLab Gsi + CE + Adam(0.9, 0.999)."""
 

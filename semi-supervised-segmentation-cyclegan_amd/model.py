@@ -306,6 +306,34 @@ class semisuper_cycleGAN(object):
         out.update({k: v.detach() for k, v in extras.items()})
         return out
 
+    def second_pass(self, fake_img, fake_gt, l_gt, unl_img):
+        """Diagnostic twin of the part of `step` that sits two DeepLab passes deep, on GIVEN first-pass outputs (teacher forcing,
+        SURVEY App. D.3): the same modules, fused head and loss kernels as step() uses for model.py:408,410,413,415,432,452,455 and for the
+        discriminator step's :418-422,501-502,527-528,534 - but no optimiser, no pools.  Returns img_cycle_loss, gt_cycle_loss,
+        cycle_img_dis_loss (device scalars), d(img_cycle_loss)/d(fake_gt), d(gt_cycle_loss)/d(fake_img) and recon_img.  The parity
+        tests feed it the fp64 oracle's first-pass outputs, so that the three losses the step can only bound statistically (the
+        first pass's fp32 noise is amplified by the second) are held to 1e-3 here."""
+        set_grad([self.Di, self.Ds, self.old_Di, self.old_Gsi, self.old_Gis], False)
+        self.g_optimizer.zero_grad()
+        self.g_optimizer.ensure_operand_copies()
+        self.d_optimizer.ensure_operand_copies()
+        labels = l_gt.reshape(l_gt.shape[0], l_gt.shape[2], l_gt.shape[3])
+        x_gt = fake_gt.detach().clone().requires_grad_(True)
+        x_img = fake_img.detach().clone().requires_grad_(True)
+        recon_img = self.interp(self.Gis(x_gt))                                          # :408,413
+        img_cycle_loss = F.mse_const(self.old_Di(recon_img), 1.0)                        # :432,452
+        _, gt_cycle_loss = F.upsample_softmax_ce(self.Gsi(x_img), self.crop, labels, want_soft=False)    # :410,415,455
+        F.backward(F.weighted_sum([img_cycle_loss, gt_cycle_loss], [1.0, 1.0]))          # (each term reaches one of the two inputs only)
+        F.SideStream.join(l_gt.device)
+        with torch.no_grad():
+            resnet_recon_img = self.old_Gis(F.softmax2d(self.old_Gsi(unl_img)))          # :418,421,422
+            r_c = F.mse_const(self.old_Di(resnet_recon_img), 1.0)                        # :501,527
+            f_c = F.mse_const(self.old_Di(recon_img.detach()), 0.0)                      # :502,528 (the pool returns the current item)
+            cycle_img_dis_loss = F.weighted_sum([r_c, f_c], [1.0, 1.0])                  # :534
+        self.g_optimizer.zero_grad()
+        return dict(img_cycle_loss=img_cycle_loss.detach(), gt_cycle_loss=gt_cycle_loss.detach(), cycle_img_dis_loss=cycle_img_dis_loss,
+                    d_fake_gt=x_gt.grad, d_fake_img=x_img.grad, recon_img=recon_img.detach())
+
     def _refresh_generator_copies(self, dev):
         """Data parallel: the generator update lands AFTER the discriminator step was queued, so the operand copies of the
         GENERATORS' weights are rebuilt here, on side lane 0, off the next step's critical path (the discriminators' copies are

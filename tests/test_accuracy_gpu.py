@@ -86,9 +86,9 @@ def test_split_mode_is_as_close_to_fp64_as_exact_fp32_at_step_level(dev):
     assert rms["f32s"] <= 1.5 * rms["ref"] and rms["f32x"] <= 1.5 * rms["ref"], rms
     for k in CHAINED:       # per loss: no draw beyond 2.5 x the worst the reference shows on that loss
         assert max(err["f32s"][k]) <= 2.5 * scale[k] and max(err["f32x"][k]) <= 2.5 * scale[k], (k, err["f32s"][k], err["f32x"][k], scale[k])
-    # CHAINED_LOSS_FLOOR (the floor of the per-seed bound of the golden-step tests) is NEEDED by the exact-fp32 arithmetic too:
-    # if this ever stops being true the floor goes back to 1e-3
-    assert max(max(err["f32x"][k]) for k in CHAINED) > 1e-3
+    # (no assertion that the build misses 1e-3 on these: a better summation order must not fail the suite.  The same three losses are
+    # held to 1e-3 where that is attainable - teacher-forced, tests/test_teacher_forced_gpu.py.)
+    print("worst chained draw: exact fp32 %.2e, split %.2e, the reference's fp32 %.2e" % tuple(max(max(err[mo][k]) for k in CHAINED) for mo in ("f32x", "f32s", "ref")))
 
 
 @pytest.mark.parametrize("name", ["deeplab_3_21", "deeplab_21_3"])

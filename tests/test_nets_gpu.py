@@ -152,12 +152,13 @@ def test_training_steps_vs_reference_golden(tag, gold, dev):
             e32 = abs(got[k] - ref32[k]) / abs(ref32[k])
             print("step %d %-20s hip %.7f ref32 %.7f f64 %.7f | e64 %.1e noise %.1e" % (s, k, got[k], ref32[k], ref64[k], e64, noise))
             if s == 0 and k in DIRECT:
-                assert min(e64, e32) < 1e-3, (s, k)
+                assert e64 < 1e-3, (s, k)
             elif s == 0:
-                # two chained DeepLab passes with an argmax one-hot in between: discrete flips.  App. D.2: k = 4 times the
-                # reference's own fp32-vs-fp64 distance; our distance is taken to the nearer of the reference's two runs
-                # (its fp32 result is as legitimate a sample of that noise as its fp64 one).
-                assert min(e64, e32) < FX.chained_loss_bound(k, noise), (s, k)
+                # two chained DeepLab passes with an argmax one-hot in between: the END-TO-END value is a noise amplifier (the
+                # reference's own fp32 run sits up to 3.7e-3 from fp64 on it), bounded statistically against fp64
+                # (oracle.fixtures.chained_loss_bound); the same three losses are held to 1e-3 TEACHER-FORCED in
+                # tests/test_teacher_forced_gpu.py, where the first pass's noise cannot compound.
+                assert e64 < FX.chained_loss_bound(k, noise), (s, k)
             else:
                 assert e64 < max(4 * step_noise, 1e-3), (s, k)
     # post-step state against the fp64 trajectory

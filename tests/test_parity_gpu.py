@@ -228,7 +228,7 @@ def test_training_step_256_vs_reference_golden(dev, meta):
         e64, e32 = abs(got[k] - ref64[k]) / abs(ref64[k]), abs(got[k] - ref32[k]) / abs(ref32[k])
         print("%-20s hip %.7f ref32 %.7f f64 %.7f | e64 %.1e e32 %.1e noise %.1e" % (k, got[k], ref32[k], ref64[k], e64, e32, noise))
         chained = k in ("img_cycle_loss", "gt_cycle_loss", "cycle_img_dis_loss")
-        assert min(e64, e32) < (FX.chained_loss_bound(k, noise) if chained else 1e-3), k
+        assert e64 < (FX.chained_loss_bound(k, noise) if chained else 1e-3), k    # (chained: 1e-3 teacher-forced in tests/test_teacher_forced_gpu.py)
 
 
 # ------------------------------------------------------------------------------------------ pools meet the overlapped D stream

@@ -176,10 +176,9 @@ def test_first_step_other_datasets_vs_oracle_golden(cfg, dev):
         e = abs(got[k] - r64[k]) / abs(r64[k])
         print("%-20s hip %.6f oracle32 %.6f oracle64 %.6f  e64 %.1e noise %.1e" % (k, got[k], ref[k], r64[k], e, noise))
         chained = k in ("img_cycle_loss", "gt_cycle_loss", "cycle_img_dis_loss")
-        # chained = two DeepLab passes with discrete argmax/ReLU-mask flips in between: SURVEY App. D.2, k = 4 times the
-        # oracle's own fp32-vs-fp64 distance, measured to the nearer of its two runs
-        e32 = abs(got[k] - ref[k]) / abs(ref[k])
-        assert (min(e, e32) < FX.chained_loss_bound(k, noise)) if chained else (e < 1e-3), k
+        # chained = two DeepLab passes with discrete argmax/ReLU-mask flips in between: bounded statistically against fp64
+        # (oracle.fixtures.chained_loss_bound); held to 1e-3 teacher-forced in tests/test_teacher_forced_gpu.py
+        assert (e < FX.chained_loss_bound(k, noise)) if chained else (e < 1e-3), k
 
 
 def test_opt_in_nets_and_loss_variants(dev):
@@ -229,22 +228,22 @@ def test_variant_step_vs_oracle_golden(dev):
              for k in FX.CHAINED_LOSSES}
     for k in r64:
         noise = abs(ref[k] - r64[k]) / abs(r64[k])
-        e, e32 = abs(got[k] - r64[k]) / abs(r64[k]), abs(got[k] - ref[k]) / abs(ref[k])
+        e = abs(got[k] - r64[k]) / abs(r64[k])
         print("%-20s hip %.6f oracle32 %.6f oracle64 %.6f  e64 %.1e noise %.1e" % (k, got[k], ref[k], r64[k], e, noise))
         chained = k in FX.CHAINED_LOSSES
         if chained:
             # a NEW seed for the chained losses: its bound comes from the six-seed evidence of tests/test_accuracy_gpu.py, not from a
             # fixed floor - no draw beyond 2.5 x the worst distance to fp64 the REFERENCE's arithmetic shows on this loss over those
             # seeds (gt_cycle_loss: 3.7e-3; the build's two arithmetics reach 5.3e-3 / 7.1e-3 there), or 4 x this seed's own noise
-            assert min(e, e32) < max(4 * noise, 2.5 * scale[k]), (k, e, noise, scale[k])
+            assert e < max(4 * noise, 2.5 * scale[k]), (k, e, noise, scale[k])
             continue
         if k == "img_cycle_l1":
             # taken on recon_img = Gis(Gsi(unl_img)) itself: two DeepLab passes deep with nothing smoothing it - the class of
             # gt_cycle_loss, whose distance to fp64 over six seeds reaches 5.3e-3 / 7.1e-3 in the build's two fp32 arithmetics and
             # 3.7e-3 in the reference's own (tests/test_accuracy_gpu.py).  Measured here: 5.2e-3.
-            assert min(e, e32) < max(4 * noise, 8e-3), k
+            assert e < max(4 * noise, 2.5 * scale["gt_cycle_loss"]), k     # (= 9.2e-3: the bound of its noise class, not a literal)
             continue
-        assert (min(e, e32) < FX.chained_loss_bound(k, noise)) if chained else (e < 1e-3), k
+        assert e < 1e-3, k
     gn = float(m.g_optimizer.grad.double().norm())
     n64, n32 = G["g_grad_norm_f64"], G["g_grad_norm_f32"]
     noise = abs(n32 - n64) / n64
