@@ -1105,3 +1105,111 @@ def test_operand_copies_of_many_weights_in_one_launch_are_bit_identical(F, dev):
     finally:
         F.BATCH_TRANSPOSES[0] = was
         F.set_conv_precision(mode)
+
+
+# ------------------------------------------------------------------------------------------ fused store phases against fp64, bench size
+def _dgrad_fp64(dy, w, H, W, pad, dil):
+    """fp64 data gradient of a stride-1 convolution on the device: dx[n, c, y, x] = sum_{ky, kx, k} dy[n, k, y + pad - ky*dil, x + pad - kx*dil]
+    w[k, c, ky, kx], as R*S matrix products over shifted views (torch has no fp64 convolution on this device)."""
+    N, K, P, Q = dy.shape
+    _, C, R, S = w.shape
+    m = (R - 1) * dil
+    dyp = TF.pad(dy.double().permute(0, 2, 3, 1), (0, 0, m, m, m, m))           # [N][P + 2m][Q + 2m][K]
+    w64 = w.double()
+    dx = torch.zeros(N, H, W, C, dtype=torch.float64, device=dy.device)
+    for ky in range(R):
+        for kx in range(S):
+            oy, ox = m + pad - ky * dil, m + pad - kx * dil
+            dx += dyp[:, oy:oy + H, ox:ox + W, :] @ w64[:, :, ky, kx]
+    return dx.permute(0, 3, 1, 2)
+
+
+# (N, H, W, C, K, R, pad, dil, residual unit in front, addend): the DeepLab layer3 Bottleneck's three data gradients at the BASELINE
+# step's size (8 x 33 x 33 = 8712 rows: 69 tiles of 128 rows, the last one ragged; /root/reference arch/generators.py:345-365)
+_STORE_PHASE_CASES = [
+    (8, 33, 33, 1024, 256, 1, 0, 1, True, True),      # conv1: its input is the previous block's relu(bn3 + shortcut); the shortcut's gradient joins
+    (8, 33, 33, 256, 1024, 1, 0, 1, False, False),    # conv3: its input is relu(bn2(conv2))
+    (8, 33, 33, 256, 256, 3, 2, 2, False, False),     # conv2 (dilation 2): its input is relu(bn1(conv1))
+    (16, 33, 33, 1024, 256, 1, 0, 1, True, True),     # the stacked Gsi pass: two BatchNorm groups of 8712 rows in one launch
+]
+
+
+@pytest.mark.parametrize("case", _STORE_PHASE_CASES, ids=lambda c: "%dx%dx%d_c%d_k%d_r%d_p%d_d%d_res%d_add%d" % tuple(int(v) for v in c))
+def test_fused_store_phases_against_fp64_at_bench_size(case, F, dev):
+    """the data gradient's fused store phases - the fan-in `addend`, the normalisation backward's sums with the mask
+    recomputed from nx or read off the unit's output - were only compared with the UNFUSED HIP passes, at small shapes.  Here, at the
+    bench step's size, against fp64: (a) dx = dgrad(dy, w) + addend, every element; (b) the backward of the unit in front finished
+    from the launch's records (sscg_norm_bwd_from_sums): its input gradient, d gamma, d beta and the shortcut's gradient, against the
+    batch-norm backward formula evaluated in fp64 on the fp64 gradient."""
+    N, H, W, C, K, R, pad, dil, res, add = case
+    groups = 2 if N == 16 else 1
+    g = torch.Generator(device=dev).manual_seed(sum(int(v) for v in case) + 3)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    w = (rn(K, C, R, R) * (1.0 / (C * R * R) ** 0.5)).contiguous(memory_format=CL)
+    dy = rn(N, K, H, W).contiguous(memory_format=CL)
+    nx = (rn(N, C, H, W) * 1.7 + 0.3).contiguous(memory_format=CL)
+    gamma, beta = (rn(C) * 0.3 + 1.0), rn(C) * 0.2
+    resid = rn(N, C, H, W).contiguous(memory_format=CL) if res else None
+    addend = rn(N, C, H, W).contiguous(memory_format=CL) if add else None
+    per_sample = False if groups == 1 else groups
+    mean, rstd = F.norm_stats(nx, per_sample)
+    z = F.norm_apply(nx, mean, rstd, gamma, beta, resid, per_sample, F.ACT_RELU)        # the unit's forward output = this conv's input
+    F.set_conv_precision("f32s")
+    try:
+        wt = F.dgrad_operand(w, z.shape, 1, pad, dil)
+        L = (N // groups) * H * W
+        info = (nx, mean, rstd, gamma, beta, (groups, L, C), F.ACT_RELU, 0.0) + ((True,) if res else ())
+        dx, rec, joined = F.conv2d_dgrad(dy, wt, z.shape, w.shape, 1, pad, dil, bsums=info, addend=addend, z=z)
+        assert rec is not None and (joined or not add), "the fused route must serve this shape (records %s, joined %s)" % (rec is not None, joined)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        dnx, dres = F.norm_bwd_from_sums(rec, dx, nx, mean, rstd, gamma, beta, per_sample, F.ACT_RELU, 0.0, dgb[0], dgb[1],
+                                         y=z if res else None, want_dres=res)
+    finally:
+        F.set_conv_precision("f32")
+    torch.cuda.synchronize()
+    # ---- fp64
+    dx64 = _dgrad_fp64(dy, w, H, W, pad, dil)
+    if add:
+        dx64 = dx64 + addend.double()
+    rms = lambda t: float(t.double().pow(2).mean().sqrt())
+    e_dx = rms(dx.double() - dx64) / rms(dx64)
+    mask = (z > 0).double()            # the forward's own mask (a fp64 re-evaluation would flip the few elements within rounding of 0)
+    gg = mask * dx64
+    gv = lambda t: t.double().reshape(groups, N // groups, C, H, W)
+    xh = (gv(nx) - mean.double().reshape(groups, 1, C, 1, 1)) * rstd.double().reshape(groups, 1, C, 1, 1)
+    s1 = gv(gg).sum((1, 3, 4), keepdim=True)
+    s2 = (gv(gg) * xh).sum((1, 3, 4), keepdim=True)
+    dnx64 = (gamma.double().reshape(1, 1, C, 1, 1) * rstd.double().reshape(groups, 1, C, 1, 1) * (gv(gg) - s1 / L - xh * s2 / L)).reshape(N, C, H, W)
+    e_dnx = rms(dnx.double() - dnx64) / rms(dnx64)
+    dgamma64, dbeta64 = s2.sum(0).flatten(), s1.sum(0).flatten()
+    scale = float((gv(gg).pow(2).sum((0, 1, 3, 4)).sqrt()).max())          # a sum of L terms: error relative to the L2 norm of its terms
+    e_dg = float((dgb[0].double() - dgamma64).abs().max()) / scale
+    e_db = float((dgb[1].double() - dbeta64).abs().max()) / scale
+    print("dx rms err %.2e, norm-backward input gradient %.2e, d gamma %.2e, d beta %.2e (of the terms' L2 norm)" % (e_dx, e_dnx, e_dg, e_db))
+    assert e_dx < 2e-6
+    assert e_dnx < 5e-6
+    assert e_dg < 2e-6 and e_db < 2e-6
+    if res:
+        assert rms(dres.double() - gg) / rms(gg) < 2e-6
+
+
+@pytest.mark.parametrize("case", [(8, 33, 33, 1024, 256, 1, 0, 1), (16, 33, 65, 1024, 256, 1, 0, 1), (8, 33, 33, 256, 256, 3, 2, 2)],
+                         ids=lambda c: "%dx%dx%d_c%d_k%d_r%d_p%d_d%d" % c)
+def test_fused_fan_in_against_fp64_at_bench_size_bf16(case, F, dev):
+    """The bf16 twin (conv16_kernel's store phase; configs 3 / 5 sizes): dx = bf16(dgrad(dy, w) + addend) against fp64 on the
+    bf16-rounded operands - within one bf16 rounding of the exact sum."""
+    N, H, W, C, K, R, pad, dil = case
+    g = torch.Generator(device=dev).manual_seed(sum(case) + 5)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    w = (rn(K, C, R, R) * (1.0 / (C * R * R) ** 0.5)).contiguous(memory_format=CL)
+    dy = rn(N, K, H, W).contiguous(memory_format=CL).to(torch.bfloat16)
+    addend = rn(N, C, H, W).contiguous(memory_format=CL).to(torch.bfloat16)
+    wt = F.weight_transposed(w, torch.bfloat16)
+    dx, rec, joined = F.conv2d_dgrad(dy, wt, (N, C, H, W), w.shape, 1, pad, dil, out_dtype=torch.bfloat16, addend=addend)
+    assert joined and dx.dtype == torch.bfloat16
+    torch.cuda.synchronize()
+    ref = _dgrad_fp64(dy.float(), w.to(torch.bfloat16).float(), H, W, pad, dil) + addend.double()
+    err = (dx.double() - ref).abs()
+    # round-to-nearest bf16 of the fp32 sum: half an ulp = 2^-9 of the value's binade, i.e. <= 2^-8 |ref|; + the fp32 accumulation's noise
+    assert float((err - ref.abs() * 2.0 ** -8).max()) <= 1e-5, float((err - ref.abs() * 2.0 ** -8).max())
+    assert float(err.pow(2).mean().sqrt()) / float(ref.pow(2).mean().sqrt()) < 3e-3

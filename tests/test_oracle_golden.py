@@ -214,3 +214,23 @@ def test_perceptual_loss_restatement_against_torch_modules():
     want = nn.MSELoss()(feats(v), feats(u))
     got = nets.perceptual_loss(sd, x, y)
     assert abs(float(got) - float(want)) <= 1e-12 * abs(float(want))
+
+
+def test_teacher_forced_second_pass_is_the_steps_second_pass():
+    """oracle.step.SemiSupOracle.second_pass (the checker of tests/test_teacher_forced_gpu.py) fed the pinned step's OWN first-pass
+    outputs reproduces that step's three chained losses bit for bit: the teacher-forced restatement is the same arithmetic as
+    model.py:408-415,432,452,455 / :501-502,527-528,534 inside `step` (which gen_golden.py pins against the real reference)."""
+    C, H, B = 21, 32, 2
+    l_img, l_gt, unl_img = FX.step_batch("tfcpu", 0, C, H, H, B)
+    np.random.seed(0)
+    col = {}
+    full = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float32, "tfcpu"), crop=(H, H)).step(l_img, l_gt, unl_img, collect=col)
+    o = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float32, "tfcpu"), crop=(H, H))
+    fake_img, fake_gt, _ = o.first_pass(l_img, l_gt, unl_img)
+    assert torch.equal(fake_img, col["fake_img"]) and torch.equal(fake_gt, col["fake_gt"])
+    r = o.second_pass(col["fake_img"], col["fake_gt"], l_gt, unl_img)
+    for k in FX.CHAINED_LOSSES:
+        assert r[k] == full[k], (k, r[k], full[k])
+    assert torch.equal(r["recon_img"], col["recon_img"])
+    assert r["d_fake_gt"].shape == fake_gt.shape and r["d_fake_img"].shape == fake_img.shape
+    assert float(r["d_fake_gt"].abs().max()) > 0 and float(r["d_fake_img"].abs().max()) > 0
