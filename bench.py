@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-elided", action="store_true")
     ap.add_argument("--no-small", action="store_true", help="skip the 64x64 batch-2 host-bound figure")
+    ap.add_argument("--no-unblocked", action="store_true", help="skip host_issue_unblocked_ms (a few dry-run steps)")
     ap.add_argument("--host-bound-only", action="store_true", help="(internal) run the 64x64 batch-2 case alone and print its JSON object")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--dtype", choices=["f32", "f32x", "f32s", "bf16", "bf16c"], default=None, help="default: the configuration's")
@@ -165,13 +166,14 @@ def main():
         out = None
         for i in range(first, first + count):
             out = run(i)
-        host[0] = (time.perf_counter() - t0) / count      # the host thread is free again: pure issue cost of a step
+        host[0] = (time.perf_counter() - t0) / count      # the host thread is free again: issue cost of a step (incl. back-pressure)
         torch.cuda.synchronize()
+        own[0] = (time.perf_counter() - t0) / count       # this rank's own time, before it waits for the others
         if dp:
             dp.barrier()
         return par.max_over_ranks(time.perf_counter() - t0), out
 
-    host = [0.0]
+    host, own = [0.0], [0.0]
 
     for i in range(a.warmup):
         run(i)
@@ -195,6 +197,35 @@ def main():
     }
     if host_bound_case is not None:
         out["host_bound_case"] = host_bound_case
+    if dp:
+        # the evidence beside `n_gpus` (= WORLD_SIZE of the environment): what the process group saw - one physical device per rank,
+        # the collective library's version, every rank's own step time (collective call: every rank takes part)
+        census = par.rank_census(1e3 * own[0])
+        out["rccl"] = census
+        if census["distinct_devices"] != census["world_size"] and not os.environ.get("SSCG_DP_SHARED_GPU"):
+            raise SystemExit("bench.py: %d ranks on %d distinct devices %s - not a %d-GPU measurement (SSCG_DP_SHARED_GPU=1 marks the "
+                             "one-GPU test rig)" % (census["world_size"], census["distinct_devices"], census["devices"], census["world_size"]))
+
+    # The host thread's issue cost of one step with NO back-pressure from the device: the same step with every kernel launch of the
+    # library turned into a no-op (sscg_set_dry_run; torch's own copies / events still run).  `host_issue_ms_per_step` above includes
+    # the time the thread spends blocked on a full launch queue; the difference is the back-pressure.
+    if not a.no_unblocked:
+        lib = importlib.import_module(PKG + "._lib").lib
+        torch.cuda.synchronize()
+        pools = [(list(p.items), p.cur_elements) for p in model.pools]       # a dry step stores never-written tensors in the image pools
+        lib.sscg_set_dry_run(1)
+        try:
+            run(a.warmup)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(a.warmup, a.warmup + min(a.steps, 4)):
+                run(i)
+            out["host_issue_unblocked_ms"] = round(1e3 * (time.perf_counter() - t0) / min(a.steps, 4), 2)
+            torch.cuda.synchronize()
+        finally:
+            lib.sscg_set_dry_run(0)
+            for p, (items, n) in zip(model.pools, pools):
+                p.items, p.cur_elements = items, n
 
     # secondary figure (BASELINE.md section 2 / SURVEY 8(d)): the same step without the forwards whose outputs the
     # reference never uses (old_Gsi(l_img) -> old_Gis, model.py:419-420,423) and without old_Di's never-applied wgrad

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 12
+#define SSCG_ABI_VERSION 13
 
 /* element types of activation / weight tensors */
 #define SSCG_F32 0
@@ -48,6 +48,10 @@ extern "C" {
 #define SSCG_PAD_REFLECT 1 /* nn.ReflectionPad2d folded into the conv loader: arch/ops.py:62,67; arch/generators.py:73,84,89 */
 
 int sscg_abi_version(void);
+/* Measurement aid (no reference counterpart): on != 0 turns every kernel launch of the library into a no-op while the host side of
+ * each entry point (checks, planning, workspace carving) still runs; returns the previous setting.  bench.py times the host's issue
+ * cost of a training step with it (no back-pressure from the device).  Results are undefined while it is on. */
+int sscg_set_dry_run(int on);
 
 /* ------------------------------------------------------------------ convolution (K1, K2, K5) */
 typedef struct sscg_conv_desc {

@@ -4,6 +4,16 @@
 #include <stdint.h>
 #include <stddef.h>
 
+// Dry runs (sscg_set_dry_run): every kernel launch of the library becomes a no-op while the host side of each entry point - argument
+// checks, planning, workspace carving, descriptor set-up - runs as usual.  bench.py uses it to time the host's issue cost of a step
+// with no back-pressure from the device ("host_issue_unblocked_ms").  One flag per process, read at every launch site.
+extern int g_sscg_dry_run;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                   \
+    do {                                                                                                                     \
+        if (!g_sscg_dry_run) { (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__); }        \
+    } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 

@@ -336,6 +336,13 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 
 extern "C" int sscg_abi_version(void) { return SSCG_ABI_VERSION; }
 
+int g_sscg_dry_run = 0;
+extern "C" int sscg_set_dry_run(int on) {
+    const int was = g_sscg_dry_run;
+    g_sscg_dry_run = on ? 1 : 0;
+    return was;
+}
+
 #define SSCG_DT_OK(dt) ((dt) == SSCG_F32 || (dt) == SSCG_BF16)
 #define BF(p) reinterpret_cast<const __bf16*>(p)
 #define BFW(p) reinterpret_cast<__bf16*>(p)

@@ -108,6 +108,50 @@ def broadcast_flat(flat, src=0, chunk=CHUNK_ELEMS):
     return flat
 
 
+def device_identity(index=None):
+    """A string that names the physical GPU this rank computes on: the device UUID where torch exposes it, else PCI domain:bus:device
+    (two ranks on one GPU report the same string; a CPU-only rank reports "cpu")."""
+    if not torch.cuda.is_available():
+        return "cpu"
+    index = torch.cuda.current_device() if index is None else index
+    p = torch.cuda.get_device_properties(index)
+    uuid = getattr(p, "uuid", None)
+    if uuid is not None:
+        return str(uuid)
+    return "pci %04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", index), getattr(p, "pci_device_id", 0))
+
+
+def collective_version():
+    """(library, version string) of the collective backend in use: RCCL reports through torch.cuda.nccl.version() on ROCm."""
+    if not dist.is_initialized():
+        return None, None
+    backend = dist.get_backend()
+    if backend == "nccl":
+        try:
+            v = torch.cuda.nccl.version()
+            return "rccl", ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception as e:          # the figure is a report, never a reason to fail a run
+            return "rccl", "unknown (%s)" % type(e).__name__
+    return backend, torch.__version__
+
+
+def rank_census(ms_per_step):
+    """What the job actually ran on, gathered from every rank (bench.py's `rccl` object): world size as the process group sees it,
+    the physical device of each rank, how many DISTINCT devices that is, the collective library's version and every rank's own
+    ms per step.  The bench line's `n_gpus` is WORLD_SIZE from the environment; this is the evidence beside it."""
+    me = {"rank": int(os.environ.get("RANK", "0")), "device": device_identity(), "ms_per_step": round(float(ms_per_step), 3)}
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        rows = [None] * dist.get_world_size()
+        dist.all_gather_object(rows, me)
+    else:
+        rows = [me]
+    rows.sort(key=lambda r: r["rank"])
+    lib, ver = collective_version()
+    return {"backend": lib, "version": ver, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "distinct_devices": len(set(r["device"] for r in rows)), "devices": [r["device"] for r in rows],
+            "per_rank_ms": [r["ms_per_step"] for r in rows]}
+
+
 def max_over_ranks(value):
     """Max of a host float over ranks (bench timing)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

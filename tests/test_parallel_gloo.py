@@ -55,8 +55,14 @@ def _worker(rank, world, port, q):
     g_shard = grads(x[rank * 2:(rank + 1) * 2]).float()
     par.allreduce_flat(g_shard)
     ok4 = float((g_shard.double() / world - g_full).abs().max() / g_full.abs().max()) < 1e-6
+    # 5. the census behind bench.py's `rccl` object: every rank reports its device and its own step time; the process group's world
+    #    size, the per-rank list in rank order and the number of DISTINCT devices come back identical on every rank.  (CPU ranks all
+    #    report "cpu" = one device for two ranks: exactly the condition under which bench.py refuses to call a run an N-GPU run.)
+    census = par.rank_census(10.0 + rank)
+    ok5 = (census["world_size"] == world and census["per_rank_ms"] == [10.0, 11.0] and census["devices"] == ["cpu", "cpu"]
+           and census["distinct_devices"] == 1 and census["backend"] == "gloo" and census["version"])
     dp.barrier()
-    q.put((rank, ok1, ok2, ok3, ok4))
+    q.put((rank, ok1, ok2, ok3, ok4, bool(ok5)))
     dist.destroy_process_group()
 
 
