@@ -34,6 +34,12 @@ namespace {
 #ifndef KS_BUFLD
 #define KS_BUFLD 1         // LDS-DMA copies as `buffer_load_dwordx4 ... offen lds`: per-lane row offset in ONE VGPR (computed once per tap), the k-tile's
 #endif                     // chunk offset in an SGPR - no 64-bit VALU address arithmetic per copy (0 = global_load_lds with 64-bit addresses)
+#ifndef KS_ACC2
+#define KS_ACC2 1          // leading piece product and the five small ones in separate accumulators (wave tiles <= 32 x 64)
+#endif
+#ifndef KS_LB4
+#define KS_LB4 1           // 64x64 class: hold the kernel to 128 registers (4 workgroups per CU, what its 40 KB of LDS allow) - two accumulator sets take it to 134
+#endif
 constexpr int BKS = 32;                    // k per tile
 typedef __bf16 bf16;
 typedef uint32_t u32;
@@ -94,7 +100,7 @@ __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
 template <int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
+__global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) void convs_kernel(KsParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -310,13 +316,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
     const int row_w = wm * TM * 32;
     const int col_w = wn * TN * 32;
 
+    // Two accumulator sets where the wave tile leaves the registers (wave tiles up to 32 x 64): the LEADING piece product a0 b0 goes
+    // to `acc`, the five small ones (<= 2^-8 of it) to `acc_lo`, summed once after the k-loop.  Every MFMA rounds its accumulator
+    // once; with one set a 3x3 256-channel reduction is a chain of 864 roundings at the full magnitude of the running sum - 5.9e-7
+    // rms against fp64, 3.8x torch's blocked CPU convolution on the same inputs (tests/aids/local_error.py: the source of the
+    // build's 1.2-1.5x forward noise on DeepLab).  Kept apart, only the 144 roundings of the a0 b0 chain are at full magnitude
+    // (the others are 2^-8 of it): sqrt(6) = 2.4x less rounding noise for 16 / 32 more registers, no more MFMAs.
+    constexpr bool ACC2 = KS_ACC2 && TM * TN <= 2;
     f32x16 acc[TM][TN];
+    f32x16 acc_lo[ACC2 ? TM : 1][ACC2 ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                if (ACC2) acc_lo[i][j][e] = 0.f;
+            }
 
     // fragment addresses.  MFMA step s (k = 16 s .. 16 s + 15 of the tile): lane half h supplies k = 16 s + 8 h + (0..7):
     //   A (fp32): 16-byte slots 4 s + 2 h and 4 s + 2 h + 1 of the 128-byte row, stored at slot ^ ((row >> 1) & 7);
@@ -372,8 +389,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][i][ap], fb[set][j][bp], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+                if (ACC2 && (ap | bp) != 0)
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][i][ap], fb[set][j][bp], acc_lo[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][i][ap], fb[set][j][bp], acc[i][j], 0, 0, 0);
+            }
     };
     constexpr int NM = TM * TN;                 // MFMAs per piece product
     constexpr int NV = TM * 44;                 // VALU operations of one split_set
@@ -443,6 +464,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void convs_kernel(KsParams p) {
             half_tile(0, true);
             half_tile(1, false);
         }
+    }
+
+    if (ACC2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += acc_lo[i][j];
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
