@@ -25,6 +25,7 @@
 #include "common.h"
 #include "sscg_internal.h"
 #include "reduce_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -99,9 +100,14 @@ template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_w
 __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
-template <int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) void convs_kernel(KsParams p) {
-    constexpr int NT = WM * WN * 64;
+// KG = 2: TWO wave groups of WM * WN waves share the tile and halve its reduction (k-tiles [0, n/2) and [n/2, n)), each with its own
+// LDS stages; the second group's accumulators join the first's through LDS before the epilogue.  For launches whose tile count
+// barely exceeds the CU count (8712-row maps x 256 output channels = 276 tiles of 128 x 64: ONE 4-wave workgroup per CU, one wave
+// per SIMD - every LDS wait, barrier and split sequence of that wave is exposed): two waves per SIMD without the partial tiles
+// and the reduce pass of a split-K over workgroups.
+template <int MODE, int WM, int WN, int TM, int TN, int KG = 1>
+__global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG == 1) ? 4 : 2)) void convs_kernel(KsParams p) {
+    constexpr int NT = WM * WN * 64;          // threads of one wave group
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int NSTAGE = 2;
@@ -116,9 +122,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
     constexpr int B_STAGE = 3 * B_PLANE;
     constexpr int NPIECE = PA + PB;
 
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2] A images, then [2][3] B plane images
+    constexpr int GROUP_LDS = NSTAGE * (A_STAGE + B_STAGE);
 
-    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // per wave group: [2] A images, then [2][3] B plane images
+
+    const int tid = KG > 1 ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x;                 // thread inside its wave group
+    const int kgrp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NT)) : 0;
     int split = 0, tile;
     bool partial = false;
     if ((int)blockIdx.x < p.full_tiles) {
@@ -221,8 +230,13 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
     };
 
     const int nk_all = p.Ktot / BKS;                         // Cs % 32 == 0: a k-tile never straddles a tap
-    const int kt0 = partial ? split * p.ksplit : 0;
-    const int kt1 = partial ? min(nk_all, kt0 + p.ksplit) : nk_all;
+    int kt0 = partial ? split * p.ksplit : 0;
+    int kt1 = partial ? min(nk_all, kt0 + p.ksplit) : nk_all;
+    int nk_pad = 0;                                          // KG > 1: barriers of the longer group's loop
+    if (KG > 1) {
+        nk_pad = (kt1 - kt0 + 1) / 2;
+        if (kgrp == 0) kt1 = kt0 + nk_pad; else kt0 = kt0 + nk_pad;
+    }
     const int f_nchunk = p.Cs / BKS;
     int f_chunk, f_ky, f_kx;
     {
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
     f_k += f_chunk * BKS;
 
     typedef __attribute__((address_space(3))) char lds_char;
-    lds_char* const lds0 = (lds_char*)smem_raw;
+    lds_char* const lds0 = (lds_char*)smem_raw + kgrp * GROUP_LDS;
     const int lds_wave = __builtin_amdgcn_readfirstlane(wave_id * 1024);      // this wave's 1 KB of every loader pass
     auto request_tile = [&]() {
         if (f_chunk == f_nchunk) {       // wave-uniform: next tap
@@ -465,12 +479,38 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
             half_tile(1, false);
         }
     }
+    if (KG > 1) {       // the groups' loops meet at workgroup barriers: the shorter one (one k-tile less, or none) keeps the count
+        for (int i = nk; i < nk_pad; ++i) __builtin_amdgcn_s_barrier();
+    }
 
     if (ACC2) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] += acc_lo[i][j];
+    }
+
+    if (KG > 1) {
+        // the second group's sums join the first's through its own (now dead) stage images, register by register, lane by lane:
+        // a fixed order, so the result does not depend on which group finished first
+        __syncthreads();                        // every wave of both groups has read its last fragments
+        float* const mb = reinterpret_cast<float*>(smem_raw + GROUP_LDS) + (wave_id * TM * TN * 16) * 64 + (tid & 63);
+        if (kgrp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) mb[((i * TN + j) * 16 + e) * 64] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (kgrp == 1) return;                  // (a barrier waits for the surviving waves only)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += mb[((i * TN + j) * 16 + e) * 64];
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -698,10 +738,17 @@ __global__ __launch_bounds__(256) void ks_reduce_kernel(const float* __restrict_
 constexpr bool KS_STAGE_OUT_HOST = KS_STAGE_OUT != 0;      // the addend joins in the staged store phase
 
 // ---- host side: tile classes and the split-K plan of the tail (same policy as conv_igemm.hip)
-enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_NCFG = 5 };
-const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64};
-const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128};
-const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2};        // wave rows of a tile = statistics records per tile row
+enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_128x64_K2 = 5, KS_NCFG = 6 };
+const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64, 128};
+const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128, 64};
+const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2, 4};     // wave rows of a tile = statistics records per tile row
+#ifndef KS_K2
+#define KS_K2 1            // 128x64 tiles as two wave groups halving the reduction where the launch has barely more tiles than the chip has CUs
+#endif
+static int ks_k2_or(int cfg, long tiles, int Ktot) {
+    static const int off = getenv("SSCG_KS_NO_K2") ? 1 : 0;          // A/B aid
+    return (KS_K2 && !off && cfg == KS_128x64 && tiles <= 384 && Ktot >= 1024) ? KS_128x64_K2 : cfg;
+}
 
 // Measured on the step's shapes (tools/convs_bench.py, profiles/r03_convs_tile_classes.txt):
 //  * 128x128 (4 waves of 64x64) wins wherever it fills the chip twice over (>= 512 tiles; >= 1024 when the reduction is short):
@@ -713,11 +760,11 @@ int ks_choose(long M, int Ng, int Ktot, int tuning) {
     const int forced = (tuning & 0xff) - 1;
     if (forced >= 0 && forced < KS_NCFG && Ng >= KS_BN[forced] / 2) return forced;
     const long tm = cdiv(M, 128);
-    if (Ng <= 64) return tm >= 384 ? KS_128x64 : KS_64x64;
+    if (Ng <= 64) return tm >= 384 ? KS_128x64 : KS_64x64;          // (>= 384 tiles: never the two-group form)
     const long t128 = tm * cdiv(Ng, 128);
     if (Ng <= 128) return (t128 >= 1024 && Ktot >= 512) ? KS_128x128 : KS_64x64;
     if (t128 >= (Ktot >= 1024 ? 512 : 1024) && Ktot >= 512) return KS_128x128;
-    if (Ktot >= 1024) return KS_128x64;
+    if (Ktot >= 1024) return ks_k2_or(KS_128x64, tm * cdiv(Ng, 64), Ktot);
     return KS_64x64;
 }
 
@@ -770,16 +817,16 @@ size_t ks_split_bytes(const KsSplit& sp, long M, int Ng) {
     return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, int KG = 1>
 int launch_ks(const KsParams& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int NT = WM * WN * 64;
+    constexpr int NT = WM * WN * 64 * KG;
     KsParams p = p0;
     p.tiles_n = cdiv(p.Ng, BN);
     p.tiles = cdiv(p.M, BM) * p.tiles_n;
-    const size_t smem = (size_t)2 * (BM * 128 + 3 * BN * 64);
-    auto kern = convs_kernel<MODE, WM, WN, TM, TN>;
+    const size_t smem = (size_t)KG * 2 * (BM * 128 + 3 * BN * 64);
+    auto kern = convs_kernel<MODE, WM, WN, TM, TN, KG>;
     SSCG_ENSURE_SMEM((kern), smem);
     if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
@@ -805,6 +852,7 @@ int dispatch_ks(const KsParams& p, int tuning, hipStream_t st) {
         case KS_64x64: return launch_ks<MODE, 2, 2, 1, 1>(p, st);
         case KS_128x64: return launch_ks<MODE, 4, 1, 1, 2>(p, st);
         case KS_64x128: return launch_ks<MODE, 2, 2, 1, 2>(p, st);
+        case KS_128x64_K2: return launch_ks<MODE, 4, 1, 1, 2, 2>(p, st);  // two groups of 4 waves of 32x64, half the reduction each
         default: return SSCG_ERR_BAD_ARG;
     }
 }

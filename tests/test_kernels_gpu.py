@@ -1225,3 +1225,45 @@ def test_fused_fan_in_against_fp64_at_bench_size_bf16(case, F, dev):
     excess = float((err - (d64.abs() + ref.abs()) * (2.0 ** -8)).max())
     assert excess <= 2e-5, excess
     assert float(err.pow(2).mean().sqrt()) / float(ref.pow(2).mean().sqrt()) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------ every tile class of the split family
+# (N, C, H, W, K, R, stride, pad, dil): ragged rows, a long reduction (tail split-K + an odd number of k-tiles per wave group), a
+# short one (fewer k-tiles than wave groups can share evenly), stride 2 (parity-class data gradient)
+_KS_CLASS_CASES = [(2, 256, 33, 33, 256, 3, 1, 2, 2), (3, 96, 19, 23, 160, 3, 1, 1, 1), (2, 32, 17, 17, 64, 1, 1, 0, 1), (2, 1024, 17, 17, 256, 1, 1, 0, 1),
+                   (2, 64, 32, 32, 128, 3, 2, 1, 1)]
+
+
+@pytest.mark.parametrize("cls", [0, 1, 2, 3, 4, 5], ids=["128x128", "128x128r", "64x64", "128x64", "64x128", "128x64_two_groups"])
+@pytest.mark.parametrize("case", _KS_CLASS_CASES, ids=lambda c: "%dx%dx%dx%d_k%d_r%d_s%d_p%d_d%d" % c)
+def test_split_conv_every_tile_class(case, cls, F, dev):
+    """conv_split.hip's tile classes forced through sscg_conv_desc.tuning - among them the two-wave-group form of the 128x64 tile
+    (both groups halve the reduction, the second group's accumulators join through LDS) - forward with the fused normalisation
+    statistics, and the data gradient, against torch fp64."""
+    n, c, h, w, k, r, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case) + cls)
+    x = torch.randn(n, c, h, w, generator=g, dtype=torch.float64)
+    wt = torch.randn(k, c, r, r, generator=g, dtype=torch.float64) * (1.0 / (c * r * r) ** 0.5)
+    xr = x.clone().requires_grad_(True)
+    yr = TF.conv2d(xr, wt, None, s, p, d)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    dxr = torch.autograd.grad(yr, xr, gy)[0]
+    F.set_conv_precision("f32s")
+    old = F.tuning(tile_class=cls)
+    try:
+        xg, wg = gpu(x, dev), gpu(wt, dev)
+        L = n * yr.shape[2] * yr.shape[3]
+        yg, cs = F.conv2d_fwd(xg, wg, None, s, p, d, stats=(1, L))
+        if cs is not None:
+            mean, rstd = F.norm_stats_from_conv(cs, (1, L, k), 1e-5)
+        dx = F.conv2d_dgrad(gpu(gy, dev), F.dgrad_operand(wg, x.shape, s, p, d), x.shape, wt.shape, s, p, d)
+    finally:
+        F.TUNING[0], F.WGRAD_TUNING[0] = old
+        F.set_conv_precision("f32")
+    assert rel_err(yg, yr) < 2e-6
+    assert rel_err(dx, dxr) < 2e-6
+    if cs is not None:
+        m64 = yr.detach().mean((0, 2, 3))
+        v64 = yr.detach().var((0, 2, 3), unbiased=False)
+        assert float(((mean[0].double().cpu() - m64) / v64.sqrt()).abs().max()) < 2e-6
+        assert float((rstd[0].double().cpu() * (v64 + 1e-5).sqrt() - 1).abs().max()) < 2e-6
