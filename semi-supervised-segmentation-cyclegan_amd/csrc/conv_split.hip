@@ -742,12 +742,19 @@ enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 
 const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64, 128};
 const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128, 64};
 const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2, 4};     // wave rows of a tile = statistics records per tile row
-#ifndef KS_K2
-#define KS_K2 1            // 128x64 tiles as two wave groups halving the reduction where the launch has barely more tiles than the chip has CUs
-#endif
+// The two-wave-group form of the 128x64 tile is built and tested but OFF by default: alone it hides the exposed waits of a launch
+// with one workgroup per CU, but in the four-lane step it costs +4 ms (135.2 against 131.1 ms, interleaved A/B on one box, round 5):
+// 112 KB of LDS and 2 x 208 registers per SIMD leave no room for the other lanes' workgroups on that CU, and those - not idle issue
+// slots - are what fills the chip in the step.  SSCG_KS_K2=1 switches it on (tools/convs_bench.py).
 static int ks_k2_or(int cfg, long tiles, int Ktot) {
-    static const int off = getenv("SSCG_KS_NO_K2") ? 1 : 0;          // A/B aid
-    return (KS_K2 && !off && cfg == KS_128x64 && tiles <= 384 && Ktot >= 1024) ? KS_128x64_K2 : cfg;
+    static const int on = getenv("SSCG_KS_K2") ? atoi(getenv("SSCG_KS_K2")) : 0;
+    return (on && cfg == KS_128x64 && tiles <= 384 && Ktot >= 1024) ? KS_128x64_K2 : cfg;
+}
+// A/B aids for the tile-class policy inside the step (the thresholds below were tuned on kernels timed ALONE; in the step the VALU
+// pipe is the contended resource, and classes with fewer split operations per MFMA may win there although they lose alone)
+static int ks_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 // Measured on the step's shapes (tools/convs_bench.py, profiles/r03_convs_tile_classes.txt):
@@ -757,14 +764,18 @@ static int ks_k2_or(int cfg, long tiles, int Ktot) {
 //    128x128 tiling would leave CUs idle (135-185 TF/s against 95-168);
 //  * 64x64 for short reductions (1x1 convs with <= 512 source channels: prologue / epilogue bound) and few output channels.
 int ks_choose(long M, int Ng, int Ktot, int tuning) {
+    static const int T128_SHORT = ks_env("SSCG_KS_T128_SHORT", 1024);   // min 128x128 tiles for that class on a short reduction
+    static const int K128 = ks_env("SSCG_KS_K128", 512);               // min reduction length for the 128x128 class
+    static const int K12864 = ks_env("SSCG_KS_K12864", 1024);          // min reduction length for the 128x64 class
+    static const int T12864 = ks_env("SSCG_KS_T12864", 0);             // min 128x64 tiles for that class (0: no condition)
     const int forced = (tuning & 0xff) - 1;
     if (forced >= 0 && forced < KS_NCFG && Ng >= KS_BN[forced] / 2) return forced;
     const long tm = cdiv(M, 128);
     if (Ng <= 64) return tm >= 384 ? KS_128x64 : KS_64x64;          // (>= 384 tiles: never the two-group form)
     const long t128 = tm * cdiv(Ng, 128);
-    if (Ng <= 128) return (t128 >= 1024 && Ktot >= 512) ? KS_128x128 : KS_64x64;
-    if (t128 >= (Ktot >= 1024 ? 512 : 1024) && Ktot >= 512) return KS_128x128;
-    if (Ktot >= 1024) return ks_k2_or(KS_128x64, tm * cdiv(Ng, 64), Ktot);
+    if (Ng <= 128) return (t128 >= T128_SHORT && Ktot >= K128) ? KS_128x128 : KS_64x64;
+    if (t128 >= (Ktot >= 1024 ? 512 : T128_SHORT) && Ktot >= K128) return KS_128x128;
+    if (Ktot >= K12864 && tm * cdiv(Ng, 64) >= T12864) return ks_k2_or(KS_128x64, tm * cdiv(Ng, 64), Ktot);
     return KS_64x64;
 }
 
