@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Stream-level timeline of a rocprofv3 --kernel-trace run of bench.py: for the last `steps` training steps (delimited by the optimiser
+launches) - per stream: kernels, busy time, the gaps BETWEEN consecutive kernels of that stream (dependency / issue stalls of a lane);
+over all streams: how long exactly k kernels were in flight; and the kernels that ran ALONE for the longest total time (what the chip
+executes with nothing beside it).  usage: python tools/timeline.py <results.db> [steps]"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    i = name.find("(")
+    return (name[:i] if i > 0 else name)[:60]
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    rows = db.execute("select start, end, stream_id, name from kernels order by start").fetchall()
+    adam = [r[1] for r in rows if "adam_kernel" in r[3]]
+    lo, hi = adam[-1 - 2 * steps], adam[-1]
+    rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
+    span = hi - lo
+    print("window: %d steps, %.2f ms per step, %d kernels per step" % (steps, span / steps / 1e6, len(rows) // steps))
+    per = defaultdict(list)
+    for s, e, sid, n in rows:
+        per[sid].append((s, e, n))
+    print("per stream (ms per step): kernels | busy | gaps between its kernels: <3us, 3-10us, 10-30us, 30-100us, >100us (count / ms)")
+    for sid, ks in sorted(per.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
+        busy = sum(e - s for s, e, _ in ks)
+        bins = [[0, 0] for _ in range(5)]
+        for (s0, e0, _), (s1, e1, _) in zip(ks, ks[1:]):
+            g = max(0, s1 - e0)
+            b = 0 if g < 3000 else 1 if g < 10000 else 2 if g < 30000 else 3 if g < 100000 else 4
+            bins[b][0] += 1
+            bins[b][1] += g
+        print("  stream %-4s %5d | %6.1f | %s" % (sid, len(ks) // steps, busy / steps / 1e6,
+                                                 "  ".join("%d / %.1f" % (c // steps, t / steps / 1e6) for c, t in bins)))
+    # concurrency histogram by sweeping events
+    ev = []
+    for i, (s, e, sid, n) in enumerate(rows):
+        ev.append((s, 1, i))
+        ev.append((e, -1, i))
+    ev.sort()
+    active = set()
+    hist = defaultdict(int)
+    alone = defaultdict(int)
+    prev = ev[0][0]
+    for t, d, i in ev:
+        k = len(active)
+        hist[k] += t - prev
+        if k == 1:
+            alone[short(rows[next(iter(active))][3])] += t - prev
+        prev = t
+        if d > 0:
+            active.add(i)
+        else:
+            active.discard(i)
+    print("kernels in flight (ms per step): " + "  ".join("%d: %.1f" % (k, v / steps / 1e6) for k, v in sorted(hist.items())))
+    print("running ALONE (ms per step), top 12:")
+    for n, v in sorted(alone.items(), key=lambda kv: -kv[1])[:12]:
+        print("  %6.2f  %s" % (v / steps / 1e6, n))
+
+
+if __name__ == "__main__":
+    main()
