@@ -93,6 +93,8 @@ struct KsParams {
     double* __restrict__ bn_sums;        // [G][bn_chunks][Ng][2]
     int bn_L, bn_G, bn_chunks, bn_act;
     float bn_slope;
+    FastDiv div_tn, div_gl;              // by tiles_n; by stat_L / bn_L (whichever the launch uses)
+    FastDiv div_hw, div_w;               // by OH * OW and by OW (launch_ks): a row's (image, y, x) without integer divisions (~30 VALU operations each)
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -139,8 +141,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
         tile = p.full_tiles + (t - split * ntail);
         partial = p.splits > 1;
     }
-    const int tile_n = tile % p.tiles_n;
-    const int tile_m = tile / p.tiles_n;
+    const int tile_m = fd_div(tile, p.div_tn);
+    const int tile_n = tile - tile_m * p.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int wave_id = tid >> 6;
@@ -163,9 +165,9 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
         const int m = m0 + r0 + ps * RPA;
         aok[ps] = m < p.M;
         const int mm = aok[ps] ? m : 0;
-        const int img = mm / (p.OH * p.OW);
+        const int img = fd_div(mm, p.div_hw);
         const int rem = mm - img * (p.OH * p.OW);
-        const int oy = rem / p.OW;
+        const int oy = fd_div(rem, p.div_w);
         const int ox = rem - oy * p.OW;
 #if KS_BUFLD
         arow[ps] = (unsigned)img * (unsigned)(p.SH * p.SW * p.Cs) * 4u;
@@ -519,9 +521,9 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     const bool want_stats = p.stats != nullptr && !partial;
     const bool want_bsums = MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (never with split-K: the host plans these launches unsplit)
     int gb = 0x7fffffff;
-    if (want_stats) gb = (m0 / p.stat_L + 1) * p.stat_L;
+    if (want_stats) gb = (fd_div(m0, p.div_gl) + 1) * p.stat_L;
     int bg = 0;
-    if (want_bsums) { bg = m0 / p.bn_L; gb = (bg + 1) * p.bn_L; }
+    if (want_bsums) { bg = fd_div(m0, p.div_gl); gb = (bg + 1) * p.bn_L; }
     // Tiles inside one group and inside the tensor (nearly all): four consecutive rows are summed in fp32, the 4-row sums in fp64 (as the
     // bf16 kernel does); tiles that straddle a group boundary or the tensor's end take every element to fp64.  Round 3 took EVERY
     // element to fp64 because the shortcut moves a BatchNorm statistic by ~1e-7 and the chained-loss bound then sat at 1e-3; round 4
@@ -584,9 +586,9 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                         } else {
                             size_t row = (size_t)m;
                             if (p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
-                                const int img = m / (p.OH * p.OW);
+                                const int img = fd_div(m, p.div_hw);
                                 const int rem = m - img * (p.OH * p.OW);
-                                const int oi = rem / p.OW;
+                                const int oi = fd_div(rem, p.div_w);
                                 const int oj = rem - oi * p.OW;
                                 row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
                             }
@@ -628,9 +630,9 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
         }
         auto out_row = [&](int m) -> size_t {
             if (p.o_step == 1) return (size_t)m;
-            const int img = m / (p.OH * p.OW);      // parity class of a strided data gradient: rows interleave into dx
+            const int img = fd_div(m, p.div_hw);      // parity class of a strided data gradient: rows interleave into dx
             const int rem = m - img * (p.OH * p.OW);
-            const int oi = rem / p.OW;
+            const int oi = fd_div(rem, p.div_w);
             const int oj = rem - oi * p.OW;
             return (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
         };
@@ -834,7 +836,11 @@ int launch_ks(const KsParams& p0, hipStream_t st) {
     constexpr int BN = WN * TN * 32;
     constexpr int NT = WM * WN * 64 * KG;
     KsParams p = p0;
+    p.div_hw = make_fastdiv(p.OH * p.OW);
+    p.div_w = make_fastdiv(p.OW);
     p.tiles_n = cdiv(p.Ng, BN);
+    p.div_tn = make_fastdiv(p.tiles_n);
+    p.div_gl = make_fastdiv((MODE == MODE_DGRAD && p.bn_sums != nullptr) ? p.bn_L : (p.stat_L > 0 ? p.stat_L : 1));
     p.tiles = cdiv(p.M, BM) * p.tiles_n;
     const size_t smem = (size_t)KG * 2 * (BM * 128 + 3 * BN * 64);
     auto kern = convs_kernel<MODE, WM, WN, TM, TN, KG>;
