@@ -219,6 +219,47 @@ class ForkStream:
                 torch.cuda.current_stream(device).wait_stream(s)
 
 
+def lane_events(device):
+    """An event on every lane that may carry gradient kernels of the current backward pass - the calling stream, the fork lane, the
+    side lanes (deferred side-lane work is launched first): a stream that waits for all of them sees every gradient kernel queued
+    so far (parallel.GradBuckets orders a bucket's all-reduce behind them)."""
+    flush_side_work(device)
+    streams = [torch.cuda.current_stream(device)]
+    for reg in (ForkStream._streams, SideStream._streams):
+        for (dev, _), st in reg.items():
+            if dev == device:
+                streams.append(st)
+    evs = []
+    for st in streams:
+        ev = torch.cuda.Event()
+        ev.record(st)
+        evs.append(ev)
+    return evs
+
+
+# Data parallelism with bucketed gradient exchange (parallel.GradBuckets): GRAD_READY[0] is called with a parameter once the LAST
+# gradient kernel of this backward pass that accumulates into its arena slice has been queued.  "Last" is known by counting: every
+# forward of a conv whose weight will receive a gradient notes one use (_note_use), every backward of one takes it back (_note_done).
+GRAD_READY = [None]
+
+
+def _note_use(*params):
+    if GRAD_READY[0] is not None:
+        for p in params:
+            if p is not None and getattr(p, "_sscg_grad", None) is not None:
+                p._sscg_uses = getattr(p, "_sscg_uses", 0) + 1
+
+
+def _note_done(*params):
+    hook = GRAD_READY[0]
+    if hook is not None:
+        for p in params:
+            if p is not None and getattr(p, "_sscg_grad", None) is not None:
+                p._sscg_uses = getattr(p, "_sscg_uses", 0) - 1
+                if p._sscg_uses == 0:
+                    hook(p)
+
+
 def d_stream(device):
     """Stream of the overlapped discriminator step: the LAST side lane - idle between the end of a backward pass and
     the next one, which is when the D step runs.  Not a stream of its own: a fifth stream in flight costs ~20 % (the
@@ -1357,6 +1398,8 @@ class Conv2dFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.wref = w
         ctx.bref = bias
+        if ctx.needs_input_grad[1]:
+            _note_use(w, bias)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         # (mean, rstd) are non-differentiable outputs: left alone, autograd hands backward() two zero-filled tensors for them -
         # 850 fill launches per Cityscapes step
@@ -1439,6 +1482,8 @@ def _conv_backward(dy, x, w, wref, bref, geom, want_x, want_w, want_b):
         dw = conv2d_wgrad(x, dy, w.shape, stride, pad, dil, pad_mode)
     if want_b and bacc is None:
         db = colsum(n * p * q, k, dy)
+    if want_w:
+        _note_done(wref, bref)
     return dx, dw, db
 
 
@@ -1605,6 +1650,8 @@ class ConvNormActFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.wref, ctx.bref, ctx.gref, ctx.betaref = w, bias, gamma, beta
+        if ctx.needs_input_grad[1]:
+            _note_use(w, bias)
         need_z = act != ACT_NONE and (residual is not None or act not in (ACT_RELU, ACT_LRELU))
         ctx.save_for_backward(x, w, y, z if need_z else None, mean, rstd, gamma, beta)
         ctx.res_join = getattr(residual, "_sscg_join", None) if (residual is not None and FUSE_JOIN[0]) else None
@@ -1657,6 +1704,8 @@ class ConvNormActHeadFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_hbias = hbias is not None
         ctx.wref, ctx.bref, ctx.gref, ctx.betaref, ctx.hwref, ctx.hbref = w, bias, gamma, beta, hw, hbias
+        if ctx.needs_input_grad[1]:
+            _note_use(w, bias)
         ctx.save_for_backward(x, w, y, mean, rstd, gamma, beta, hw32)
         return out
 

@@ -140,6 +140,8 @@ class semisuper_cycleGAN(object):
         set_grad([self.Di, self.Ds, self.old_Di], False)
         set_grad([self.old_Gsi, self.old_Gis], False)
         self.g_optimizer.zero_grad()
+        if self.dp is not None:
+            self.dp.begin_backward(self.g_optimizer)     # SSCG_DP_BUCKETS: buckets of the gradient arena go out as the backward fills them
         # the generators' operand copies (bf16 shadow / split planes) exist and are current before any lane reads them: a no-op
         # after the first step (the Adam kernel rewrites them); the discriminators' follow at :431, behind their own update
         self.g_optimizer.ensure_operand_copies()

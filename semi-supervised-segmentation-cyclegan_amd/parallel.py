@@ -60,10 +60,25 @@ class DataParallel:
     def sync_grads(self, opt):
         allreduce_flat(opt.grad)
 
+    def begin_backward(self, opt):
+        """SSCG_DP_BUCKETS=n (n > 1): exchange `opt`'s gradient arena in n buckets, each as soon as the backward pass has queued the
+        last gradient kernel of its parameters (reverse-order overlap with the backward).  Call before the step's
+        forwards; `sync_grads_async` then returns the handles of the buckets already in flight plus the rest."""
+        n = int(os.environ.get("SSCG_DP_BUCKETS", "0"))
+        if n < 2:
+            return
+        b = getattr(opt, "_sscg_buckets", None)
+        if b is None or b.n_asked != n:
+            b = opt._sscg_buckets = GradBuckets(opt, n)
+        b.begin()
+
     def sync_grads_async(self, opt):
         """Start the all-reduce of an optimiser's gradient arena and return the work handles: the generator
         exchange (343 MB) then runs over xGMI while the discriminator step computes (nothing in the D step reads
         generator weights, so applying the G update after it is the same arithmetic as model.py:474)."""
+        b = getattr(opt, "_sscg_buckets", None)
+        if b is not None and b.active:
+            return b.finish()
         return allreduce_flat(opt.grad, wait=False)
 
     @staticmethod
@@ -73,6 +88,83 @@ class DataParallel:
 
     def barrier(self):
         dist.barrier()
+
+
+class GradBuckets:
+    """Reverse-order bucketed exchange of one optimiser's gradient arena (off unless SSCG_DP_BUCKETS=n).
+
+    The arena is in parameter order; a bucket is a contiguous range of whole parameters.  The backward pass reaches the parameters
+    roughly last-to-first, several times over (every DeepLab is used by two or three passes of the step): functional counts a
+    parameter's uses in the forward and reports it (`functional.GRAD_READY`) when the backward has queued its LAST gradient kernel;
+    a bucket whose parameters have all reported is exchanged at once - on a stream of its own, behind one event per lane that may
+    carry gradient kernels - while the rest of the backward runs.  Buckets that never complete (parameters outside the counted
+    paths, unused parameters) go out from `finish()`, after the backward.  The launch order is a function of the step's graph
+    alone, hence identical on every rank (collectives must be issued in one order everywhere); the sums are the same
+    all-reduces over the same elements as the one-piece exchange, so the result does not depend on the bucketing."""
+
+    def __init__(self, opt, n):
+        from . import functional as F
+        self.F, self.opt, self.n_asked = F, opt, n
+        items = sorted(((off, cnt, p) for p, (off, cnt) in opt.slices.items()), key=lambda t: t[0])
+        total = opt.grad.numel()
+        self.bounds, self.bucket_of, self.size = [], {}, []
+        start, b = 0, 0
+        for i, (off, cnt, p) in enumerate(items):
+            self.bucket_of[id(p)] = b
+            if len(self.size) <= b:
+                self.size.append(0)
+            self.size[b] += 1
+            end = items[i + 1][0] if i + 1 < len(items) else total
+            if (end >= (b + 1) * total / n and b < n - 1) or i + 1 == len(items):
+                self.bounds.append((start, end))
+                start, b = end, b + 1
+        self.n = len(self.bounds)
+        self.active = False
+        self.comm = torch.cuda.Stream(device=opt.grad.device) if opt.grad.is_cuda else None
+
+    def begin(self):
+        for p in self.opt.slices:
+            p._sscg_uses = 0
+        self.left = list(self.size)
+        self.launched = [False] * self.n
+        self.works = []
+        self.order = []
+        self.active = True
+        self.F.GRAD_READY[0] = self.ready
+
+    def ready(self, p):
+        b = self.bucket_of.get(id(p))
+        if b is None or not self.active:
+            return
+        self.left[b] -= 1
+        if self.left[b] == 0 and not self.launched[b]:
+            self._launch(b)
+
+    def _launch(self, b):
+        lo, hi = self.bounds[b]
+        self.launched[b] = True
+        self.order.append(b)
+        flat = self.opt.grad[lo:hi]
+        if self.comm is None:
+            self.works += allreduce_flat(flat, wait=False)
+            return
+        dev = flat.device
+        evs = self.F.lane_events(dev)
+        for ev in evs:
+            self.comm.wait_event(ev)
+        with torch.cuda.stream(self.comm):
+            self.works += allreduce_flat(flat, wait=False)
+
+    def finish(self):
+        """After the backward pass: what has not gone out yet, then every handle (in launch order)."""
+        self.F.GRAD_READY[0] = None
+        for b in range(self.n - 1, -1, -1):
+            if not self.launched[b]:
+                self._launch(b)
+        self.active = False
+        if self.comm is not None:       # `wait()` on a handle orders the CALLING stream behind the collective; the comm stream's own
+            torch.cuda.current_stream(self.opt.grad.device).wait_stream(self.comm)   # prologue (event waits) is ordered here
+        return self.works
 
 
 def _refresh_operand_copies(opt):

@@ -56,11 +56,11 @@ def _state(m):
             "bn_var": m.Gis.state_dict()["layer2.1.bn1.running_var"].detach().cpu()}
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, buckets=0):
     import importlib
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      SSCG_DP_SHARED_GPU="1", SSCG_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      SSCG_DP_SHARED_GPU="1", SSCG_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SSCG_DP_BUCKETS=str(buckets))
     par = importlib.import_module(PKG_NAME + ".parallel")
     md = importlib.import_module(PKG_NAME + ".model")
     from oracle import fixtures as FX
@@ -79,7 +79,8 @@ def _worker(rank, world, port, outdir):
         m.sync_losses()
         losses.append({k: float(v) for k, v in out.items()})
     st = _state(m)
-    st.update(after_attach=after_attach, losses=losses)
+    gb = getattr(m.g_optimizer, "_sscg_buckets", None)
+    st.update(after_attach=after_attach, losses=losses, bucket_order=None if gb is None else list(gb.order), buckets=None if gb is None else gb.n)
     torch.save(st, os.path.join(outdir, "rank%d.pt" % rank))
     dp.barrier()
     import torch.distributed as dist
@@ -97,10 +98,14 @@ class _Deferred:
         self.real()
 
 
-def test_dp_step_world_size_2_shared_gpu(dev, tmp_path):
+@pytest.mark.parametrize("buckets", [0, 4], ids=["one_piece", "four_buckets_overlapping_the_backward"])
+def test_dp_step_world_size_2_shared_gpu(buckets, dev, tmp_path):
+    """buckets = 4: SSCG_DP_BUCKETS - the generator arena goes out in four all-reduces, each as soon as the backward has queued the
+    last gradient kernel of its parameters (parallel.GradBuckets); gloo reads the bucket on the host, so an all-reduce issued before
+    a gradient kernel it depends on would change the bits below."""
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), buckets)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -108,6 +113,11 @@ def test_dp_step_world_size_2_shared_gpu(dev, tmp_path):
         assert p.exitcode == 0, "rank process failed (exit code %s)" % p.exitcode
     r0 = torch.load(str(tmp_path / "rank0.pt"))
     r1 = torch.load(str(tmp_path / "rank1.pt"))
+    if buckets:
+        # every bucket went out, in one order on both ranks, and not all of them from finish() (which walks them last-to-first
+        # after the backward): at least the last bucket - the DeepLab stems and first layers - completes during the backward
+        assert r0["buckets"] == buckets and sorted(r0["bucket_order"]) == list(range(buckets)) and r0["bucket_order"] == r1["bucket_order"]
+        print("bucket launch order:", r0["bucket_order"])
     # (1) broadcast from rank 0 at attach time
     for k in ("g", "d", "old"):
         assert torch.equal(r0["after_attach"][k], r1["after_attach"][k]), "attach(): rank 1 does not hold rank 0's %s weights" % k

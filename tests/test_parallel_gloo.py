@@ -61,8 +61,25 @@ def _worker(rank, world, port, q):
     census = par.rank_census(10.0 + rank)
     ok5 = (census["world_size"] == world and census["per_rank_ms"] == [10.0, 11.0] and census["devices"] == ["cpu", "cpu"]
            and census["distinct_devices"] == 1 and census["backend"] == "gloo" and census["version"])
+    # 6. bucketed exchange (SSCG_DP_BUCKETS; parallel.GradBuckets) on a CPU arena: parameters report "last gradient kernel queued" in
+    #    reverse order, two of them never report (outside the counted paths) - their bucket goes out from finish().  Every element is
+    #    exchanged exactly once: the result is the plain sum over ranks, whatever the bucketing.
+    import types
+    sizes = [640, 64, 1280, 256, 64, 2048, 128, 704]
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    params = [torch.nn.Parameter(torch.zeros(1)) for _ in sizes]
+    opt = types.SimpleNamespace(slices={p_: (o, n_) for p_, o, n_ in zip(params, offs, sizes)}, grad=torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1))
+    gb = par.GradBuckets(opt, 3)
+    ok6 = gb.n == 3 and gb.bounds[0][0] == 0 and gb.bounds[-1][1] == sum(sizes) and all(a[1] == b[0] for a, b in zip(gb.bounds, gb.bounds[1:]))
+    gb.begin()
+    for p_ in reversed(params[2:]):          # (params 0 and 1 never report)
+        gb.ready(p_)
+    early = list(gb.order)
+    for w in gb.finish():
+        w.wait()
+    ok6 = ok6 and early == [2, 1] and gb.order == [2, 1, 0] and torch.equal(opt.grad, torch.arange(sum(sizes), dtype=torch.float32) * 3)
     dp.barrier()
-    q.put((rank, ok1, ok2, ok3, ok4, bool(ok5)))
+    q.put((rank, ok1, ok2, ok3, ok4, bool(ok5), bool(ok6)))
     dist.destroy_process_group()
 
 

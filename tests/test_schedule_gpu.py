@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 
 def _run(script, args, env=None, timeout=1100):
     e = dict(os.environ)
-    for k in ("SSCG_SIDE_PRIORITY", "SSCG_SIDE_LANES", "SSCG_FORCE_DP", "GPU_MAX_HW_QUEUES", "SSCG_RACECHECK", "SSCG_FUZZ"):
+    for k in ("SSCG_SIDE_PRIORITY", "SSCG_SIDE_LANES", "SSCG_FORCE_DP", "GPU_MAX_HW_QUEUES", "SSCG_RACECHECK", "SSCG_FUZZ", "SSCG_DP_BUCKETS"):
         e.pop(k, None)
     e.update(env or {})
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -47,6 +47,14 @@ def test_fuzzed_schedules_compute_the_serial_schedules_bits():
     one-stream run, from NaN-poisoned allocator blocks."""
     r = _run("fuzz_step.py", [2, 3, 64, 2], {"GPU_MAX_HW_QUEUES": "2", "SSCG_SIDE_PRIORITY": "1"})
     assert r.returncode == 0 and "0 of 3 schedules differ" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "finite=False" not in r.stdout
+
+
+def test_bucketed_exchange_through_rccl_equals_the_serial_non_dp_bits():
+    """The same with SSCG_DP_BUCKETS=4: four all-reduces on a stream of their own, each ordered behind one event per lane, while the
+    backward is still running - 12 steps, plain and fuzzed, bit for bit the serial non-DP run."""
+    r = _run("fuzz_step.py", [1, 12, 64, 2], {"SSCG_FORCE_DP": "1", "SSCG_DP_BUCKETS": "4", "MASTER_PORT": "29733"})
+    assert r.returncode == 0 and "0 of 2 schedules differ" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
     assert "finite=False" not in r.stdout
 
 
