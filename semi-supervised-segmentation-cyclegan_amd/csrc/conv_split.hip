@@ -114,7 +114,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     constexpr int BN = WN * TN * 32;
     constexpr int NSTAGE = 2;
     constexpr int RPA = NT / 8;               // A rows per loader pass (8 lanes x 16 B per 128-byte row)
-    constexpr int RPB = NT / 4;               // B rows per loader pass (4 lanes x 16 B per 64-byte row)
+    constexpr int RPB = (NT / 4 < BN) ? NT / 4 : BN;   // B rows per loader pass (4 lanes x 16 B per 64-byte row); a tile narrower than a pass
+                                              // (BN = 32): the upper waves copy the same rows to the same place again
     constexpr int PA = BM / RPA;
     constexpr int HB = BN / RPB;              // passes per weight plane
     constexpr int PB = 3 * HB;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     // ---- copy side
     const int r0 = tid >> 3;                                   // A row inside a pass
     const int kqa = (tid & 7) ^ ((r0 >> 1) & 7);               // 16-byte k slot this lane fetches (lands at LDS slot tid & 7 of row r0)
-    const int rb0 = tid >> 2;                                  // B row inside a pass
+    const int rb0 = (tid >> 2) % RPB;                          // B row inside a pass
     const int kqb = (tid & 3) ^ ((rb0 >> 2) & 3);
 
 #if KS_BUFLD
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     typedef __attribute__((address_space(3))) char lds_char;
     lds_char* const lds0 = (lds_char*)smem_raw + kgrp * GROUP_LDS;
     const int lds_wave = __builtin_amdgcn_readfirstlane(wave_id * 1024);      // this wave's 1 KB of every loader pass
+    const int lds_wave_b = __builtin_amdgcn_readfirstlane((wave_id % (RPB / 16)) * 1024);
     auto request_tile = [&]() {
         if (f_chunk == f_nchunk) {       // wave-uniform: next tap
             f_chunk = 0;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + dma_stage * B_STAGE +
-                                                                                                        pl * B_PLANE + lds_wave + hb * (RPB * 64)),
+                                                                                                        pl * B_PLANE + lds_wave_b + hb * (RPB * 64)),
                                                          16, (int)brow[hb], so_b, 0, 0);
         }
 #else
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                 const bf16* g = brow[hb] + (pl * p.wplane + f_k);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + dma_stage * B_STAGE + pl * B_PLANE +
-                                                                                            lds_wave + hb * (RPB * 64)), 16, 0, 0);
+                                                                                            lds_wave_b + hb * (RPB * 64)), 16, 0, 0);
             }
         }
 #endif
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
 #define KS_STAGE_OUT 1
 #endif
     constexpr int OLD = BN + 4;
-    const bool staged = KS_STAGE_OUT && !partial;
+    const bool staged = KS_STAGE_OUT && !partial && (p.Ng & 3) == 0;      // (16-byte row segments: heads with 21 / 20 output channels store element by element)
     float* const ot = reinterpret_cast<float*>(smem_raw);
     if (staged) __syncthreads();           // every wave has read its last fragments
 #pragma unroll
@@ -734,16 +736,27 @@ __global__ __launch_bounds__(256) void ks_reduce_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(y + i) = o;
 }
 
+// the same, element by element (Ng % 4 != 0: heads with 21 / 20 output channels)
+__global__ __launch_bounds__(256) void ks_reduce1_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
+                                                          size_t n, int Ng, int splits, int act, float slope) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
+    y[i] = sscg_act(s + (bias ? bias[(int)(i % Ng)] : 0.f), act, slope);
+}
+
 #ifndef KS_STAGE_OUT
 #define KS_STAGE_OUT 1
 #endif
 constexpr bool KS_STAGE_OUT_HOST = KS_STAGE_OUT != 0;      // the addend joins in the staged store phase
 
 // ---- host side: tile classes and the split-K plan of the tail (same policy as conv_igemm.hip)
-enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_128x64_K2 = 5, KS_NCFG = 6 };
-const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64, 128};
-const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128, 64};
-const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2, 4};     // wave rows of a tile = statistics records per tile row
+enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_128x64_K2 = 5, KS_128x32 = 6, KS_NCFG = 7 };
+const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64, 128, 128};
+const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128, 64, 32};
+const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2, 4, 4};  // wave rows of a tile = statistics records per tile row
 // The two-wave-group form of the 128x64 tile is built and tested but OFF by default: alone it hides the exposed waits of a launch
 // with one workgroup per CU, but in the four-lane step it costs +4 ms (135.2 against 131.1 ms, interleaved A/B on one box, round 5):
 // 112 KB of LDS and 2 x 208 registers per SIMD leave no room for the other lanes' workgroups on that CU, and those - not idle issue
@@ -773,6 +786,7 @@ int ks_choose(long M, int Ng, int Ktot, int tuning) {
     const int forced = (tuning & 0xff) - 1;
     if (forced >= 0 && forced < KS_NCFG && Ng >= KS_BN[forced] / 2) return forced;
     const long tm = cdiv(M, 128);
+    if (Ng <= 32) return KS_128x32;       // heads: 21 / 20 output channels (the ResNet generators' 7x7 heads, the DeepLab classifiers)
     if (Ng <= 64) return tm >= 384 ? KS_128x64 : KS_64x64;          // (>= 384 tiles: never the two-group form)
     const long t128 = tm * cdiv(Ng, 128);
     if (Ng <= 128) return (t128 >= T128_SHORT && Ktot >= K128) ? KS_128x128 : KS_64x64;
@@ -854,8 +868,11 @@ int launch_ks(const KsParams& p0, hipStream_t st) {
         float* yt = p.dst + (size_t)p.m_tail0 * p.Ng;
         if (p.xstats)
             return launch_split_reduce_stats(p.part, p.bias, yt, 0, p.M - p.m_tail0, p.Ng, p.splits, p.act, p.slope, p.xstats, st);
-        hipLaunchKernelGGL(ks_reduce_kernel, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st, p.part, p.bias, yt, n, p.Ng, p.splits, p.act,
-                           p.slope, p.addend ? p.addend + (size_t)p.m_tail0 * p.Ng : nullptr);
+        if (p.Ng & 3)
+            hipLaunchKernelGGL(ks_reduce1_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, p.part, p.bias, yt, n, p.Ng, p.splits, p.act, p.slope);
+        else
+            hipLaunchKernelGGL(ks_reduce_kernel, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st, p.part, p.bias, yt, n, p.Ng, p.splits, p.act,
+                               p.slope, p.addend ? p.addend + (size_t)p.m_tail0 * p.Ng : nullptr);
         SSCG_LAUNCH_CHECK();
     }
     return SSCG_OK;
@@ -870,6 +887,7 @@ int dispatch_ks(const KsParams& p, int tuning, hipStream_t st) {
         case KS_128x64: return launch_ks<MODE, 4, 1, 1, 2>(p, st);
         case KS_64x128: return launch_ks<MODE, 2, 2, 1, 2>(p, st);
         case KS_128x64_K2: return launch_ks<MODE, 4, 1, 1, 2, 2>(p, st);  // two groups of 4 waves of 32x64, half the reduction each
+        case KS_128x32: return launch_ks<MODE, 4, 1, 1, 1>(p, st);        // 4 waves of 32x32: few-channel heads
         default: return SSCG_ERR_BAD_ARG;
     }
 }
@@ -935,8 +953,9 @@ static bool ks_extents_ok(const sscg_conv_desc* d, bool dgrad) {
 }
 
 bool sscg_convs_fwd_applies(const sscg_conv_desc* d) {
+    // (>= 16 output channels: the 128x32 class serves the 21 / 20-channel heads; 1- and 3-channel heads keep conv_igemm.hip's 4-column MFMA)
     return d->x_dtype == SSCG_F32 && d->w_dtype == SSCG_BF16X3 && d->y_dtype == SSCG_F32 && d->C % BKS == 0 && d->C <= 4096 &&
-           d->K >= 32 && d->K % 4 == 0 && ks_extents_ok(d, false);
+           d->K >= 16 && ks_extents_ok(d, false);
 }
 
 bool sscg_convs_dgrad_applies(const sscg_conv_desc* d) {
