@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 13
+#define SSCG_ABI_VERSION 14
 
 /* element types of activation / weight tensors */
 #define SSCG_F32 0
@@ -220,6 +220,11 @@ int sscg_act_fwd(const void* x, void* y, int dtype, int64_t n, int act, float sl
 int sscg_act_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n, int act, float slope, void* stream);
 /* y = a + b */
 int sscg_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
+/* dst[r][c] = (c < Cs) ? src[r][c] : 0 for c < Cd, r < rows (fp32): an NHWC tensor (or a [K][R][S][C] weight) with its channels
+ * padded with zeros (Cd > Cs) or cut (Cd < Cs).  No reference counterpart: the 21-channel stems (arch/generators.py:73,373 on a
+ * one-hot / softmax map) run as 32-channel convolutions on the split contraction - a zero channel meets a zero weight - and the data
+ * gradient's extra channels are cut again. */
+int sscg_resize_channels(const float* src, float* dst, int64_t rows, int Cs, int Cd, void* stream);
 /* nn.Dropout(0.5) in training mode (arch/ops.py:66): y = x * keep / (1-p); keep is derived from a
  * counter-based hash of (seed, element index), so backward can regenerate it. */
 int sscg_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, void* stream);

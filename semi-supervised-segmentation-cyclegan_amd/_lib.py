@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 F32, BF16, BF16X3 = 0, 1, 2     # SSCG_F32 / SSCG_BF16 / SSCG_BF16X3 (split weight operand)
 
@@ -42,6 +42,7 @@ _dp = C.POINTER(ConvDesc)
 SIGNATURES = {
     "sscg_abi_version": (_i, []),
     "sscg_set_dry_run": (_i, [_i]),
+    "sscg_resize_channels": (_i, [_p, _p, _i64, _i, _i, _p]),
     "sscg_conv2d_fwd_workspace": (_sz, [_dp]),
     "sscg_conv2d_fwd": (_i, [_dp, _p, _p, _p, _p, _p, _sz, _p]),
     "sscg_conv2d_fwd_stats_bytes": (_sz, [_dp, _i, _i64]),

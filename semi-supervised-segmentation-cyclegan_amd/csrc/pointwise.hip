@@ -402,6 +402,33 @@ extern "C" int sscg_cast(const void* src, int src_dtype, void* dst, int dst_dtyp
     return SSCG_OK;
 }
 
+// dst[r][c] = c < Cs ? src[r][c] : 0 for c < Cd: channel padding (Cd > Cs) or channel slicing (Cd < Cs) of an NHWC tensor
+__global__ __launch_bounds__(256) void resize_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int Cs, int Cd) {
+    const int gd = (Cd + 3) >> 2;                       // 4-channel groups of a destination row
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * gd) return;
+    const size_t r = i / gd;
+    const int c0 = (int)(i - r * gd) * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (c0 + e < Cs && c0 + e < Cd) ? src[r * Cs + c0 + e] : 0.f;
+    if ((Cd & 3) == 0) {
+        *reinterpret_cast<f32x4*>(dst + r * Cd + c0) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < Cd) dst[r * Cd + c0 + e] = v[e];
+    }
+}
+
+extern "C" int sscg_resize_channels(const float* src, float* dst, int64_t rows, int Cs, int Cd, void* stream) {
+    if (!src || !dst || rows <= 0 || Cs <= 0 || Cd <= 0) return SSCG_ERR_BAD_ARG;
+    const size_t n = (size_t)rows * ((Cd + 3) >> 2);
+    hipLaunchKernelGGL(resize_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, (size_t)rows, Cs, Cd);
+    SSCG_LAUNCH_CHECK();
+    return SSCG_OK;
+}
+
 extern "C" int sscg_fill(float* x, int64_t n, float v, void* stream) {
     if (!x || n <= 0) return SSCG_ERR_BAD_ARG;
     hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, v);

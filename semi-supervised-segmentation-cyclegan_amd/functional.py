@@ -586,6 +586,14 @@ class ConvProfile:
         return out
 
 
+def _unprofiled(fn):
+    prof, ConvProfile.active = ConvProfile.active, None
+    try:
+        return fn()
+    finally:
+        ConvProfile.active = prof
+
+
 def _timed(kind, d, fn):
     prof = ConvProfile.active
     if prof is None:
@@ -630,9 +638,49 @@ def _out_dtype(out_f32):
     return torch.bfloat16 if (_MODE[0] == "bf16" and not out_f32) else torch.float32
 
 
+PAD_STEMS = [os.environ.get("SSCG_PAD_STEMS", "1") != "0"]
+
+
+def resize_channels(x, c_new):
+    """[N, C, H, W] (channels-last) or a [K, C, R, S] weight -> the same with c_new channels: zero-padded or cut (fp32)."""
+    x = x if x.is_contiguous(memory_format=CL) else x.contiguous(memory_format=CL)
+    n, c, h, w = x.shape
+    y = torch.empty((n, c_new, h, w), dtype=torch.float32, device=x.device).contiguous(memory_format=CL)
+    check(lib.sscg_resize_channels(x.data_ptr(), y.data_ptr(), n * h * w, c, c_new, _stream()), "sscg_resize_channels")
+    return y
+
+
+def _padded_stem(xshape, wshape, stride, pad, dil, pad_mode, kind):
+    """Split mode: a convolution over 17-31 source channels (the 21 / 20-channel stems on one-hot / softmax maps: arch/generators.py:73,
+    373) runs as a 32-channel convolution on the split contraction - the extra channels are zero in the activation AND in the weight
+    copy - instead of the exact-fp32 kernel's ragged-channel path (57 TFLOP/s): returns 32 when the padded geometry is served."""
+    c = xshape[1]
+    if not (PAD_STEMS[0] and _MODE[0] == "f32s" and 16 < c < 32 and wshape[0] >= 16):
+        return 0
+    kname = "fwd" if kind == 0 else "dgrad"
+    if kname not in SPLIT_KINDS:
+        return 0
+    xs = (xshape[0], 32, xshape[2], xshape[3])
+    ws = (wshape[0], 32, wshape[2], wshape[3])
+    return 32 if split_applies(xs, ws, stride, pad, dil, pad_mode if kind == 0 else PAD_ZEROS, kind) else 0
+
+
+def _padded_weight(w, c_new):
+    """The weight with zero-padded source channels, cached on the weight (rebuilt when the optimiser rewrites it); its own operand
+    copies (split planes, transposed split planes) are cached on the padded tensor and die with it."""
+    return _cached_copy(w, "_sscg_wpad", lambda: resize_channels(w.detach(), c_new))
+
+
 def conv2d_fwd(x, w, bias, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0, out_f32=True, stats=None):
     """y = act(conv(x, w) + bias).  out_f32: keep the output fp32 in bf16 mode (network heads).
     stats = (G, L): also return the epilogue's column statistics buffer (None when the fusion does not apply)."""
+    if x.dtype == torch.float32:
+        cp = _padded_stem(x.shape, w.shape, stride, pad, dil, pad_mode, 0)
+        if cp:
+            # (the profile books this launch - padding pass included - under the ORIGINAL geometry: algorithmic FLOP of the 21-channel conv)
+            d0 = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, act, slope, F32, BF16X3, F32, _prec(), 0)
+            return _timed("fwd", d0, lambda: _unprofiled(lambda: conv2d_fwd(resize_channels(x, cp), _padded_weight(w, cp), bias, stride, pad, dil,
+                                                                             pad_mode, act, slope, out_f32, stats)))
     wop, wdt, wplane = _fwd_operands(x, w, (stride, pad, dil, pad_mode))
     ydt = _out_dtype(out_f32)
     d = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, act, slope, _dt(x), wdt, _DT[ydt], _prec(), wplane)
@@ -755,6 +803,14 @@ def conv2d_dgrad_param(dy, w, xshape, wshape, stride, pad, dil, bias=None, act=A
                        addend=None, z=None):
     """conv2d_dgrad with the transposed operand copy of parameter `w` taken from the per-parameter cache, in the element
     type the kernel for dy reads (bf16 tiles for a bf16 dy, fp32 otherwise)."""
+    if dy.dtype == torch.float32 and out_dtype == torch.float32 and bias is None and act == ACT_NONE and bsums is None and addend is None:
+        cp = _padded_stem(xshape, wshape, stride, pad, dil, PAD_ZEROS, 1)
+        if cp:      # the padded weight's data gradient has 32 channels: the extra ones (zero weights: zero gradient) are cut again
+            wp = _padded_weight(w, cp)
+            xs = (xshape[0], cp, xshape[2], xshape[3])
+            d0 = make_desc(xshape, wshape, stride, pad, dil, xdt=F32, wdt=BF16X3, ydt=F32, prec=_prec("dgrad"))
+            return _timed("dgrad", d0, lambda: _unprofiled(lambda: resize_channels(
+                conv2d_dgrad(dy, _cached_wt(wp, "x3"), xs, tuple(wp.shape), stride, pad, dil), xshape[1])))
     if dy.dtype == torch.bfloat16:
         if wshape[0] % 64:
             raise _lib.SscgError("bf16 output gradients with %d channels: the bf16 conv kernels need a multiple of 64" % wshape[0])

@@ -1271,3 +1271,45 @@ def test_split_conv_every_tile_class(case, cls, F, dev):
         v64 = yr.detach().var((0, 2, 3), unbiased=False)
         assert float(((mean[0].double().cpu() - m64) / v64.sqrt()).abs().max()) < 2e-6
         assert float((rstd[0].double().cpu() * (v64 + 1e-5).sqrt() - 1).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("case", [(2, 21, 64, 64, 64, 7, 2, 3, 0), (2, 21, 32, 32, 64, 7, 1, 3, 1), (3, 20, 17, 23, 48, 3, 1, 1, 0)],
+                         ids=["deeplab_conv1_onehot", "resnet_stem_reflect", "ragged_20"])
+def test_21_channel_stems_run_zero_padded_on_the_split_contraction(case, F, dev):
+    """arch/generators.py:73,373 on a 21-channel one-hot / softmax map: in the split mode the convolution runs over 32 source channels
+    (zero channels against zero weights: sscg_resize_channels) on the bf16 matrix cores instead of the exact kernel's ragged path;
+    the data gradient's extra channels are cut again.  Forward (with the fused normalisation statistics), data gradient and the
+    unchanged exact weight gradient against torch fp64; the padded weight copy follows an in-place update of the weight."""
+    n, c, h, w, k, r, s, p, reflect = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, c, h, w, generator=g, dtype=torch.float64)
+    wt = torch.randn(k, c, r, r, generator=g, dtype=torch.float64) * (1.0 / (c * r * r) ** 0.5)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = ref_conv(xr, wr, None, s, p, 1, reflect, 0)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    dxr, dwr = torch.autograd.grad(yr, (xr, wr), gy)
+    calls = []
+    real = F.resize_channels
+    F.resize_channels = lambda t, cn: (calls.append((t.shape[1], cn)), real(t, cn))[1]
+    F.set_conv_precision("f32s")
+    try:
+        xg, wg = gpu(x, dev), gpu(wt, dev)
+        L = n * yr.shape[2] * yr.shape[3]
+        yg, cs = F.conv2d_fwd(xg, wg, None, s, p, 1, F.PAD_REFLECT if reflect else F.PAD_ZEROS, stats=(1, L))
+        assert (c, 32) in calls, calls                           # activation and weight were padded
+        assert rel_err(yg, yr) < 2e-6
+        if cs is not None:
+            mean, rstd = F.norm_stats_from_conv(cs, (1, L, k), 1e-5)
+            assert float(((mean[0].double().cpu() - yr.detach().mean((0, 2, 3))) / yr.detach().var((0, 2, 3), unbiased=False).sqrt()).abs().max()) < 2e-6
+        if not reflect:
+            dx = F.conv2d_dgrad_param(gpu(gy, dev), wg, x.shape, wt.shape, s, p, 1)
+            assert (32, c) in calls, calls                       # the 32-channel gradient was cut back
+            assert tuple(dx.shape) == tuple(x.shape) and rel_err(dx, dxr) < 2e-6
+        dw = F.conv2d_wgrad(xg, gpu(gy, dev), wt.shape, s, p, 1, F.PAD_REFLECT if reflect else F.PAD_ZEROS)
+        assert rel_err(dw, dwr) < 5e-6
+        wg.mul_(2.0)                                             # torch rewrites the weight: the cached padded copy must follow
+        y2 = F.conv2d_fwd(xg, wg, None, s, p, 1, F.PAD_REFLECT if reflect else F.PAD_ZEROS)
+        assert rel_err(y2, 2.0 * yr) < 2e-6
+    finally:
+        F.resize_channels = real
+        F.set_conv_precision("f32")
