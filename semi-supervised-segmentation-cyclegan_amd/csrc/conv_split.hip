@@ -954,8 +954,9 @@ static bool ks_extents_ok(const sscg_conv_desc* d, bool dgrad) {
 
 bool sscg_convs_fwd_applies(const sscg_conv_desc* d) {
     // (>= 16 output channels: the 128x32 class serves the 21 / 20-channel heads; 1- and 3-channel heads keep conv_igemm.hip's 4-column MFMA)
+    static const bool heads = getenv("SSCG_KS_NO_HEADS") == nullptr;       // A/B aid: heads back on the exact kernel
     return d->x_dtype == SSCG_F32 && d->w_dtype == SSCG_BF16X3 && d->y_dtype == SSCG_F32 && d->C % BKS == 0 && d->C <= 4096 &&
-           d->K >= 16 && ks_extents_ok(d, false);
+           (heads ? d->K >= 16 : (d->K >= 32 && d->K % 4 == 0)) && ks_extents_ok(d, false);
 }
 
 bool sscg_convs_dgrad_applies(const sscg_conv_desc* d) {
