@@ -38,6 +38,9 @@ namespace {
 #ifndef KS_ACC2
 #define KS_ACC2 1          // leading piece product and the five small ones in separate accumulators (wave tiles <= 32 x 64)
 #endif
+#ifndef KS_LATE_WAIT
+#define KS_LATE_WAIT 0
+#endif
 #ifndef KS_LB4
 #define KS_LB4 1           // 64x64 class: hold the kernel to 128 registers (4 workgroups per CU, what its 40 KB of LDS allow) - two accumulator sets take it to 134
 #endif
@@ -416,26 +419,30 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     };
     constexpr int NM = TM * TN;                 // MFMAs per piece product
     constexpr int NV = TM * 44;                 // VALU operations of one split_set
-    constexpr int VPM = (NV + 5 * NM - 1) / (5 * NM);
+    // products issued BEFORE the wait for the next half-tile's fragments (KS_LATE_WAIT: two where a product is at least two MFMAs -
+    // the fragment reads were requested just ahead of this half-tile, one product of 64 cycles does not cover their latency)
+    constexpr int NPRE = (KS_LATE_WAIT && NM >= 2) ? 2 : 1;
+    constexpr int VPM = (NV + (6 - NPRE) * NM - 1) / ((6 - NPRE) * NM);
     // the six piece products of half-tile `set` (smallest terms first); with `prep`, the fragments of the next half-tile - already
-    // requested - are waited for after the first product and split between the MFMAs of the other five
+    // requested - are waited for after the first NPRE products and split between the MFMAs of the others
     auto half_tile = [&](int set, bool prep) {
         __builtin_amdgcn_sched_barrier(0);
         product(set, 2, 0);
+        if (NPRE == 2) product(set, 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (prep) {
             wait_lgkm<0>();
             landed(set ^ 1);
             split_set(set ^ 1);
         }
-        product(set, 1, 1);
+        if (NPRE == 1) product(set, 1, 1);
         product(set, 0, 2);
         product(set, 1, 0);
         product(set, 0, 1);
         product(set, 0, 0);
         if (prep) {
 #pragma unroll
-            for (int n = 0; n < 5 * NM; ++n) {
+            for (int n = 0; n < (6 - NPRE) * NM; ++n) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);      // VPM VALU
             }

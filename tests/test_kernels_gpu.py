@@ -1259,6 +1259,8 @@ def test_split_conv_every_tile_class(case, cls, F, dev):
         yg, cs = F.conv2d_fwd(xg, wg, None, s, p, d, stats=(1, L))
         if cs is not None:
             mean, rstd = F.norm_stats_from_conv(cs, (1, L, k), 1e-5)
+        if k < 32:              # (a head's data gradient stays on the exact kernel family, whose tile classes this code does not name)
+            F.TUNING[0] = 0
         dx = F.conv2d_dgrad(gpu(gy, dev), F.dgrad_operand(wg, x.shape, s, p, d), x.shape, wt.shape, s, p, d)
     finally:
         F.TUNING[0], F.WGRAD_TUNING[0] = old

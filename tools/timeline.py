@@ -37,6 +37,17 @@ def main():
             bins[b][1] += g
         print("  stream %-4s %5d | %6.1f | %s" % (sid, len(ks) // steps, busy / steps / 1e6,
                                                  "  ".join("%d / %.1f" % (c // steps, t / steps / 1e6) for c, t in bins)))
+    # what the generator's optimiser launch waits for: per stream, when its last kernel before each adam launch of the window ended
+    adam_rows = [r for r in rows if "adam_kernel" in r[3]]
+    big = [r for r in adam_rows if (r[1] - r[0]) > 100000]          # the generator arena's launch (85.7 M elements: hundreds of us)
+    for a in big[:steps]:
+        t0 = a[0]
+        tails = {}
+        for sid, ks in per.items():
+            prev = [k for k in ks if k[1] <= t0]
+            if prev:
+                tails[sid] = (t0 - prev[-1][1], short(prev[-1][2]))
+        print("before the generator update at +%.1f ms: " % ((t0 - lo) / 1e6) + "; ".join("stream %s idle for %.0f us (last: %s)" % (sid, g / 1e3, n[:28]) for sid, (g, n) in sorted(tails.items())))
     # concurrency histogram by sweeping events
     ev = []
     for i, (s, e, sid, n) in enumerate(rows):
