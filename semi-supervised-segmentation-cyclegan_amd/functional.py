@@ -665,6 +665,24 @@ def _padded_stem(xshape, wshape, stride, pad, dil, pad_mode, kind):
     return 32 if split_applies(xs, ws, stride, pad, dil, pad_mode if kind == 0 else PAD_ZEROS, kind) else 0
 
 
+def _padded_head(xshape, wshape, stride, pad, dil):
+    """Split mode: the data gradient of a convolution with 17-31 OUTPUT channels (the reduction runs over taps x output channels: 21
+    is no multiple of the 32-wide k-tile) runs with dy and the filters padded to 32 output channels: returns 32 when served."""
+    k = wshape[0]
+    if not (PAD_STEMS[0] and _MODE[0] == "f32s" and 16 < k < 32 and "dgrad" in SPLIT_KINDS):
+        return 0
+    return 32 if split_applies(xshape, (32,) + tuple(wshape[1:]), stride, pad, dil, PAD_ZEROS, 1) else 0
+
+
+def _pad_filters(w, k_new):
+    """[K, C, R, S] -> [k_new, C, R, S] with zero filters appended (a device copy of the K * R * S * C leading elements)."""
+    w = w if w.is_contiguous(memory_format=CL) else w.contiguous(memory_format=CL)
+    wp = torch.empty((k_new,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device).contiguous(memory_format=CL)
+    fill_(wp, 0.0)
+    wp[:w.shape[0]].copy_(w)
+    return wp
+
+
 def _padded_weight(w, c_new):
     """The weight with zero-padded source channels, cached on the weight (rebuilt when the optimiser rewrites it); its own operand
     copies (split planes, transposed split planes) are cached on the padded tensor and die with it."""
@@ -803,14 +821,20 @@ def conv2d_dgrad_param(dy, w, xshape, wshape, stride, pad, dil, bias=None, act=A
                        addend=None, z=None):
     """conv2d_dgrad with the transposed operand copy of parameter `w` taken from the per-parameter cache, in the element
     type the kernel for dy reads (bf16 tiles for a bf16 dy, fp32 otherwise)."""
-    if dy.dtype == torch.float32 and out_dtype == torch.float32 and bias is None and act == ACT_NONE and bsums is None and addend is None:
-        cp = _padded_stem(xshape, wshape, stride, pad, dil, PAD_ZEROS, 1)
+    if dy.dtype == torch.float32 and out_dtype == torch.float32 and bias is None and act == ACT_NONE:
+        cp = _padded_stem(xshape, wshape, stride, pad, dil, PAD_ZEROS, 1) if (bsums is None and addend is None) else 0
         if cp:      # the padded weight's data gradient has 32 channels: the extra ones (zero weights: zero gradient) are cut again
             wp = _padded_weight(w, cp)
             xs = (xshape[0], cp, xshape[2], xshape[3])
             d0 = make_desc(xshape, wshape, stride, pad, dil, xdt=F32, wdt=BF16X3, ydt=F32, prec=_prec("dgrad"))
             return _timed("dgrad", d0, lambda: _unprofiled(lambda: resize_channels(
                 conv2d_dgrad(dy, _cached_wt(wp, "x3"), xs, tuple(wp.shape), stride, pad, dil), xshape[1])))
+        kp = _padded_head(xshape, wshape, stride, pad, dil)
+        if kp:      # a 21 / 20-channel head (the DeepLab classifiers): dy and the filters padded to 32 OUTPUT channels - zero gradients
+            wp = _cached_copy(w, "_sscg_wpadk", lambda: _pad_filters(w.detach(), kp))       # against zero filters add nothing to dx; the
+            d0 = make_desc(xshape, wshape, stride, pad, dil, xdt=F32, wdt=BF16X3, ydt=F32, prec=_prec("dgrad"))      # result has dx's own shape:
+            return _timed("dgrad", d0, lambda: _unprofiled(lambda: conv2d_dgrad(      # the fused store phases (fan-in, backward sums) apply
+                resize_channels(dy, kp), _cached_wt(wp, "x3"), xshape, tuple(wp.shape), stride, pad, dil, bsums=bsums, addend=addend, z=z)))
     if dy.dtype == torch.bfloat16:
         if wshape[0] % 64:
             raise _lib.SscgError("bf16 output gradients with %d channels: the bf16 conv kernels need a multiple of 64" % wshape[0])

@@ -1315,3 +1315,34 @@ def test_21_channel_stems_run_zero_padded_on_the_split_contraction(case, F, dev)
     finally:
         F.resize_channels = real
         F.set_conv_precision("f32")
+
+
+@pytest.mark.parametrize("with_addend", [False, True], ids=["plain", "fan_in_joined"])
+def test_21_channel_head_data_gradient_runs_zero_padded_on_the_split_contraction(with_addend, F, dev):
+    """The DeepLab classifier (arch/generators.py:373,388: 2048 -> 21, dilation 6 / 12; both classifiers read one tensor, so the
+    second data gradient also joins the first's result): dy and the filters padded to 32 output channels, on the split contraction,
+    against torch fp64."""
+    n, c, h, w, k, r, p, d = 2, 2048, 9, 9, 21, 3, 6, 6
+    g = torch.Generator().manual_seed(77 + with_addend)
+    wt = torch.randn(k, c, r, r, generator=g, dtype=torch.float64) * (1.0 / (c * r * r) ** 0.5)
+    xr = torch.randn(n, c, h, w, generator=g, dtype=torch.float64).requires_grad_(True)
+    yr = TF.conv2d(xr, wt, None, 1, p, d)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    dxr = torch.autograd.grad(yr, xr, gy)[0]
+    add = torch.randn(n, c, h, w, generator=g, dtype=torch.float64) if with_addend else None
+    calls = []
+    real = F.resize_channels
+    F.resize_channels = lambda t, cn: (calls.append((t.shape[1], cn)), real(t, cn))[1]
+    F.set_conv_precision("f32s")
+    try:
+        out = F.conv2d_dgrad_param(gpu(gy, dev), gpu(wt, dev), (n, c, h, w), wt.shape, 1, p, d, addend=gpu(add, dev) if with_addend else None)
+    finally:
+        F.resize_channels = real
+        F.set_conv_precision("f32")
+    assert calls == [(21, 32)], calls
+    if with_addend:
+        dx, rec, joined = out
+        assert joined and rec is None
+        assert rel_err(dx, dxr + add) < 2e-6
+    else:
+        assert rel_err(out, dxr) < 2e-6
