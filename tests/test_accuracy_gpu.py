@@ -40,9 +40,9 @@ def _first_step(m, tag, cfg, dev):
 
 
 def test_split_mode_is_as_close_to_fp64_as_exact_fp32_at_step_level(dev):
-    """Measured (profiles/r04_accuracy.txt): pooled over 3 chained losses x 6 seeds, error / the reference's own worst error on that
-    loss: exact fp32 MFMA rms 0.65 (max 1.42), split rms 0.72 (max 1.93), the reference's fp32 arithmetic rms 0.58 (max 1.00);
-    gt_cycle_loss reaches 5.3e-3 (exact), 7.1e-3 (split), 3.7e-3 (reference) on seed ch3 - which is why CHAINED_LOSS_FLOOR exists."""
+    """Measured (profiles/r05_accuracy.txt): pooled over 3 chained losses x 6 seeds, error / the reference's own worst error on that
+    loss: exact fp32 MFMA rms 0.65 (max 1.42), split rms 0.27 (max 0.50; round 4, one accumulator chain per reduction: 0.72 / 1.93),
+    the reference's fp32 arithmetic rms 0.58 (max 1.00); gt_cycle_loss reaches 5.3e-3 (exact), 1.4e-3 (split), 3.7e-3 (reference)."""
     F = load_sub("functional")
     md = load_sub("model")
     G = json.load(open(os.path.join(GOLD, "g7_first_steps.json")))
@@ -84,8 +84,11 @@ def test_split_mode_is_as_close_to_fp64_as_exact_fp32_at_step_level(dev):
     assert float(np.median(pooled["f32s"])) <= 2.0 * float(np.median(pooled["f32x"])), pooled
     assert float(pooled["f32s"].max()) <= 2.0 * float(pooled["f32x"].max()), pooled
     assert rms["f32s"] <= 1.5 * rms["ref"] and rms["f32x"] <= 1.5 * rms["ref"], rms
-    for k in CHAINED:       # per loss: no draw beyond 2.5 x the worst the reference shows on that loss
-        assert max(err["f32s"][k]) <= 2.5 * scale[k] and max(err["f32x"][k]) <= 2.5 * scale[k], (k, err["f32s"][k], err["f32x"][k], scale[k])
+    for k in CHAINED:       # per loss: the product's arithmetic (split) no further from fp64 than the reference's own worst draw on that
+        # loss (measured round 5: at most 0.50 of it); the exact-fp32-MFMA mode (one rounding chain per reduction) within 2.5 x
+        assert max(err["f32s"][k]) <= FX.chained_loss_bound(k), (k, err["f32s"][k], scale[k])
+        assert max(err["f32x"][k]) <= 2.5 * scale[k], (k, err["f32x"][k], scale[k])
+    assert rms["f32s"] <= rms["ref"], rms       # (0.27 against 0.58: two accumulator sets per wave tile, conv_split.hip KS_ACC2)
     # (no assertion that the build misses 1e-3 on these: a better summation order must not fail the suite.  The same three losses are
     # held to 1e-3 where that is attainable - teacher-forced, tests/test_teacher_forced_gpu.py.)
     print("worst chained draw: exact fp32 %.2e, split %.2e, the reference's fp32 %.2e" % tuple(max(max(err[mo][k]) for k in CHAINED) for mo in ("f32x", "f32s", "ref")))
@@ -116,4 +119,5 @@ def test_deeplab_forward_split_vs_exact_vs_fp64(name, dev):
     e["ref"] = rel_l2(g2[name + "/y/f32"], g2[name + "/y/f64"])
     print("%s forward rel-L2 vs fp64: reference fp32 %.2e, exact-fp32 MFMA %.2e, split %.2e" % (name, e["ref"], e["f32x"], e["f32s"]))
     assert e["f32s"] <= 1.25 * e["f32x"] + 2e-7
-    assert e["f32s"] <= 2.0 * e["ref"] + 2e-7          # (measured: 21 -> 3 classes 6.3e-4 split, 6.5e-4 exact, 4.4e-4 the reference's fp32 on the CPU)
+    assert e["f32s"] <= 1.1 * e["ref"] + 2e-7          # (measured round 5: 2.1e-4 / 2.1e-4 split against 2.7e-4 / 4.4e-4 for the reference's fp32 on the CPU;
+                                                       #  round 4, before the two accumulator sets and the padded 21-channel stem: 3.2e-4 / 6.0e-4)

@@ -235,7 +235,7 @@ def test_variant_step_vs_oracle_golden(dev):
             # a NEW seed for the chained losses: its bound comes from the six-seed evidence of tests/test_accuracy_gpu.py, not from a
             # fixed floor - no draw beyond 2.5 x the worst distance to fp64 the REFERENCE's arithmetic shows on this loss over those
             # seeds (gt_cycle_loss: 3.7e-3; the build's two arithmetics reach 5.3e-3 / 7.1e-3 there), or 4 x this seed's own noise
-            assert e < max(4 * noise, 2.5 * scale[k]), (k, e, noise, scale[k])
+            assert e < FX.chained_loss_bound(k), (k, e, noise, scale[k])
             continue
         if k == "img_cycle_l1":
             # taken on recon_img = Gis(Gsi(unl_img)) itself: two DeepLab passes deep with nothing smoothing it - the class of
