@@ -188,14 +188,14 @@ class SemiSupOracle:
 
 
     # ------------------------------------------------------------------ teacher-forced second pass
-    def first_pass(self, l_img, l_gt, unl_img):
+    def first_pass(self, l_img, l_gt, unl_img, want_lab=True):
         """The first-pass outputs the second pass consumes (model.py:385-387,390-392,401-402), without a graph:
         fake_img = interp(Gis(onehot(l_gt))), fake_gt = softmax(interp(Gsi(unl_img))), lab_gt = softmax(interp(Gsi(l_img)))."""
         C, sd, q = self.C, self.sd, self.q
         with torch.no_grad():
             fake_img = self.interp(nets.deeplab(sd["Gis"], one_hot(l_gt, C, l_img.dtype), True, q=q))     # :385,390
             fake_gt = torch.softmax(self.interp(nets.deeplab(sd["Gsi"], unl_img, True, q=q)), 1)           # :386,391,402
-            lab_gt = torch.softmax(self.interp(nets.deeplab(sd["Gsi"], l_img, True, q=q)), 1)              # :387,392,401
+            lab_gt = torch.softmax(self.interp(nets.deeplab(sd["Gsi"], l_img, True, q=q)), 1) if want_lab else None   # :387,392,401
         return fake_img, fake_gt, lab_gt
 
     def second_pass(self, fake_img, fake_gt, l_gt, unl_img):

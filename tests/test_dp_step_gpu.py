@@ -98,26 +98,37 @@ class _Deferred:
         self.real()
 
 
-@pytest.mark.parametrize("buckets", [0, 4], ids=["one_piece", "four_buckets_overlapping_the_backward"])
-def test_dp_step_world_size_2_shared_gpu(buckets, dev, tmp_path):
-    """buckets = 4: SSCG_DP_BUCKETS - the generator arena goes out in four all-reduces, each as soon as the backward has queued the
-    last gradient kernel of its parameters (parallel.GradBuckets); gloo reads the bucket on the host, so an all-reduce issued before
-    a gradient kernel it depends on would change the bits below."""
+def test_dp_step_world_size_2_shared_gpu(dev, tmp_path):
+    """Two exchanges of the generator arena, each by its own pair of ranks (the four processes run side by side): in one piece after
+    the backward (the default), and with SSCG_DP_BUCKETS=4 - four all-reduces, each as soon as the backward has queued the last
+    gradient kernel of its parameters (parallel.GradBuckets); gloo reads a bucket on the host, so an all-reduce issued before a
+    gradient kernel it depends on would change the bits below.  Both must reproduce ONE lockstep simulation bit for bit."""
     ctx = mp.get_context("spawn")
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), buckets)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(900)
-        assert p.exitcode == 0, "rank process failed (exit code %s)" % p.exitcode
-    r0 = torch.load(str(tmp_path / "rank0.pt"))
-    r1 = torch.load(str(tmp_path / "rank1.pt"))
-    if buckets:
-        # every bucket went out, in one order on both ranks, and not all of them from finish() (which walks them last-to-first
-        # after the backward): at least the last bucket - the DeepLab stems and first layers - completes during the backward
-        assert r0["buckets"] == buckets and sorted(r0["bucket_order"]) == list(range(buckets)) and r0["bucket_order"] == r1["bucket_order"]
-        print("bucket launch order:", r0["bucket_order"])
+    runs = {}
+    for buckets in (0, 4):
+        out = tmp_path / ("b%d" % buckets)
+        out.mkdir()
+        port = _free_port()
+        runs[buckets] = (out, [ctx.Process(target=_worker, args=(r, 2, port, str(out), buckets)) for r in range(2)])
+        for p in runs[buckets][1]:
+            p.start()
+    for buckets, (out, procs) in runs.items():
+        for p in procs:
+            p.join(900)
+            assert p.exitcode == 0, "rank process failed (exit code %s, buckets %d)" % (p.exitcode, buckets)
+    res = {b: (torch.load(str(out / "rank0.pt")), torch.load(str(out / "rank1.pt"))) for b, (out, _) in runs.items()}
+    r0, r1 = res[4]
+    # every bucket went out, in one order on both ranks, and not all of them from finish() (which walks them last-to-first
+    # after the backward)
+    assert r0["buckets"] == 4 and sorted(r0["bucket_order"]) == list(range(4)) and r0["bucket_order"] == r1["bucket_order"]
+    assert r0["bucket_order"] != [3, 2, 1, 0], r0["bucket_order"]
+    print("bucket launch order:", r0["bucket_order"])
+    sim = None
+    for buckets, (r0, r1) in res.items():
+        sim = _check_against_lockstep(r0, r1, dev, sim)
+
+
+def _check_against_lockstep(r0, r1, dev, sim):
     # (1) broadcast from rank 0 at attach time
     for k in ("g", "d", "old"):
         assert torch.equal(r0["after_attach"][k], r1["after_attach"][k]), "attach(): rank 1 does not hold rank 0's %s weights" % k
@@ -125,7 +136,10 @@ def test_dp_step_world_size_2_shared_gpu(buckets, dev, tmp_path):
     assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["d"], r1["d"])
     assert not torch.equal(r0["bn_mean"], r1["bn_mean"])          # BatchNorm statistics stay per rank
     assert r0["losses"][0]["lab_loss_CE"] != r1["losses"][0]["lab_loss_CE"]
-    # (3) lockstep simulation in this process
+    # (3) lockstep simulation in this process (once: both exchanges must reproduce it)
+    if sim is not None:
+        _compare(sim, r0, r1)
+        return sim
     md = load_sub("model")
     from oracle import fixtures as FX
     reps = []
@@ -151,7 +165,13 @@ def test_dp_step_world_size_2_shared_gpu(buckets, dev, tmp_path):
         for _, g, d in reps:
             g.apply()
             d.apply()
-    sim = _state(reps[0][0])
+    sim = (_state(reps[0][0]), sim_losses)
+    _compare(sim, r0, r1)
+    return sim
+
+
+def _compare(sim, r0, r1):
+    sim, sim_losses = sim
     for k in ("g", "d", "bn_mean", "bn_var"):
         diff = float((sim[k].double() - r0[k].double()).abs().max() / r0[k].double().abs().max())
         print("lockstep vs DP rank 0, %s: max rel diff %.3e (bitwise %s)" % (k, diff, torch.equal(sim[k], r0[k])))
