@@ -96,6 +96,21 @@ struct KsParams {
     double* __restrict__ bn_sums;        // [G][bn_chunks][Ng][2]
     int bn_L, bn_G, bn_chunks, bn_act;
     float bn_slope;
+    // In-kernel tails (tickets != null; launches of at most KS_TAIL_TILES tile rows): the LAST partial workgroup of a tail tile sums the
+    // tile's partial results (fixed order) and finishes it as a whole tile - no reduce launch -, and the LAST tile of a column block
+    // turns the column's records into the layer's statistics (forward) / backward coefficients (data gradient) - no finalize launch.
+    // Everything a workgroup reads from another one (partial tiles, records) is written and read at agent scope (sc1: the XCDs' L2s
+    // are not coherent with each other inside a launch); the sums are taken in a fixed order, not in arrival order.
+    int* __restrict__ tickets;           // [tiles_n] column tickets, then one per tail tile; zero before the launch and after it
+    int tiles_m, fin_G;
+    float* __restrict__ fin_mean;        // forward: [G][Ng]
+    float* __restrict__ fin_rstd;
+    float* __restrict__ fin_rmean;       // [Ng] or null
+    float* __restrict__ fin_rvar;
+    float fin_eps, fin_momentum;
+    float* __restrict__ fin_coef;        // data gradient: [G][Ng][2]
+    float* __restrict__ fin_dgamma;      // [Ng] or null (written)
+    float* __restrict__ fin_dbeta;
     FastDiv div_tn, div_gl;              // by tiles_n; by stat_L / bn_L (whichever the launch uses)
     FastDiv div_hw, div_w;               // by OH * OW and by OW (launch_ks): a row's (image, y, x) without integer divisions (~30 VALU operations each)
 };
@@ -105,13 +120,30 @@ template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_w
 __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
+// ---- agent-scope accessors and the "last arrival" ticket of the in-kernel tails
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Every thread of the workgroup calls this after its agent-scope stores: true in ALL threads of the workgroup that arrives last of
+// `expected`.  (vmcnt(0): the write-through stores are acknowledged before the ticket is taken.)
+__device__ __forceinline__ bool last_arrival(int* ticket, int expected, int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return *flag == expected - 1;
+}
+constexpr int KS_TAIL_TILES = 160;       // tile rows a column's last workgroup walks (8712- and 17424-row maps: 69 / 137 tiles of 128 rows)
+
 // KG = 2: TWO wave groups of WM * WN waves share the tile and halve its reduction (k-tiles [0, n/2) and [n/2, n)), each with its own
 // LDS stages; the second group's accumulators join the first's through LDS before the epilogue.  For launches whose tile count
 // barely exceeds the CU count (8712-row maps x 256 output channels = 276 tiles of 128 x 64: ONE 4-wave workgroup per CU, one wave
 // per SIMD - every LDS wait, barrier and split sequence of that wave is exposed): two waves per SIMD without the partial tiles
 // and the reduce pass of a split-K over workgroups.
 template <int MODE, int WM, int WN, int TM, int TN, int KG = 1>
-__global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG == 1) ? 4 : 2)) void convs_kernel(KsParams p) {
+__global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG == 1) ? 4 : 2)) void convs_kernel(KsParams p) {      // (HIP: the second figure is WAVES PER SIMD)
     constexpr int NT = WM * WN * 64;          // threads of one wave group
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -527,12 +559,6 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     // Fused statistics of the normalisation layer that follows (conv_igemm.hip): fp64 column sums of y and y^2 over this tile's
     // rows, four rows at a time in fp32 where the tile lies inside one group and inside the tensor.
-    const bool want_stats = p.stats != nullptr && !partial;
-    const bool want_bsums = MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (never with split-K: the host plans these launches unsplit)
-    int gb = 0x7fffffff;
-    if (want_stats) gb = (fd_div(m0, p.div_gl) + 1) * p.stat_L;
-    int bg = 0;
-    if (want_bsums) { bg = fd_div(m0, p.div_gl); gb = (bg + 1) * p.bn_L; }
     // Tiles inside one group and inside the tensor (nearly all): four consecutive rows are summed in fp32, the 4-row sums in fp64 (as the
     // bf16 kernel does); tiles that straddle a group boundary or the tensor's end take every element to fp64.  Round 3 took EVERY
     // element to fp64 because the shortcut moves a BatchNorm statistic by ~1e-7 and the chained-loss bound then sat at 1e-3; round 4
@@ -541,8 +567,6 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
 #ifndef KS_FAST_STATS
 #define KS_FAST_STATS 1
 #endif
-    const bool slow_stats = want_stats && (!KS_FAST_STATS || m0 + BM > gb || m0 + BM > p.M);
-    const bool fast_stats = want_stats && !slow_stats;
     // Results leave through LDS (whole tiles; the k-loop's images are dead): in the MFMA layout a lane owns single elements of 16 rows -
     // 32 four-byte stores per lane of a 128x64 tile, each wave-instruction touching 2 x 128 bytes, ~2000 cycles of the store path
     // against 6000 cycles of MFMAs when the reduction is 256 long.  Staged as [row][BN + 4] floats, every thread then writes 16 bytes =
@@ -551,9 +575,60 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
 #define KS_STAGE_OUT 1
 #endif
     constexpr int OLD = BN + 4;
-    const bool staged = KS_STAGE_OUT && !partial && (p.Ng & 3) == 0;      // (16-byte row segments: heads with 21 / 20 output channels store element by element)
+    constexpr int SREC_OFF = BM * OLD * 4;     // in-kernel tails: the waves' statistics meet behind the staged tile, [WM][BN][4] doubles
+    __shared__ int s_flag;
+    const bool fold = KG == 1 && p.tickets != nullptr;
+    const bool want_bsums = MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (never with split-K: the host plans these launches unsplit)
     float* const ot = reinterpret_cast<float*>(smem_raw);
-    if (staged) __syncthreads();           // every wave has read its last fragments
+    if (partial && fold) {
+        // ---- tail tile, in-kernel: every partial workgroup leaves its accumulators in the workspace; the LAST of the tile's `splits`
+        // workgroups to arrive sums the partial tiles in split order (whoever is last: the same sum) back into its accumulators and
+        // goes on as the workgroup of a whole tile
+        const int n_l = n0 + col_w + li;
+        const int r_l = m0 + row_w + 4 * lh - p.m_tail0;
+        const unsigned off0 = (unsigned)r_l * (unsigned)p.Ng + (unsigned)n_l;       // (the workspace of a tail is a few MB: 32-bit offsets)
+        float* const mine = p.part + (size_t)split * (p.M - p.m_tail0) * p.Ng;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int dr = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (r_l + dr + p.m_tail0 < p.M && n_l + j * 32 < p.Ng) st_agent(mine + (off0 + (unsigned)dr * (unsigned)p.Ng + j * 32), acc[i][j][e]);
+                }
+        int* const tk = p.tickets + p.tiles_n + (tile - p.full_tiles);
+        if (!last_arrival(tk, p.splits, &s_flag)) return;
+        if (tid == 0) st_agent(tk, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int k = 0; k < p.splits; ++k) {
+            const float* const pk = p.part + (size_t)k * (p.M - p.m_tail0) * p.Ng;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int dr = i * 32 + (e & 3) + 8 * (e >> 2);
+                        if (r_l + dr + p.m_tail0 < p.M && n_l + j * 32 < p.Ng) acc[i][j][e] += ld_agent(pk + (off0 + (unsigned)dr * (unsigned)p.Ng + j * 32));
+                    }
+        }
+        partial = false;
+    }
+    const bool want_stats = p.stats != nullptr && !partial;
+    int gb = 0x7fffffff;
+    if (want_stats) gb = (fd_div(m0, p.div_gl) + 1) * p.stat_L;
+    int bg = 0;
+    if (want_bsums) { bg = fd_div(m0, p.div_gl); gb = (bg + 1) * p.bn_L; }
+    const bool slow_stats = want_stats && (!KS_FAST_STATS || m0 + BM > gb || m0 + BM > p.M);
+    const bool fast_stats = want_stats && !slow_stats;
+    const bool staged = KS_STAGE_OUT && !partial && (p.Ng & 3) == 0;      // (16-byte row segments: heads with 21 / 20 output channels store element by element)
+    if (staged || (fold && want_stats)) __syncthreads();           // every wave has read its last fragments
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + col_w + j * 32 + li;
@@ -610,11 +685,29 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
         if (want_stats) {
             s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);      // the lane halves hold different rows of a column
             s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-            if (lh == 0 && nok) {
+            if (fold) {
+                if (lh == 0) {
+                    double* sr = reinterpret_cast<double*>(smem_raw + SREC_OFF) + (size_t)(wm * BN + col_w + j * 32 + li) * 4;
+                    sr[0] = s0; sr[1] = q0; sr[2] = s1; sr[3] = q1;
+                }
+            } else if (lh == 0 && nok) {
                 double* rec = p.stats + ((size_t)(tile_m * WM + wm) * 2) * p.Ng * 2;
                 rec[(size_t)n * 2] = s0; rec[(size_t)n * 2 + 1] = q0;
                 rec[((size_t)p.Ng + n) * 2] = s1; rec[((size_t)p.Ng + n) * 2 + 1] = q1;
             }
+        }
+    }
+    if (fold && want_stats) {
+        // ONE record per tile ([tile row][2 slots][Ng][2] doubles): the wave rows' sums meet in LDS, in wave-row order
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Ng) {
+            const double* sr = reinterpret_cast<const double*>(smem_raw + SREC_OFF) + (size_t)tid * 4;
+            double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { a += sr[w * BN * 4]; b += sr[w * BN * 4 + 1]; c += sr[w * BN * 4 + 2]; d += sr[w * BN * 4 + 3]; }
+            double* rec = p.stats + ((size_t)tile_m * 2 * p.Ng + (n0 + tid)) * 2;
+            st_agent(rec, a); st_agent(rec + 1, b);
+            st_agent(rec + (size_t)p.Ng * 2, c); st_agent(rec + (size_t)p.Ng * 2 + 1, d);
         }
     }
     if (staged) {
@@ -717,12 +810,94 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                 const int nn = n0 + tid;
                 const int k0 = tile_m - (int)(((long)bg * p.bn_L) / BM);          // chunk of group g = tile row - first tile row of g
                 double* r0 = p.bn_sums + (((size_t)bg * p.bn_chunks + k0) * p.Ng + nn) * 2;
-                r0[0] = a; r0[1] = b;
+                if (fold) { st_agent(r0, a); st_agent(r0 + 1, b); } else { r0[0] = a; r0[1] = b; }
                 if (m0 + BM > gb && bg + 1 < p.bn_G) {          // the tile straddles into group g + 1: it is that group's first tile
                     double* r1 = p.bn_sums + ((size_t)(bg + 1) * p.bn_chunks * p.Ng + nn) * 2;
-                    r1[0] = c; r1[1] = d;
+                    if (fold) { st_agent(r1, c); st_agent(r1 + 1, d); } else { r1[0] = c; r1[1] = d; }
                 }
             }
+        }
+    }
+
+    // ---- column tails: the last tile of this column block finishes the layer's statistics / backward coefficients for its channels
+    if (fold && (p.stats != nullptr || want_bsums)) {
+        if (!last_arrival(p.tickets + tile_n, p.tiles_m, &s_flag)) return;
+        if (tid == 0) st_agent(p.tickets + tile_n, 0);
+        constexpr int NL = NT / BN;             // record lanes per channel
+        const int c = tid % BN, lane = tid / BN;
+        const int n = n0 + c;
+        const bool nok = n < p.Ng;
+        double* const sm = reinterpret_cast<double*>(smem_raw);      // [NL][BN][2] (every other use of the LDS is over)
+        double tg = 0.0, tb = 0.0;
+        for (int g = 0; g < p.fin_G; ++g) {     // (groups in order: the running statistics see them as successive forwards would)
+            double s = 0.0, q = 0.0;
+            const double* base;
+            int cnt;
+            size_t stride;
+            if (want_bsums) {
+                const int tf = (int)(((long)g * p.bn_L) / BM);
+                cnt = (int)((((long)(g + 1) * p.bn_L + BM - 1) / BM) - tf);
+                base = p.bn_sums + ((size_t)g * p.bn_chunks * p.Ng + n) * 2;
+                stride = (size_t)p.Ng * 2;
+            } else {
+                const long lo = (long)g * p.stat_L, hi = lo + p.stat_L;
+                const int t_first = (int)((lo + BM - 1) / BM);
+                int t_last = (int)((hi + BM - 1) / BM) - 1;
+                if (t_last > p.tiles_m - 1) t_last = p.tiles_m - 1;
+                cnt = t_last - t_first + 1;                      // slot-0 records of the tiles that start inside the group
+                base = p.stats + ((size_t)t_first * 2 * p.Ng + n) * 2;
+                stride = (size_t)2 * p.Ng * 2;
+                if (nok && lane == 0 && g > 0 && t_first >= 1) {             // slot 1 of the tile that straddles the group's lower boundary
+                    const double* r1 = p.stats + (((size_t)(t_first - 1) * 2 + 1) * p.Ng + n) * 2;
+                    s += ld_agent(r1); q += ld_agent(r1 + 1);
+                }
+            }
+            if (nok) {
+                int k = lane;
+                for (; k + 3 * NL < cnt; k += 4 * NL) {          // four records in flight
+                    const double* r = base + (size_t)k * stride;
+                    const double a0 = ld_agent(r), b0 = ld_agent(r + 1);
+                    const double a1 = ld_agent(r + NL * stride), b1 = ld_agent(r + NL * stride + 1);
+                    const double a2 = ld_agent(r + 2 * NL * stride), b2 = ld_agent(r + 2 * NL * stride + 1);
+                    const double a3 = ld_agent(r + 3 * NL * stride), b3 = ld_agent(r + 3 * NL * stride + 1);
+                    s += (a0 + a1) + (a2 + a3);
+                    q += (b0 + b1) + (b2 + b3);
+                }
+                for (; k < cnt; k += NL) {
+                    const double* r = base + (size_t)k * stride;
+                    s += ld_agent(r); q += ld_agent(r + 1);
+                }
+            }
+            sm[(lane * BN + c) * 2] = s; sm[(lane * BN + c) * 2 + 1] = q;
+            __syncthreads();
+            if (lane == 0 && nok) {
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) { a += sm[(l * BN + c) * 2]; b += sm[(l * BN + c) * 2 + 1]; }
+                const size_t i = (size_t)g * p.Ng + n;
+                if (want_bsums) {
+                    p.fin_coef[i * 2] = (float)(a / (double)p.bn_L);
+                    p.fin_coef[i * 2 + 1] = (float)(b / (double)p.bn_L);
+                    tb += a; tg += b;
+                } else {
+                    const double L = (double)p.stat_L;
+                    const double mu = a / L;
+                    double var = b / L - mu * mu;
+                    if (var < 0.0) var = 0.0;
+                    p.fin_mean[i] = (float)mu;
+                    p.fin_rstd[i] = (float)(1.0 / sqrt(var + (double)p.fin_eps));
+                    if (p.fin_rmean) {
+                        const double unb = p.stat_L > 1 ? var * L / (L - 1.0) : var;
+                        p.fin_rmean[n] = (float)((1.0 - (double)p.fin_momentum) * (double)p.fin_rmean[n] + (double)p.fin_momentum * mu);
+                        p.fin_rvar[n] = (float)((1.0 - (double)p.fin_momentum) * (double)p.fin_rvar[n] + (double)p.fin_momentum * unb);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (want_bsums && lane == 0 && nok) {
+            if (p.fin_dgamma) p.fin_dgamma[n] = (float)tg;
+            if (p.fin_dbeta) p.fin_dbeta[n] = (float)tb;
         }
     }
 }
@@ -760,10 +935,10 @@ __global__ __launch_bounds__(256) void ks_reduce1_kernel(const float* __restrict
 constexpr bool KS_STAGE_OUT_HOST = KS_STAGE_OUT != 0;      // the addend joins in the staged store phase
 
 // ---- host side: tile classes and the split-K plan of the tail (same policy as conv_igemm.hip)
-enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_128x64_K2 = 5, KS_128x32 = 6, KS_NCFG = 7 };
-const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64, 128, 128};
-const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128, 64, 32};
-const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2, 4, 4};  // wave rows of a tile = statistics records per tile row
+enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_128x64_K2 = 5, KS_128x32 = 6, KS_64x64_W2 = 7, KS_NCFG = 8 };
+const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64, 128, 128, 64};
+const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128, 64, 32, 64};
+const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2, 4, 4, 2};  // wave rows of a tile = statistics records per tile row
 // The two-wave-group form of the 128x64 tile is built and tested but OFF by default: alone it hides the exposed waits of a launch
 // with one workgroup per CU, but in the four-lane step it costs +4 ms (135.2 against 131.1 ms, interleaved A/B on one box, round 5):
 // 112 KB of LDS and 2 x 208 registers per SIMD leave no room for the other lanes' workgroups on that CU, and those - not idle issue
@@ -785,7 +960,10 @@ static int ks_env(const char* name, int dflt) {
 //  * 128x64 (4 waves of 32x64: every A fragment is split by ONE wave) for long reductions on the 8712 / 17424-row maps whose
 //    128x128 tiling would leave CUs idle (135-185 TF/s against 95-168);
 //  * 64x64 for short reductions (1x1 convs with <= 512 source channels: prologue / epilogue bound) and few output channels.
-int ks_choose(long M, int Ng, int Ktot, int tuning) {
+static int ks_choose_plan(long M, int Ng, int Ktot, int tuning);
+static int ks_w2_or(int cfg);
+int ks_choose(long M, int Ng, int Ktot, int tuning) { return ks_w2_or(ks_choose_plan(M, Ng, Ktot, tuning)); }
+static int ks_choose_plan(long M, int Ng, int Ktot, int tuning) {
     static const int T128_SHORT = ks_env("SSCG_KS_T128_SHORT", 1024);   // min 128x128 tiles for that class on a short reduction
     static const int K128 = ks_env("SSCG_KS_K128", 512);               // min reduction length for the 128x128 class
     static const int K12864 = ks_env("SSCG_KS_K12864", 1024);          // min reduction length for the 128x64 class
@@ -800,6 +978,11 @@ int ks_choose(long M, int Ng, int Ktot, int tuning) {
     if (t128 >= (Ktot >= 1024 ? 512 : T128_SHORT) && Ktot >= K128) return KS_128x128;
     if (Ktot >= K12864 && tm * cdiv(Ng, 64) >= T12864) return ks_k2_or(KS_128x64, tm * cdiv(Ng, 64), Ktot);
     return KS_64x64;
+}
+// the 64x64 tile as TWO waves of 32x64 (every A fragment split once, 7 instead of 17 VALU operations per MFMA) instead of four of 32x32
+static int ks_w2_or(int cfg) {
+    static const int on = ks_env("SSCG_KS_W2", 0);
+    return (on && cfg == KS_64x64) ? KS_64x64_W2 : cfg;
 }
 
 struct KsSplit { int splits, ksplit, full_tiles, m_tail0; };
@@ -851,6 +1034,14 @@ size_t ks_split_bytes(const KsSplit& sp, long M, int Ng) {
     return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
 
+// in-kernel tails: not for the two-group form (its second group leaves before the epilogue), not where a column's last workgroup
+// would walk more than KS_TAIL_TILES records; the tickets a launch may touch: one per column block + one per tail tile
+bool ks_fold_ok(long M, int Ng, int Ktot, int tuning) {
+    static const int on = ks_env("SSCG_KS_TAILS", 1);
+    const int cfg = ks_choose(M, Ng, Ktot, tuning);
+    return on && cfg != KS_128x64_K2 && cdiv(M, KS_BM[cfg]) <= KS_TAIL_TILES && cdiv(Ng, KS_BN[cfg]) + 208 <= SSCG_TAIL_TICKETS;
+}
+
 template <int MODE, int WM, int WN, int TM, int TN, int KG = 1>
 int launch_ks(const KsParams& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
@@ -862,7 +1053,8 @@ int launch_ks(const KsParams& p0, hipStream_t st) {
     p.tiles_n = cdiv(p.Ng, BN);
     p.div_tn = make_fastdiv(p.tiles_n);
     p.div_gl = make_fastdiv((MODE == MODE_DGRAD && p.bn_sums != nullptr) ? p.bn_L : (p.stat_L > 0 ? p.stat_L : 1));
-    p.tiles = cdiv(p.M, BM) * p.tiles_n;
+    p.tiles_m = cdiv(p.M, BM);
+    p.tiles = p.tiles_m * p.tiles_n;
     const size_t smem = (size_t)KG * 2 * (BM * 128 + 3 * BN * 64);
     auto kern = convs_kernel<MODE, WM, WN, TM, TN, KG>;
     SSCG_ENSURE_SMEM((kern), smem);
@@ -870,7 +1062,7 @@ int launch_ks(const KsParams& p0, hipStream_t st) {
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);
     SSCG_LAUNCH_CHECK();
-    if (p.splits > 1) {
+    if (p.splits > 1 && !p.tickets) {     // (with tickets the tail tiles are finished inside the launch)
         const size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
         float* yt = p.dst + (size_t)p.m_tail0 * p.Ng;
         if (p.xstats)
@@ -895,6 +1087,7 @@ int dispatch_ks(const KsParams& p, int tuning, hipStream_t st) {
         case KS_64x128: return launch_ks<MODE, 2, 2, 1, 2>(p, st);
         case KS_128x64_K2: return launch_ks<MODE, 4, 1, 1, 2, 2>(p, st);  // two groups of 4 waves of 32x64, half the reduction each
         case KS_128x32: return launch_ks<MODE, 4, 1, 1, 1>(p, st);        // 4 waves of 32x32: few-channel heads
+        case KS_64x64_W2: return launch_ks<MODE, 2, 1, 1, 2>(p, st);      // 2 waves of 32x64: the 64x64 tile with every A fragment split ONCE
         default: return SSCG_ERR_BAD_ARG;
     }
 }
@@ -995,8 +1188,9 @@ size_t sscg_convs_dgrad_workspace(const sscg_conv_desc* d) {
 }
 
 int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
-                   double* xstats, void* ws, size_t ws_bytes, hipStream_t st) {
+                   double* xstats, void* ws, size_t ws_bytes, hipStream_t st, const sscg_fin* fin, int* folded) {
     KsParams p = {};
+    if (folded) *folded = 0;
     p.src = reinterpret_cast<const float*>(x); p.wgt = reinterpret_cast<const bf16*>(w); p.wplane = ks_plane(d);
     p.bias = bias; p.dst = reinterpret_cast<float*>(y);
     p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Cs = d->C; p.Ktot = d->R * d->S * d->C;
@@ -1011,6 +1205,12 @@ int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const 
     if (sp.splits > 1 && (!ws || ws_bytes < ks_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
+    if (fin && fin->tickets && fin->G <= 4 && ks_fold_ok(p.M, p.Ng, p.Ktot, d->tuning) && (!stats || (fin->mean && fin->rstd && (long)fin->G * stat_L == p.M))) {
+        p.tickets = fin->tickets; p.fin_G = stats ? fin->G : 0;
+        p.fin_mean = fin->mean; p.fin_rstd = fin->rstd; p.fin_rmean = fin->rmean; p.fin_rvar = fin->rvar;
+        p.fin_eps = fin->eps; p.fin_momentum = fin->momentum;
+        if (folded) *folded = 1;
+    }
     return dispatch_ks<MODE_FWD>(p, d->tuning, st);
 }
 
@@ -1030,9 +1230,10 @@ bool sscg_convs_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, 
 }
 
 int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs, const void* addend) {
+                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs, const void* addend, int* folded) {
     KsParams p = {};
     bool fused = false;
+    if (folded) *folded = 0;
     if (addend) {
         if (bias || act != SSCG_ACT_NONE || !KS_STAGE_OUT_HOST) return SSCG_ERR_UNSUPPORTED;
         p.addend = reinterpret_cast<const float*>(addend);
@@ -1086,6 +1287,11 @@ int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, co
     if (sp.splits > 1 && (!ws || ws_bytes < ks_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
+    if (fused && bs->tickets && bs->coef && bs->G <= 4 && ks_fold_ok(p.M, p.Ng, p.Ktot, d->tuning)) {
+        p.tickets = bs->tickets; p.fin_G = bs->G;
+        p.fin_coef = bs->coef; p.fin_dgamma = bs->dgamma; p.fin_dbeta = bs->dbeta;
+        if (folded) *folded = 1;
+    }
     return dispatch_ks<MODE_DGRAD>(p, d->tuning, st);
 }
 

@@ -24,6 +24,10 @@ from .optim import FusedAdam
 from .utils import CLASSES, make_one_hot
 
 _DBG_TOPWAIT = [x for x in os.environ.get("SSCG_DBG_TOPWAIT", "").split(",") if x]
+# where the host ISSUES the frozen generators' pass (model.py:418-423: it feeds the D step only) and the unused Gis(lab_gt) pass (:409):
+# "early" = the reference's program order, "mid" = behind the trainable generators' forwards, "late" = behind the backward's launches
+_FROZEN_AT = os.environ.get("SSCG_FROZEN_AT", "early")
+_UNUSED_AT = os.environ.get("SSCG_UNUSED_AT", "early")
 
 
 def _check_bf16_widths(args):
@@ -160,7 +164,7 @@ class semisuper_cycleGAN(object):
                     return both[:unl_img.shape[0]]
                 fake = F.softmax2d(self.old_Gsi(unl_img))                            # :418,421
                 return self.old_Gis(fake)                                            # :422
-        resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch)
+        resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch) if _FROZEN_AT == "early" else None
         dev = l_img.device
         fork = F.SideStream.enabled and self.fork_forward and not self.stack_gis
         self._wait_operand_copies(torch.cuda.current_stream(dev))
@@ -219,7 +223,8 @@ class semisuper_cycleGAN(object):
         def unused_pass():
             with torch.no_grad():
                 self.Gis(lab_det)
-        F.run_on_side_stream(l_img.device, (lab_det,), unused_pass)
+        if _UNUSED_AT == "early":
+            F.run_on_side_stream(l_img.device, (lab_det,), unused_pass)
         if fork:
             with torch.cuda.stream(lane):
                 lane.wait_event(gsi_second)
@@ -250,6 +255,10 @@ class semisuper_cycleGAN(object):
             extras["gt_label_gen_loss"] = F.mse_const(self.Ds(lab_gt), 1.0)
             extra_terms.append(extras["gt_label_gen_loss"])
             extra_weights.append(a.adversarial_weight)
+        if _UNUSED_AT == "mid":
+            F.run_on_side_stream(l_img.device, (lab_det,), unused_pass)
+        if _FROZEN_AT == "mid":
+            resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch)
         if self.overlap_d:      # the previous step's discriminator update (on the D stream) must have landed
             torch.cuda.current_stream(dev).wait_stream(F.d_stream(dev))
         self.d_optimizer.ensure_operand_copies()
@@ -267,6 +276,10 @@ class semisuper_cycleGAN(object):
             [lab_loss_CE, lab_loss_MSE, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss] + extra_terms,
             [a.lab_CE_weight, a.lab_MSE_weight, a.adversarial_weight, a.adversarial_weight, 1.0, a.lamda_gt] + extra_weights)
         F.backward(gen_loss)                                                         # :472
+        if _UNUSED_AT == "late":
+            F.run_on_side_stream(l_img.device, (lab_det,), unused_pass)
+        if _FROZEN_AT == "late":
+            resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch)
         F.ForkStream.join(l_img.device)
         F.SideStream.join(l_img.device)            # side stream: weight gradients + frozen generators are complete
         resnet_recon_img.record_stream(torch.cuda.current_stream(l_img.device))

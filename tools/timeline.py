@@ -74,5 +74,47 @@ def main():
         print("  %6.2f  %s" % (v / steps / 1e6, n))
 
 
+    gantt(rows, per, lo + (steps - 1) * span // steps, hi)
+
+
+def gantt(rows, per, t0, t1, bucket_us=1000):
+    """The last step as a chart: one row per stream, one character per bucket - the busy fraction of the stream in that bucket
+    (' ' idle, '.' < 1/3, ':' < 2/3, '#' more) - and under it the kind of kernel that filled most of the bucket
+    (F forward conv, D data gradient, W weight gradient, n norm apply, b norm backward, o other)."""
+    nb = int((t1 - t0) / (bucket_us * 1000)) + 1
+
+    def kind(n):
+        if "convs_kernel<0" in n or "conv_kc_kernel<0" in n or "conv16_kernel<0" in n:
+            return "F"
+        if "convs_kernel<1" in n or "conv_kc_kernel<1" in n or "conv16_kernel<1" in n:
+            return "D"
+        if "wgrad" in n:
+            return "W"
+        if "norm_apply" in n:
+            return "n"
+        if "norm_bwd" in n:
+            return "b"
+        return "o"
+    print("last step, %d us per character:" % bucket_us)
+    for sid, ks in sorted(per.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
+        busy = [0.0] * nb
+        kinds = [defaultdict(float) for _ in range(nb)]
+        for s, e, n in ks:
+            if e <= t0 or s >= t1:
+                continue
+            s, e = max(s, t0), min(e, t1)
+            b = int((s - t0) / (bucket_us * 1000))
+            while s < e:
+                be = t0 + (b + 1) * bucket_us * 1000
+                d = min(e, be) - s
+                busy[b] += d
+                kinds[b][kind(n)] += d
+                s = min(e, be)
+                b += 1
+        frac = [x / (bucket_us * 1000) for x in busy]
+        print("  stream %-3s |%s|" % (sid, "".join(" " if f < 0.02 else "." if f < 0.33 else ":" if f < 0.67 else "#" for f in frac)))
+        print("             |%s|" % "".join(" " if not k else max(k.items(), key=lambda kv: kv[1])[0] for k in kinds))
+
+
 if __name__ == "__main__":
     main()
