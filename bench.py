@@ -61,7 +61,8 @@ CONFIGS = {
 DTYPE_TEXT = {"f32": "fp32", "f32x": "fp32 tensors, exact fp32 MFMA contractions (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 (bf16 activations + conv weight operands in HBM, fp32 accumulate / master weights / norm statistics / losses)",
               "bf16c": "bf16 conv contractions (fp32 tensors)",
               "f32s": "fp32 tensors, 3-piece split-bf16 contraction, fp32-accurate (six exact bf16 piece products per fp32 product on "
-                      "the bf16 matrix cores, fp32 accumulation - forward, data and weight gradients; few-channel stems and heads on the exact fp32 MFMA)"}
+                      "the bf16 matrix cores, fp32 accumulation - forward, data and weight gradients; 21 / 20-channel stems and heads zero-padded onto the same "
+                      "contraction, 1- / 3-channel ends on the exact fp32 MFMA)"}
 
 
 def main():
@@ -178,6 +179,15 @@ def main():
     for i in range(a.warmup):
         run(i)
     dt, losses = timed(a.warmup, a.steps)
+    if os.environ.get("SSCG_PHASE_EVENTS") == "1" and rank == 0:
+        # diagnostic: one more step with timed events around its passes (model.py _mark) - when each pass ran on the GPU and when
+        # the host issued it, without a tracer's overhead
+        torch.cuda.synchronize()
+        run(a.warmup + a.steps)
+        torch.cuda.synchronize()
+        m0 = model.phase_marks[0]
+        for name, ev, th in model.phase_marks:
+            print("%8.2f ms gpu  %8.2f ms host  %s" % (m0[1].elapsed_time(ev), (th - m0[2]) * 1e3, name), file=sys.stderr)
     finite = all(bool(torch.isfinite(v)) for v in losses.values())
     peak = PEAK[dtype]
     value = world * bsz * a.steps / dt

@@ -168,16 +168,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize of a kernel that wants more than 64 KB of dynamic LDS: set when the request grows, not on
-// every launch (the call costs the host 1-2 us; the step issues ~1000 such launches).  One static per call site = per template
-// instantiation; two threads racing here set the same value twice.
+// every launch (the call costs the host 1-2 us; the step issues ~1000 such launches).  One static table per call site = per template
+// instantiation, one entry per DEVICE (the attribute is per device: a process that launches on a second GPU - a test, a --gpu_ids
+// switch - must set it there too); two threads racing here set the same value twice.
 #define SSCG_ENSURE_SMEM(kern, smem)                                                                                                   \
     do {                                                                                                                               \
-        static size_t sscg_attr_smem_ = 64 * 1024;                                                                                     \
-        if ((size_t)(smem) > sscg_attr_smem_) {                                                                                        \
+        static size_t sscg_attr_smem_[16] = {0};                                                                                       \
+        int sscg_dev_ = 0;                                                                                                             \
+        if (hipGetDevice(&sscg_dev_) != hipSuccess) sscg_dev_ = 0;                                                                     \
+        size_t& sscg_cur_ = sscg_attr_smem_[sscg_dev_ & 15];                                                                           \
+        if (sscg_cur_ == 0) sscg_cur_ = 64 * 1024;                                                                                     \
+        if ((size_t)(smem) > sscg_cur_) {                                                                                              \
             hipError_t sscg_e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                      (int)(smem));                                                                     \
             if (sscg_e_ != hipSuccess) return (int)sscg_e_;                                                                            \
-            sscg_attr_smem_ = (size_t)(smem);                                                                                          \
+            sscg_cur_ = (size_t)(smem);                                                                                                \
         }                                                                                                                              \
     } while (0)
 

@@ -41,6 +41,13 @@ namespace {
 #ifndef KS_LATE_WAIT
 #define KS_LATE_WAIT 0
 #endif
+// In-kernel tails (the ABI v15 entries fold their small launches into the conv launch): compiled OUT by default - the ticket paths
+// cost the kernel +5.4 ms per config-2 step even when no launch uses them (134.3 against 128.9 ms, same box, interleaved:
+// profiles/r05_experiments.txt item 13) and +3 ms more when used.  -DKS_TAILS=1 builds them (tools/variant_lib.sh; the tests run
+// the same assertions on either build).
+#ifndef KS_TAILS
+#define KS_TAILS 0
+#endif
 #ifndef KS_LB4
 #define KS_LB4 1           // 64x64 class: hold the kernel to 128 registers (4 workgroups per CU, what its 40 KB of LDS allow) - two accumulator sets take it to 134
 #endif
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     constexpr int OLD = BN + 4;
     constexpr int SREC_OFF = BM * OLD * 4;     // in-kernel tails: the waves' statistics meet behind the staged tile, [WM][BN][4] doubles
     __shared__ int s_flag;
-    const bool fold = KG == 1 && p.tickets != nullptr;
+    const bool fold = KS_TAILS && KG == 1 && p.tickets != nullptr;
     const bool want_bsums = MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (never with split-K: the host plans these launches unsplit)
     float* const ot = reinterpret_cast<float*>(smem_raw);
     if (partial && fold) {
@@ -1037,7 +1044,7 @@ size_t ks_split_bytes(const KsSplit& sp, long M, int Ng) {
 // in-kernel tails: not for the two-group form (its second group leaves before the epilogue), not where a column's last workgroup
 // would walk more than KS_TAIL_TILES records; the tickets a launch may touch: one per column block + one per tail tile
 bool ks_fold_ok(long M, int Ng, int Ktot, int tuning) {
-    static const int on = ks_env("SSCG_KS_TAILS", 1);
+    static const int on = KS_TAILS && ks_env("SSCG_KS_TAILS", 1);
     const int cfg = ks_choose(M, Ng, Ktot, tuning);
     return on && cfg != KS_128x64_K2 && cdiv(M, KS_BM[cfg]) <= KS_TAIL_TILES && cdiv(Ng, KS_BN[cfg]) + 208 <= SSCG_TAIL_TICKETS;
 }
@@ -1874,12 +1881,7 @@ int launch_wgf(const sscg_conv_desc* d, const void* x, const void* dy, float* dw
     p.npix = d->N * d->P * d->Q; p.chunk = pl.chunk;
     p.tiles_n = cdiv(p.C, 128); p.tiles = cdiv(p.Kc, 128) * p.tiles_n; p.splits = pl.splits;
     p.beta = pl.splits > 1 ? 0.f : beta;
-    static bool attr_set = false;       // one attribute per process (idempotent; a race sets it twice)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgradf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WF_SMEM);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    SSCG_ENSURE_SMEM(wgradf_kernel, WF_SMEM);
     hipLaunchKernelGGL(wgradf_kernel, dim3(p.tiles * pl.splits), dim3(256), WF_SMEM, st, p);
     SSCG_LAUNCH_CHECK();
     if (pl.splits > 1) return sscg_wgrad_reduce(reinterpret_cast<const float*>(ws), dw, (size_t)d->K * d->C, pl.splits, beta, st);
@@ -1943,12 +1945,7 @@ int sscg_wgrads(const sscg_conv_desc* d, const void* x, const void* dy, float* d
         hipLaunchKernelGGL(wgrads_kernel<2>, dim3(p.tiles * pl.splits), dim3(256), smem2, st, p);
     } else {
         const size_t smem = (size_t)3 * WS_STAGE;      // 72 KB
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrads_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        SSCG_ENSURE_SMEM(wgrads_kernel<3>, smem);
         hipLaunchKernelGGL(wgrads_kernel<3>, dim3(p.tiles * pl.splits), dim3(256), smem, st, p);
     }
     SSCG_LAUNCH_CHECK();

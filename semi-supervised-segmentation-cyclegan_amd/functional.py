@@ -608,7 +608,9 @@ def _unprofiled(fn):
         ConvProfile.active = prof
 
 
-def _timed(kind, d, fn):
+def _timed(kind, d, fn, extra_bytes=0):
+    """extra_bytes: algorithmic reads of a launch's fused store phase beyond operands and result (the fan-in addend, the normalisation
+    layer's input and mask source of a data gradient that takes the backward sums)."""
     prof = ConvProfile.active
     if prof is None:
         return fn()
@@ -628,7 +630,7 @@ def _timed(kind, d, fn):
     # algorithmic HBM bytes of the launch: every operand read once, the result written once
     esz = {F32: 4, BF16: 2, BF16X3: 6}
     nbytes = (d.N * d.H * d.W * d.C * esz[d.x_dtype] + d.N * d.P * d.Q * d.K * esz[d.y_dtype]
-              + d.K * d.R * d.S * d.C * (4 if kind == "wgrad" else esz[d.w_dtype]))
+              + d.K * d.R * d.S * d.C * (4 if kind == "wgrad" else esz[d.w_dtype])) + extra_bytes
     prof.records.append(((kind, "split" if d.w_dtype == BF16X3 else ("bf16" if b16 else "f32")), flops, key, e0, e1, float(nbytes)))
     return r
 
@@ -854,6 +856,7 @@ def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NO
             nb = 0
         if nb:
             sums = torch.empty(nb, dtype=torch.uint8, device=dy.device)
+            fused_reads = dx.numel() * dx.element_size() * (1 + (1 if res else 0) + (1 if addend is not None else 0))      # nx [, z] [, addend]
             if TAILS[0]:
                 # the layer's backward coefficients [G][C][2] and dgamma [C], dbeta [C] come out of this call (of the launch itself where
                 # the family serves it): norm_bwd_from_sums only applies them
@@ -863,16 +866,17 @@ def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NO
                     C.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), nx.data_ptr(), z.data_ptr() if res else None, _ptr(addend),
                     mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta), g, l, nact, nslope, sums.data_ptr(), nb, fin.data_ptr(),
                     fin.data_ptr() + 4 * g * c * 2, fin.data_ptr() + 4 * (g * c * 2 + c), tk.data_ptr(), ws.data_ptr(), ws.numel(),
-                    _stream()), "sscg_conv2d_dgrad_bsums_fin"))
+                    _stream()), "sscg_conv2d_dgrad_bsums_fin"), extra_bytes=fused_reads)
                 return dx, (d, sums, res, fin), joinable
             _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad_bsums(
                 C.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), nx.data_ptr(), z.data_ptr() if res else None, _ptr(addend),
                 mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta), g, l, nact, nslope, sums.data_ptr(), nb, ws.data_ptr(),
-                ws.numel(), _stream()), "sscg_conv2d_dgrad_bsums"))
+                ws.numel(), _stream()), "sscg_conv2d_dgrad_bsums"), extra_bytes=fused_reads)
             return dx, (d, sums, res), joinable
     if joinable:
         _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad_add(C.byref(d), dy.data_ptr(), wt.data_ptr(), addend.data_ptr(), dx.data_ptr(),
-                                                                   ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_dgrad_add"))
+                                                                   ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_dgrad_add"),
+               extra_bytes=dx.numel() * dx.element_size())
         return dx, None, True
     _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wt.data_ptr(), _ptr(bias), dx.data_ptr(),
                                                            act, slope, ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_dgrad"))
@@ -1810,7 +1814,10 @@ class ConvNormActFn(torch.autograd.Function):
         need_z = act != ACT_NONE and (residual is not None or act not in (ACT_RELU, ACT_LRELU))
         ctx.save_for_backward(x, w, y, z if need_z else None, mean, rstd, gamma, beta)
         ctx.res_join = getattr(residual, "_sscg_join", None) if (residual is not None and FUSE_JOIN[0]) else None
-        if FUSE_BSUMS[0] and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and (residual is None or FUSE_JOIN[0]):
+        # (only for a forward that will see a backward: the attribute keeps y, mean, rstd alive as long as z lives - the frozen
+        # generators, evaluation and validation would hold every pre-norm activation for nothing)
+        if (FUSE_BSUMS[0] and any(ctx.needs_input_grad) and act in (ACT_NONE, ACT_RELU, ACT_LRELU)
+                and (residual is None or FUSE_JOIN[0])):
             # for the consumer's data gradient (_conv_backward): what this unit's backward reduction needs besides dz; last entry: the
             # mask cannot be recomputed from y (a residual joined before the activation) - it is read off z, the consumer's own input
             z._sscg_norm = (y, mean, rstd, gamma, beta, (g, l, c), act, slope, need_z)
@@ -2217,6 +2224,9 @@ class UpsampleHeadFn(torch.autograd.Function):
                                          _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "sscg_upsample_head_fwd")
         ctx.geom = (oh, ow)
         ctx.save_for_backward(x, dl, valid)
+        # an output nothing differentiates (the step reads lab_gt's softmax through .detach() only): backward gets None, not a
+        # zero-filled [B, C, crop] map to gather over
+        ctx.set_materialize_grads(False)
         return y, loss
 
     @staticmethod

@@ -26,6 +26,7 @@ from .utils import CLASSES, make_one_hot
 _DBG_TOPWAIT = [x for x in os.environ.get("SSCG_DBG_TOPWAIT", "").split(",") if x]
 # where the host ISSUES the frozen generators' pass (model.py:418-423: it feeds the D step only) and the unused Gis(lab_gt) pass (:409):
 # "early" = the reference's program order, "mid" = behind the trainable generators' forwards, "late" = behind the backward's launches
+_PHASES = os.environ.get("SSCG_PHASE_EVENTS") == "1"      # diagnostic: timed events around the passes of a step (tools/phases.py)
 _FROZEN_AT = os.environ.get("SSCG_FROZEN_AT", "early")
 _UNUSED_AT = os.environ.get("SSCG_UNUSED_AT", "early")
 
@@ -131,12 +132,23 @@ class semisuper_cycleGAN(object):
             self.best_iou = -100
 
     # ------------------------------------------------------------------------------------------ one iteration
+    def _mark(self, name, stream=None):
+        """Diagnostic (SSCG_PHASE_EVENTS=1): a timed event on `stream` (default: the current one) + the host's clock, under `name`."""
+        if not _PHASES:
+            return
+        import time
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream())
+        self.phase_marks.append((name, ev, time.perf_counter()))
+
     def interp(self, x):
         return F.upsample_bilinear(x, self.crop)
 
     def step(self, l_img, l_gt, unl_img):
         """One G step + one D step (model.py:376-542).  Returns the nine losses as 0-dim device tensors."""
         a, C = self.args, self.n_channels
+        self.phase_marks = []
+        self._mark("step start")
         F.set_side_priority(F.side_priority_for(l_img.shape[0] * l_img.shape[2] * l_img.shape[3]))      # (the process's first step decides)
         if self.overlap_d and _DBG_TOPWAIT:     # bisection aid: these streams wait for the previous D step before anything of this step
             F.debug_wait_for_d(l_img.device, _DBG_TOPWAIT)
@@ -159,8 +171,10 @@ class semisuper_cycleGAN(object):
                 if self.as_written:
                     # :418-423 runs old_Gsi/old_Gis on unl_img (used) and on l_img (results never used): both batches
                     # in one pass (per-sample InstanceNorm; batch_groups keeps a BatchNorm variant equivalent too)
+                    self._mark("frozen: start")
                     with arch.batch_groups(2):
                         both = self.old_Gis(F.softmax2d(self.old_Gsi(torch.cat([unl_img, l_img], 0))))
+                    self._mark("frozen: end")
                     return both[:unl_img.shape[0]]
                 fake = F.softmax2d(self.old_Gsi(unl_img))                            # :418,421
                 return self.old_Gis(fake)                                            # :422
@@ -179,7 +193,9 @@ class semisuper_cycleGAN(object):
             main, lane = torch.cuda.current_stream(dev), F.ForkStream.get(dev)
             lane.wait_stream(main)
             with torch.cuda.stream(lane):
+                self._mark("fork Gis(onehot): start")
                 fake_img = self.interp(self.Gis(onehot_gt))                          # :385,390
+                self._mark("fork Gis(onehot): end")
                 gis_first = torch.cuda.Event()
                 gis_first.record(lane)
             onehot_gt.record_stream(lane)
@@ -189,8 +205,10 @@ class semisuper_cycleGAN(object):
             # Gsi(unl_img) and Gsi(l_img) (:386-387) as ONE pass over both batches: every BatchNorm normalises the two
             # halves separately and advances its running statistics twice, in order (arch.batch_groups) - the same
             # arithmetic, on convolutions with twice the rows and half the launches.
+            self._mark("main Gsi(unl, l): start")
             with arch.batch_groups(2):
                 both = self.Gsi(torch.cat([unl_img, l_img], 0))
+            self._mark("main Gsi(unl, l): end")
             fake_logits, lab_logits = F.split_batch(both, 2)
         else:
             fake_logits = self.Gsi(unl_img)                                          # :386
@@ -214,7 +232,9 @@ class semisuper_cycleGAN(object):
             fake_img = self.interp(fake_lo)                                          # :385,390
             recon_img = self.interp(recon_lo)                                        # :408,413
         else:
+            self._mark("main Gis(fake_gt): start")
             recon_img = self.interp(self.Gis(fake_gt))                               # :408,413
+            self._mark("main Gis(fake_gt): end")
         # :409 - output unused by the reference, but it advances Gis' BN running stats (after those of the :408 pass
         # above, which the side stream waits for).  Nothing reads the result: it runs beside the critical path and is
         # joined before the optimiser touches Gis' weights.
@@ -222,14 +242,18 @@ class semisuper_cycleGAN(object):
 
         def unused_pass():
             with torch.no_grad():
+                self._mark("side Gis(lab_gt) unused: start")
                 self.Gis(lab_det)
+                self._mark("side Gis(lab_gt) unused: end")
         if _UNUSED_AT == "early":
             F.run_on_side_stream(l_img.device, (lab_det,), unused_pass)
         if fork:
             with torch.cuda.stream(lane):
                 lane.wait_event(gsi_second)
                 fake_img, fake_img_d, fake_img_l1 = F.split(fake_img, 3)             # consumers: Gsi, Di, L1
+                self._mark("fork Gsi(fake_img): start")
                 recon_logits = self.Gsi(fake_img)                                    # :410
+                self._mark("fork Gsi(fake_img): end")
             main.wait_stream(lane)
             fake_img.record_stream(main)
             recon_logits.record_stream(main)
@@ -275,13 +299,16 @@ class semisuper_cycleGAN(object):
         gen_loss = F.weighted_sum(
             [lab_loss_CE, lab_loss_MSE, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss] + extra_terms,
             [a.lab_CE_weight, a.lab_MSE_weight, a.adversarial_weight, a.adversarial_weight, 1.0, a.lamda_gt] + extra_weights)
+        self._mark("main: backward start")
         F.backward(gen_loss)                                                         # :472
+        self._mark("main: backward issued / main's part done")
         if _UNUSED_AT == "late":
             F.run_on_side_stream(l_img.device, (lab_det,), unused_pass)
         if _FROZEN_AT == "late":
             resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch)
         F.ForkStream.join(l_img.device)
         F.SideStream.join(l_img.device)            # side stream: weight gradients + frozen generators are complete
+        self._mark("main: all lanes joined")
         resnet_recon_img.record_stream(torch.cuda.current_stream(l_img.device))
         g_works = None
         if self.dp is not None:
@@ -316,6 +343,9 @@ class semisuper_cycleGAN(object):
                 self.dp.wait(g_works)
                 self.g_optimizer.step()                                              # :474 (deferred: no D-step op reads G weights)
                 self._refresh_generator_copies(dev)
+        self._mark("main: step issued (G update queued)")
+        if self.overlap_d:
+            self._mark("D stream: D step done", F.d_stream(dev))
         vals = d_vals + (img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss, lab_loss_CE, lab_loss_MSE)
         out = {k: v.detach() for k, v in zip(LOSS_KEYS, vals)}
         out.update({k: v.detach() for k, v in extras.items()})

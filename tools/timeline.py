@@ -80,13 +80,24 @@ def main():
 def gantt(rows, per, t0, t1, bucket_us=1000):
     """The last step as a chart: one row per stream, one character per bucket - the busy fraction of the stream in that bucket
     (' ' idle, '.' < 1/3, ':' < 2/3, '#' more) - and under it the kind of kernel that filled most of the bucket
-    (F forward conv, D data gradient, W weight gradient, n norm apply, b norm backward, o other)."""
+    (F / D forward conv / data gradient of the 128x64 class, f / d of the 64x64 class, R / r of the 128x128 class, k exact-fp32 stems,
+    W weight gradient, n norm apply, b norm backward, o other)."""
     nb = int((t1 - t0) / (bucket_us * 1000)) + 1
 
     def kind(n):
-        if "convs_kernel<0" in n or "conv_kc_kernel<0" in n or "conv16_kernel<0" in n:
+        if "conv_kc_kernel" in n or "thin_" in n:
+            return "k"                  # exact-fp32 stems / thin 1x1
+        if "convs_kernel<0, 2, 2, 2, 2" in n:
+            return "R"                  # 128x128 class forward (the ResNet generators' 64x64 maps)
+        if "convs_kernel<1, 2, 2, 2, 2" in n:
+            return "r"
+        if "convs_kernel<0, 2, 2, 1, 1" in n:
+            return "f"                  # 64x64 class
+        if "convs_kernel<1, 2, 2, 1, 1" in n:
+            return "d"
+        if "convs_kernel<0" in n or "conv16_kernel<0" in n:
             return "F"
-        if "convs_kernel<1" in n or "conv_kc_kernel<1" in n or "conv16_kernel<1" in n:
+        if "convs_kernel<1" in n or "conv16_kernel<1" in n:
             return "D"
         if "wgrad" in n:
             return "W"
