@@ -30,7 +30,7 @@
 namespace {
 
 #ifndef KS_ABLATE
-#define KS_ABLATE 0        // tools/: timing ablations of the k-loop (1 = no copies after the prologue, 2 = no operand split, 4 = no barrier / copy wait); WRONG results
+#define KS_ABLATE 0        // tools/: timing ablations of the k-loop (1 = no copies after the prologue, 2 = no operand split, 4 = no barrier / copy wait, 8 = no epilogue); WRONG results
 #endif
 #ifndef KS_BUFLD
 #define KS_BUFLD 1         // LDS-DMA copies as `buffer_load_dwordx4 ... offen lds`: per-lane row offset in ONE VGPR (computed once per tap), the k-tile's
@@ -47,6 +47,9 @@ namespace {
 // the same assertions on either build).
 #ifndef KS_TAILS
 #define KS_TAILS 0
+#endif
+#ifndef KS_LAUNDER
+#define KS_LAUNDER 0       // the epilogue re-reads its parameters from the kernel-argument segment (0: A/B aid)
 #endif
 #ifndef KS_LB4
 #define KS_LB4 1           // 64x64 class: hold the kernel to 128 registers (4 workgroups per CU, what its 40 KB of LDS allow) - two accumulator sets take it to 134
@@ -563,6 +566,30 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                 for (int e = 0; e < 16; ++e) acc[i][j][e] += mb[((i * TN + j) * 16 + e) * 64];
     }
 
+    // The epilogue reads its parameters through a laundered kernel-argument pointer: hipcc loads every kernel argument at the top of the
+    // kernel and keeps it in SGPRs across the k-loop (a dozen pointers and scalars of the fused store phases: 20-130 SGPR spills in the
+    // loop's shadow); behind the opaque move below the loads cannot be hoisted, the loop keeps its registers.
+#if KS_LAUNDER
+    typedef const __attribute__((address_space(4))) KsParams* KsArgs;          // (the constant address space: scalar loads)
+    KsArgs ka_ = (KsArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka_));
+    const __attribute__((address_space(4))) KsParams& ep = *ka_;
+#else
+    const KsParams& ep = p;
+#endif
+    const FastDiv e_gl = {ep.div_gl.mul, ep.div_gl.shift, ep.div_gl.d}, e_hw = {ep.div_hw.mul, ep.div_hw.shift, ep.div_hw.d},
+                  e_w = {ep.div_w.mul, ep.div_w.shift, ep.div_w.d};
+    if (KS_ABLATE & 8) {        // timing ablation: no epilogue (one store per lane keeps the accumulators alive); WRONG results
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+        p.dst[(size_t)(m0 % 64) * p.Ng + (tid & 31)] = t;
+        return;
+    }
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     // Fused statistics of the normalisation layer that follows (conv_igemm.hip): fp64 column sums of y and y^2 over this tile's
     // rows, four rows at a time in fp32 where the tile lies inside one group and inside the tensor.
@@ -584,17 +611,17 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     constexpr int OLD = BN + 4;
     constexpr int SREC_OFF = BM * OLD * 4;     // in-kernel tails: the waves' statistics meet behind the staged tile, [WM][BN][4] doubles
     __shared__ int s_flag;
-    const bool fold = KS_TAILS && KG == 1 && p.tickets != nullptr;
-    const bool want_bsums = MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (never with split-K: the host plans these launches unsplit)
+    const bool fold = KS_TAILS && KG == 1 && ep.tickets != nullptr;
+    const bool want_bsums = MODE == MODE_DGRAD && ep.bn_sums != nullptr;        // (never with split-K: the host plans these launches unsplit)
     float* const ot = reinterpret_cast<float*>(smem_raw);
     if (partial && fold) {
         // ---- tail tile, in-kernel: every partial workgroup leaves its accumulators in the workspace; the LAST of the tile's `splits`
         // workgroups to arrive sums the partial tiles in split order (whoever is last: the same sum) back into its accumulators and
         // goes on as the workgroup of a whole tile
         const int n_l = n0 + col_w + li;
-        const int r_l = m0 + row_w + 4 * lh - p.m_tail0;
-        const unsigned off0 = (unsigned)r_l * (unsigned)p.Ng + (unsigned)n_l;       // (the workspace of a tail is a few MB: 32-bit offsets)
-        float* const mine = p.part + (size_t)split * (p.M - p.m_tail0) * p.Ng;
+        const int r_l = m0 + row_w + 4 * lh - ep.m_tail0;
+        const unsigned off0 = (unsigned)r_l * (unsigned)ep.Ng + (unsigned)n_l;       // (the workspace of a tail is a few MB: 32-bit offsets)
+        float* const mine = ep.part + (size_t)split * (ep.M - ep.m_tail0) * ep.Ng;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -602,10 +629,10 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int dr = i * 32 + (e & 3) + 8 * (e >> 2);
-                    if (r_l + dr + p.m_tail0 < p.M && n_l + j * 32 < p.Ng) st_agent(mine + (off0 + (unsigned)dr * (unsigned)p.Ng + j * 32), acc[i][j][e]);
+                    if (r_l + dr + ep.m_tail0 < ep.M && n_l + j * 32 < ep.Ng) st_agent(mine + (off0 + (unsigned)dr * (unsigned)ep.Ng + j * 32), acc[i][j][e]);
                 }
-        int* const tk = p.tickets + p.tiles_n + (tile - p.full_tiles);
-        if (!last_arrival(tk, p.splits, &s_flag)) return;
+        int* const tk = ep.tickets + ep.tiles_n + (tile - ep.full_tiles);
+        if (!last_arrival(tk, ep.splits, &s_flag)) return;
         if (tid == 0) st_agent(tk, 0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -613,8 +640,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        for (int k = 0; k < p.splits; ++k) {
-            const float* const pk = p.part + (size_t)k * (p.M - p.m_tail0) * p.Ng;
+        for (int k = 0; k < ep.splits; ++k) {
+            const float* const pk = ep.part + (size_t)k * (ep.M - ep.m_tail0) * ep.Ng;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -622,25 +649,28 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int dr = i * 32 + (e & 3) + 8 * (e >> 2);
-                        if (r_l + dr + p.m_tail0 < p.M && n_l + j * 32 < p.Ng) acc[i][j][e] += ld_agent(pk + (off0 + (unsigned)dr * (unsigned)p.Ng + j * 32));
+                        if (r_l + dr + ep.m_tail0 < ep.M && n_l + j * 32 < ep.Ng) acc[i][j][e] += ld_agent(pk + (off0 + (unsigned)dr * (unsigned)ep.Ng + j * 32));
                     }
         }
         partial = false;
     }
-    const bool want_stats = p.stats != nullptr && !partial;
+    const bool want_stats = MODE == MODE_FWD && ep.stats != nullptr && !partial;      // (a data gradient never takes forward statistics)
     int gb = 0x7fffffff;
-    if (want_stats) gb = (fd_div(m0, p.div_gl) + 1) * p.stat_L;
+    if (want_stats) gb = (fd_div(m0, e_gl) + 1) * ep.stat_L;
     int bg = 0;
-    if (want_bsums) { bg = fd_div(m0, p.div_gl); gb = (bg + 1) * p.bn_L; }
-    const bool slow_stats = want_stats && (!KS_FAST_STATS || m0 + BM > gb || m0 + BM > p.M);
+    if (want_bsums) { bg = fd_div(m0, e_gl); gb = (bg + 1) * ep.bn_L; }
+    const bool slow_stats = want_stats && (!KS_FAST_STATS || m0 + BM > gb || m0 + BM > ep.M);
     const bool fast_stats = want_stats && !slow_stats;
-    const bool staged = KS_STAGE_OUT && !partial && (p.Ng & 3) == 0;      // (16-byte row segments: heads with 21 / 20 output channels store element by element)
+    // Only the heads' class (32 columns) serves Ng % 4 != 0 (ks_choose routes such launches to it) and stores element by element then;
+    // everywhere else the tile - a partial one of a split-K tail too - leaves through LDS as 16-byte row segments
+    constexpr bool ANY_NG = BN == 32;
+    const bool staged = KS_STAGE_OUT && (!ANY_NG || (ep.Ng & 3) == 0);
     if (staged || (fold && want_stats)) __syncthreads();           // every wave has read its last fragments
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + col_w + j * 32 + li;
-        const bool nok = n < p.Ng;
-        const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+        const bool nok = n < ep.Ng;
+        const float bv = (!partial && ep.bias && nok) ? ep.bias[n] : 0.f;
         double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
         if (fast_stats) {
 #pragma unroll
@@ -663,28 +693,27 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < p.M && nok) {
+                const float pre = acc[i][j][e] + bv;
+                if (slow_stats && m < ep.M && nok) {
+                    const double d = (double)pre;
+                    if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
+                }
+                const float v = partial ? pre : sscg_act(pre, ep.act, ep.slope);
+                if (staged) {           // (rows / columns past the tensor are staged too: the store phase drops them)
+                    ot[(row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OLD + col_w + j * 32 + li] = v;
+                } else if (m < ep.M && nok) {
                     if (partial) {
-                        p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc[i][j][e];
+                        ep.part[((size_t)split * (ep.M - ep.m_tail0) + (m - ep.m_tail0)) * ep.Ng + n] = v;
                     } else {
-                        const float pre = acc[i][j][e] + bv;
-                        if (slow_stats) {
-                            const double d = (double)pre;
-                            if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
+                        size_t row = (size_t)m;
+                        if (MODE == MODE_DGRAD && ep.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
+                            const int img = fd_div(m, e_hw);
+                            const int rem = m - img * (ep.OH * ep.OW);
+                            const int oi = fd_div(rem, e_w);
+                            const int oj = rem - oi * ep.OW;
+                            row = (size_t)img * ep.o_HW + (size_t)(oi * ep.o_step + ep.o_a) * ep.o_W + oj * ep.o_step + ep.o_b;
                         }
-                        if (staged) {
-                            ot[(row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OLD + col_w + j * 32 + li] = sscg_act(pre, p.act, p.slope);
-                        } else {
-                            size_t row = (size_t)m;
-                            if (p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
-                                const int img = fd_div(m, p.div_hw);
-                                const int rem = m - img * (p.OH * p.OW);
-                                const int oi = fd_div(rem, p.div_w);
-                                const int oj = rem - oi * p.OW;
-                                row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
-                            }
-                            p.dst[row * p.Ng + n] = sscg_act(pre, p.act, p.slope);
-                        }
+                        ep.dst[row * ep.Ng + n] = v;
                     }
                 }
             }
@@ -698,23 +727,23 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                     sr[0] = s0; sr[1] = q0; sr[2] = s1; sr[3] = q1;
                 }
             } else if (lh == 0 && nok) {
-                double* rec = p.stats + ((size_t)(tile_m * WM + wm) * 2) * p.Ng * 2;
+                double* rec = ep.stats + ((size_t)(tile_m * WM + wm) * 2) * ep.Ng * 2;
                 rec[(size_t)n * 2] = s0; rec[(size_t)n * 2 + 1] = q0;
-                rec[((size_t)p.Ng + n) * 2] = s1; rec[((size_t)p.Ng + n) * 2 + 1] = q1;
+                rec[((size_t)ep.Ng + n) * 2] = s1; rec[((size_t)ep.Ng + n) * 2 + 1] = q1;
             }
         }
     }
     if (fold && want_stats) {
         // ONE record per tile ([tile row][2 slots][Ng][2] doubles): the wave rows' sums meet in LDS, in wave-row order
         __syncthreads();
-        if (tid < BN && n0 + tid < p.Ng) {
+        if (tid < BN && n0 + tid < ep.Ng) {
             const double* sr = reinterpret_cast<const double*>(smem_raw + SREC_OFF) + (size_t)tid * 4;
             double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { a += sr[w * BN * 4]; b += sr[w * BN * 4 + 1]; c += sr[w * BN * 4 + 2]; d += sr[w * BN * 4 + 3]; }
-            double* rec = p.stats + ((size_t)tile_m * 2 * p.Ng + (n0 + tid)) * 2;
+            double* rec = ep.stats + ((size_t)tile_m * 2 * ep.Ng + (n0 + tid)) * 2;
             st_agent(rec, a); st_agent(rec + 1, b);
-            st_agent(rec + (size_t)p.Ng * 2, c); st_agent(rec + (size_t)p.Ng * 2 + 1, d);
+            st_agent(rec + (size_t)ep.Ng * 2, c); st_agent(rec + (size_t)ep.Ng * 2 + 1, d);
         }
     }
     if (staged) {
@@ -728,34 +757,36 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
         // result leaves - over the thread's <= BM / RPP rows in fp32 (per group: a tile meets at most one group boundary), then in
         // fp64 across the RPP row lanes.  One record per tile and group.
         f32x4 mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f, ga = 1.f, be = 0.f, sl = 0.f, ql = 0.f, sh = 0.f, qh = 0.f;
-        if (want_bsums && n < p.Ng) {
-            mu0 = *reinterpret_cast<const f32x4*>(p.bn_mean + (size_t)bg * p.Ng + n);
-            rs0 = *reinterpret_cast<const f32x4*>(p.bn_rstd + (size_t)bg * p.Ng + n);
-            if (bg + 1 < p.bn_G) {
-                mu1 = *reinterpret_cast<const f32x4*>(p.bn_mean + (size_t)(bg + 1) * p.Ng + n);
-                rs1 = *reinterpret_cast<const f32x4*>(p.bn_rstd + (size_t)(bg + 1) * p.Ng + n);
+        if (want_bsums && n < ep.Ng) {
+            mu0 = *reinterpret_cast<const f32x4*>(ep.bn_mean + (size_t)bg * ep.Ng + n);
+            rs0 = *reinterpret_cast<const f32x4*>(ep.bn_rstd + (size_t)bg * ep.Ng + n);
+            if (bg + 1 < ep.bn_G) {
+                mu1 = *reinterpret_cast<const f32x4*>(ep.bn_mean + (size_t)(bg + 1) * ep.Ng + n);
+                rs1 = *reinterpret_cast<const f32x4*>(ep.bn_rstd + (size_t)(bg + 1) * ep.Ng + n);
             }
-            if (p.bn_gamma) { ga = *reinterpret_cast<const f32x4*>(p.bn_gamma + n); be = *reinterpret_cast<const f32x4*>(p.bn_beta + n); }
+            if (ep.bn_gamma) { ga = *reinterpret_cast<const f32x4*>(ep.bn_gamma + n); be = *reinterpret_cast<const f32x4*>(ep.bn_beta + n); }
         }
         auto out_row = [&](int m) -> size_t {
-            if (p.o_step == 1) return (size_t)m;
-            const int img = fd_div(m, p.div_hw);      // parity class of a strided data gradient: rows interleave into dx
-            const int rem = m - img * (p.OH * p.OW);
-            const int oi = fd_div(rem, p.div_w);
-            const int oj = rem - oi * p.OW;
-            return (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
+            if (MODE == MODE_FWD || ep.o_step == 1) return (size_t)m;
+            const int img = fd_div(m, e_hw);      // parity class of a strided data gradient: rows interleave into dx
+            const int rem = m - img * (ep.OH * ep.OW);
+            const int oi = fd_div(rem, e_w);
+            const int oj = rem - oi * ep.OW;
+            return (size_t)img * ep.o_HW + (size_t)(oi * ep.o_step + ep.o_a) * ep.o_W + oj * ep.o_step + ep.o_b;
         };
-        const bool joins = MODE == MODE_DGRAD && (want_bsums || p.addend != nullptr);
-        if (n < p.Ng && !joins) {               // (Ng % 4 == 0: a 16-byte piece is inside the row or outside it)
+        const bool joins = MODE == MODE_DGRAD && !partial && (want_bsums || ep.addend != nullptr);
+        // (a partial tile of a split-K tail goes to its slice of the workspace, rows counted from the tail's first)
+        float* const obase = partial ? ep.part + ((long)split * (ep.M - ep.m_tail0) - ep.m_tail0) * (long)ep.Ng : ep.dst;
+        if (n < ep.Ng && !joins) {               // (Ng % 4 == 0: a 16-byte piece is inside the row or outside it)
 #pragma unroll
             for (int ps = 0; ps < BM / RPP; ++ps) {
                 const int r = tid / TPR + ps * RPP;
                 const int m = m0 + r;
-                if (m >= p.M) break;
-                *reinterpret_cast<f32x4*>(p.dst + out_row(m) * p.Ng + n) = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
+                if (m >= ep.M) break;
+                *reinterpret_cast<f32x4*>(obase + out_row(m) * ep.Ng + n) = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
             }
         }
-        if (n < p.Ng && joins) {
+        if (n < ep.Ng && joins) {
             // the addend, the layer's input and the mask source of FOUR rows are requested before the first is used: taken row by
             // row the store phase waited one memory latency per row (the 128x64 data-gradient class went from 88 to 107 us)
             constexpr int PSN = BM / RPP;
@@ -768,12 +799,12 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                 for (int q = 0; q < 4; ++q) {
                     const int m = m0 + tid / TPR + (h + q) * RPP;
                     av[q] = 0.f; yv[q] = 0.f; zv[q] = 0.f; rows[q] = 0;
-                    if (m < p.M) {
+                    if (m < ep.M) {
                         rows[q] = out_row(m);
-                        if (p.addend) av[q] = *reinterpret_cast<const f32x4*>(p.addend + rows[q] * p.Ng + n);
+                        if (ep.addend) av[q] = *reinterpret_cast<const f32x4*>(ep.addend + rows[q] * ep.Ng + n);
                         if (want_bsums) {
-                            yv[q] = *reinterpret_cast<const f32x4*>(p.bn_x + (size_t)m * p.Ng + n);
-                            if (p.bn_z) zv[q] = *reinterpret_cast<const f32x4*>(p.bn_z + (size_t)m * p.Ng + n);
+                            yv[q] = *reinterpret_cast<const f32x4*>(ep.bn_x + (size_t)m * ep.Ng + n);
+                            if (ep.bn_z) zv[q] = *reinterpret_cast<const f32x4*>(ep.bn_z + (size_t)m * ep.Ng + n);
                         }
                     }
                 }
@@ -781,18 +812,18 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                 for (int q = 0; q < 4; ++q) {
                     const int r = tid / TPR + (h + q) * RPP;
                     const int m = m0 + r;
-                    if (m >= p.M) break;
+                    if (m >= ep.M) break;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4) + av[q];
-                    *reinterpret_cast<f32x4*>(p.dst + rows[q] * p.Ng + n) = v;
+                    *reinterpret_cast<f32x4*>(ep.dst + rows[q] * ep.Ng + n) = v;
                     if (want_bsums) {
                         const bool lo = m < gb;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float xh = (yv[q][e] - (lo ? mu0[e] : mu1[e])) * (lo ? rs0[e] : rs1[e]);
-                            const float ym = p.bn_z ? zv[q][e] : xh * ga[e] + be[e];       // (sign of the output = sign of the pre-activation)
+                            const float ym = ep.bn_z ? zv[q][e] : xh * ga[e] + be[e];       // (sign of the output = sign of the pre-activation)
                             float gg = v[e];
-                            if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? gg : 0.f;
-                            else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? gg : gg * p.bn_slope;
+                            if (ep.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? gg : 0.f;
+                            else if (ep.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? gg : gg * ep.bn_slope;
                             if (lo) { sl[e] += gg; ql[e] = fmaf(gg, xh, ql[e]); } else { sh[e] += gg; qh[e] = fmaf(gg, xh, qh[e]); }
                         }
                     }
@@ -802,12 +833,12 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
         if (want_bsums) {
             __syncthreads();                    // the staged tile is dead: its LDS takes the row lanes' partial sums [RPP][BN][4]
             f32x4* ps4 = reinterpret_cast<f32x4*>(smem_raw);
-            if (n < p.Ng) {
+            if (n < ep.Ng) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ps4[(tid / TPR) * BN + c4 + e] = f32x4{sl[e], ql[e], sh[e], qh[e]};
             }
             __syncthreads();
-            if (tid < BN && n0 + tid < p.Ng) {
+            if (tid < BN && n0 + tid < ep.Ng) {
                 double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
 #pragma unroll 4
                 for (int rl = 0; rl < RPP; ++rl) {
@@ -815,11 +846,11 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                     a += (double)t[0]; b += (double)t[1]; c += (double)t[2]; d += (double)t[3];
                 }
                 const int nn = n0 + tid;
-                const int k0 = tile_m - (int)(((long)bg * p.bn_L) / BM);          // chunk of group g = tile row - first tile row of g
-                double* r0 = p.bn_sums + (((size_t)bg * p.bn_chunks + k0) * p.Ng + nn) * 2;
+                const int k0 = tile_m - (int)(((long)bg * ep.bn_L) / BM);          // chunk of group g = tile row - first tile row of g
+                double* r0 = ep.bn_sums + (((size_t)bg * ep.bn_chunks + k0) * ep.Ng + nn) * 2;
                 if (fold) { st_agent(r0, a); st_agent(r0 + 1, b); } else { r0[0] = a; r0[1] = b; }
-                if (m0 + BM > gb && bg + 1 < p.bn_G) {          // the tile straddles into group g + 1: it is that group's first tile
-                    double* r1 = p.bn_sums + ((size_t)(bg + 1) * p.bn_chunks * p.Ng + nn) * 2;
+                if (m0 + BM > gb && bg + 1 < ep.bn_G) {          // the tile straddles into group g + 1: it is that group's first tile
+                    double* r1 = ep.bn_sums + ((size_t)(bg + 1) * ep.bn_chunks * ep.Ng + nn) * 2;
                     if (fold) { st_agent(r1, c); st_agent(r1 + 1, d); } else { r1[0] = c; r1[1] = d; }
                 }
             }
@@ -827,35 +858,35 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     }
 
     // ---- column tails: the last tile of this column block finishes the layer's statistics / backward coefficients for its channels
-    if (fold && (p.stats != nullptr || want_bsums)) {
-        if (!last_arrival(p.tickets + tile_n, p.tiles_m, &s_flag)) return;
-        if (tid == 0) st_agent(p.tickets + tile_n, 0);
+    if (fold && (ep.stats != nullptr || want_bsums)) {
+        if (!last_arrival(ep.tickets + tile_n, ep.tiles_m, &s_flag)) return;
+        if (tid == 0) st_agent(ep.tickets + tile_n, 0);
         constexpr int NL = NT / BN;             // record lanes per channel
         const int c = tid % BN, lane = tid / BN;
         const int n = n0 + c;
-        const bool nok = n < p.Ng;
+        const bool nok = n < ep.Ng;
         double* const sm = reinterpret_cast<double*>(smem_raw);      // [NL][BN][2] (every other use of the LDS is over)
         double tg = 0.0, tb = 0.0;
-        for (int g = 0; g < p.fin_G; ++g) {     // (groups in order: the running statistics see them as successive forwards would)
+        for (int g = 0; g < ep.fin_G; ++g) {     // (groups in order: the running statistics see them as successive forwards would)
             double s = 0.0, q = 0.0;
             const double* base;
             int cnt;
             size_t stride;
             if (want_bsums) {
-                const int tf = (int)(((long)g * p.bn_L) / BM);
-                cnt = (int)((((long)(g + 1) * p.bn_L + BM - 1) / BM) - tf);
-                base = p.bn_sums + ((size_t)g * p.bn_chunks * p.Ng + n) * 2;
-                stride = (size_t)p.Ng * 2;
+                const int tf = (int)(((long)g * ep.bn_L) / BM);
+                cnt = (int)((((long)(g + 1) * ep.bn_L + BM - 1) / BM) - tf);
+                base = ep.bn_sums + ((size_t)g * ep.bn_chunks * ep.Ng + n) * 2;
+                stride = (size_t)ep.Ng * 2;
             } else {
-                const long lo = (long)g * p.stat_L, hi = lo + p.stat_L;
+                const long lo = (long)g * ep.stat_L, hi = lo + ep.stat_L;
                 const int t_first = (int)((lo + BM - 1) / BM);
                 int t_last = (int)((hi + BM - 1) / BM) - 1;
-                if (t_last > p.tiles_m - 1) t_last = p.tiles_m - 1;
+                if (t_last > ep.tiles_m - 1) t_last = ep.tiles_m - 1;
                 cnt = t_last - t_first + 1;                      // slot-0 records of the tiles that start inside the group
-                base = p.stats + ((size_t)t_first * 2 * p.Ng + n) * 2;
-                stride = (size_t)2 * p.Ng * 2;
+                base = ep.stats + ((size_t)t_first * 2 * ep.Ng + n) * 2;
+                stride = (size_t)2 * ep.Ng * 2;
                 if (nok && lane == 0 && g > 0 && t_first >= 1) {             // slot 1 of the tile that straddles the group's lower boundary
-                    const double* r1 = p.stats + (((size_t)(t_first - 1) * 2 + 1) * p.Ng + n) * 2;
+                    const double* r1 = ep.stats + (((size_t)(t_first - 1) * 2 + 1) * ep.Ng + n) * 2;
                     s += ld_agent(r1); q += ld_agent(r1 + 1);
                 }
             }
@@ -881,30 +912,30 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                 double a = 0.0, b = 0.0;
 #pragma unroll
                 for (int l = 0; l < NL; ++l) { a += sm[(l * BN + c) * 2]; b += sm[(l * BN + c) * 2 + 1]; }
-                const size_t i = (size_t)g * p.Ng + n;
+                const size_t i = (size_t)g * ep.Ng + n;
                 if (want_bsums) {
-                    p.fin_coef[i * 2] = (float)(a / (double)p.bn_L);
-                    p.fin_coef[i * 2 + 1] = (float)(b / (double)p.bn_L);
+                    ep.fin_coef[i * 2] = (float)(a / (double)ep.bn_L);
+                    ep.fin_coef[i * 2 + 1] = (float)(b / (double)ep.bn_L);
                     tb += a; tg += b;
                 } else {
-                    const double L = (double)p.stat_L;
+                    const double L = (double)ep.stat_L;
                     const double mu = a / L;
                     double var = b / L - mu * mu;
                     if (var < 0.0) var = 0.0;
-                    p.fin_mean[i] = (float)mu;
-                    p.fin_rstd[i] = (float)(1.0 / sqrt(var + (double)p.fin_eps));
-                    if (p.fin_rmean) {
-                        const double unb = p.stat_L > 1 ? var * L / (L - 1.0) : var;
-                        p.fin_rmean[n] = (float)((1.0 - (double)p.fin_momentum) * (double)p.fin_rmean[n] + (double)p.fin_momentum * mu);
-                        p.fin_rvar[n] = (float)((1.0 - (double)p.fin_momentum) * (double)p.fin_rvar[n] + (double)p.fin_momentum * unb);
+                    ep.fin_mean[i] = (float)mu;
+                    ep.fin_rstd[i] = (float)(1.0 / sqrt(var + (double)ep.fin_eps));
+                    if (ep.fin_rmean) {
+                        const double unb = ep.stat_L > 1 ? var * L / (L - 1.0) : var;
+                        ep.fin_rmean[n] = (float)((1.0 - (double)ep.fin_momentum) * (double)ep.fin_rmean[n] + (double)ep.fin_momentum * mu);
+                        ep.fin_rvar[n] = (float)((1.0 - (double)ep.fin_momentum) * (double)ep.fin_rvar[n] + (double)ep.fin_momentum * unb);
                     }
                 }
             }
             __syncthreads();
         }
         if (want_bsums && lane == 0 && nok) {
-            if (p.fin_dgamma) p.fin_dgamma[n] = (float)tg;
-            if (p.fin_dbeta) p.fin_dbeta[n] = (float)tb;
+            if (ep.fin_dgamma) ep.fin_dgamma[n] = (float)tg;
+            if (ep.fin_dbeta) ep.fin_dbeta[n] = (float)tb;
         }
     }
 }
@@ -949,7 +980,7 @@ const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2, 4, 4, 2};  // wave rows of a tile = s
 // The two-wave-group form of the 128x64 tile is built and tested but OFF by default: alone it hides the exposed waits of a launch
 // with one workgroup per CU, but in the four-lane step it costs +4 ms (135.2 against 131.1 ms, interleaved A/B on one box, round 5):
 // 112 KB of LDS and 2 x 208 registers per SIMD leave no room for the other lanes' workgroups on that CU, and those - not idle issue
-// slots - are what fills the chip in the step.  SSCG_KS_K2=1 switches it on (tools/convs_bench.py).
+// slots - are what fills the chip in the stq.  SSCG_KS_K2=1 switches it on (tools/convs_bench.py).
 static int ks_k2_or(int cfg, long tiles, int Ktot) {
     static const int on = getenv("SSCG_KS_K2") ? atoi(getenv("SSCG_KS_K2")) : 0;
     return (on && cfg == KS_128x64 && tiles <= 384 && Ktot >= 1024) ? KS_128x64_K2 : cfg;
@@ -975,6 +1006,7 @@ static int ks_choose_plan(long M, int Ng, int Ktot, int tuning) {
     static const int K128 = ks_env("SSCG_KS_K128", 512);               // min reduction length for the 128x128 class
     static const int K12864 = ks_env("SSCG_KS_K12864", 1024);          // min reduction length for the 128x64 class
     static const int T12864 = ks_env("SSCG_KS_T12864", 0);             // min 128x64 tiles for that class (0: no condition)
+    if (Ng & 3) return KS_128x32;         // the only class that stores element by element (rows of Ng floats are no multiple of 16 bytes)
     const int forced = (tuning & 0xff) - 1;
     if (forced >= 0 && forced < KS_NCFG && Ng >= KS_BN[forced] / 2) return forced;
     const long tm = cdiv(M, 128);
