@@ -264,12 +264,9 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
             const int tx = ax0[ps] - tdx;
             if (p.stride == 1) {
                 sy = ty; sx = tx;
-            } else if (p.stride == 2) {
+            } else {                    // stride 2 (sscg_convs_dgrad_applies: larger strides stay on conv_igemm.hip's kernel)
                 sy = ty >> 1; sx = tx >> 1;
                 ok = ok && (((ty | tx) & 1) == 0);
-            } else {
-                sy = ty / p.stride; sx = tx / p.stride;
-                ok = ok && (ty >= 0) && (tx >= 0) && (sy * p.stride == ty) && (sx * p.stride == tx);
             }
         }
         ok = ok && ((unsigned)sy < (unsigned)p.SH) && ((unsigned)sx < (unsigned)p.SW);
@@ -665,6 +662,10 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     // everywhere else the tile - a partial one of a split-K tail too - leaves through LDS as 16-byte row segments
     constexpr bool ANY_NG = BN == 32;
     const bool staged = KS_STAGE_OUT && (!ANY_NG || (ep.Ng & 3) == 0);
+    // the few tiles that straddle a group boundary or the tensor's end take their statistics element by element in fp64: from the STAGED
+    // tile, in a loop over its rows (store phase below) - in registers (64 unrolled fp64 updates per wave tile) only where nothing is staged
+    const bool reg_slow = slow_stats && !staged;
+    const bool reg_stats = fast_stats || reg_slow;
     if (staged || (fold && want_stats)) __syncthreads();           // every wave has read its last fragments
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const float pre = acc[i][j][e] + bv;
-                if (slow_stats && m < ep.M && nok) {
+                if (reg_slow && m < ep.M && nok) {
                     const double d = (double)pre;
                     if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
                 }
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                 }
             }
         }
-        if (want_stats) {
+        if (reg_stats) {
             s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);      // the lane halves hold different rows of a column
             s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
             if (fold) {
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
             }
         }
     }
-    if (fold && want_stats) {
+    if (fold && reg_stats) {
         // ONE record per tile ([tile row][2 slots][Ng][2] doubles): the wave rows' sums meet in LDS, in wave-row order
         __syncthreads();
         if (tid < BN && n0 + tid < ep.Ng) {
@@ -748,6 +749,38 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     }
     if (staged) {
         __syncthreads();
+        if (slow_stats) {               // (workgroup-uniform; the statistics launches carry no activation: the staged tile holds y + bias)
+            constexpr int NLS = NT / BN;
+            const int c = tid % BN, ln = tid / BN;
+            double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+            for (int r = ln; r < BM; r += NLS) {
+                const int m = m0 + r;
+                if (m >= ep.M) break;
+                const double d = (double)ot[r * OLD + c];
+                if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
+            }
+            double* const sr = reinterpret_cast<double*>(smem_raw + SREC_OFF);
+            sr[(ln * BN + c) * 4] = s0; sr[(ln * BN + c) * 4 + 1] = q0; sr[(ln * BN + c) * 4 + 2] = s1; sr[(ln * BN + c) * 4 + 3] = q1;
+            __syncthreads();
+            if (tid < BN && n0 + tid < ep.Ng) {
+                double a = 0.0, b = 0.0, cc = 0.0, d = 0.0;
+#pragma unroll
+                for (int l = 0; l < NLS; ++l) { a += sr[(l * BN + tid) * 4]; b += sr[(l * BN + tid) * 4 + 1]; cc += sr[(l * BN + tid) * 4 + 2]; d += sr[(l * BN + tid) * 4 + 3]; }
+                const int nn = n0 + tid;
+                if (fold) {
+                    double* rec = ep.stats + ((size_t)tile_m * 2 * ep.Ng + nn) * 2;
+                    st_agent(rec, a); st_agent(rec + 1, b);
+                    st_agent(rec + (size_t)ep.Ng * 2, cc); st_agent(rec + (size_t)ep.Ng * 2 + 1, d);
+                } else {                // the tile's total in its first wave row's record, zeros in the others
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) {
+                        double* rec = ep.stats + ((size_t)(tile_m * WM + w) * 2) * ep.Ng * 2;
+                        rec[(size_t)nn * 2] = w ? 0.0 : a; rec[(size_t)nn * 2 + 1] = w ? 0.0 : b;
+                        rec[((size_t)ep.Ng + nn) * 2] = w ? 0.0 : cc; rec[((size_t)ep.Ng + nn) * 2 + 1] = w ? 0.0 : d;
+                    }
+                }
+            }
+        }
         constexpr int TPR = BN / 4;             // threads per row (four channels = 16 bytes each)
         constexpr int RPP = NT / TPR;           // rows per pass
         const int c4 = (tid % TPR) * 4;
@@ -791,8 +824,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
             // row the store phase waited one memory latency per row (the 128x64 data-gradient class went from 88 to 107 us)
             constexpr int PSN = BM / RPP;
             static_assert(PSN % 4 == 0, "rows per thread");
-#pragma unroll
-            for (int h = 0; h < PSN; h += 4) {
+#pragma unroll 1
+            for (int h = 0; h < PSN; h += 4) {          // (rolled: the body - twelve 16-byte loads in flight, four rows of sums - is the launch's largest block of code)
                 f32x4 av[4], yv[4], zv[4];
                 size_t rows[4];
 #pragma unroll
@@ -1200,7 +1233,7 @@ bool sscg_convs_fwd_applies(const sscg_conv_desc* d) {
 
 bool sscg_convs_dgrad_applies(const sscg_conv_desc* d) {
     return d->y_dtype == SSCG_F32 && d->w_dtype == SSCG_BF16X3 && d->x_dtype == SSCG_F32 && d->K % BKS == 0 && d->K <= 4096 && d->C >= 32 && d->C % 4 == 0 &&
-           d->pad_mode == 0 && ks_extents_ok(d, true);
+           d->pad_mode == 0 && d->stride <= 2 && ks_extents_ok(d, true);
 }
 
 bool sscg_convs_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* wm, int* tiles_n, int* splits, int* full_tiles, int* m_tail0) {
