@@ -84,7 +84,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }      // orders the consumer behind the wait above it
 
-template <int MODE, int WM, int WN, int TM, int TN, int NSTAGE>
+// BS: the data gradient also takes the backward sums of the normalisation layer in front (its own instances: the sums' code - per
+// element loads of the layer's input, two accumulation paths - otherwise rides in every data-gradient launch's epilogue)
+template <int MODE, int WM, int WN, int TM, int TN, int NSTAGE, bool BS = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 2) void conv16_kernel(K16Params p) {
     constexpr int NT = WM * WN * 64;          // 4 waves (256 threads) or 8 waves (512)
     constexpr int BM = WM * TM * 32;
@@ -374,8 +376,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
     // Fused normalisation statistics (InstanceNorm / BatchNorm of the layer that follows, arch/ops.py:40-57): column sums of
     // x and x^2 over this tile's rows, taken from the fp32 accumulators (+ bias), in fp64; a tile may straddle ONE group
     // boundary (rows m < gb belong to the tile's first group, the rest to the next one).
-    const bool want_stats = p.stats != nullptr && !partial;
-    const bool want_bsums = MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (the host plans these launches without split-K)
+    const bool want_stats = MODE == MODE_FWD && p.stats != nullptr && !partial;      // (a data gradient never takes forward statistics)
+    const bool want_bsums = BS && MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (the host plans these launches without split-K)
     int gb = 0x7fffffff;
     if (want_stats) {
         const int g0 = m0 / p.stat_L;
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         bf16* out = reinterpret_cast<bf16*>(p.dst);
         const uint32_t* src = ot + (tid / TPR) * OLD + c8;
         auto out_row = [&](int m) -> size_t {
-            if (p.o_step == 1) return (size_t)m;
+            if (MODE == MODE_FWD || p.o_step == 1) return (size_t)m;
             const int img = m / (p.OH * p.OW);          // parity class of a strided data gradient: rows interleave into dx
             const int rem = m - img * (p.OH * p.OW);
             const int oi = rem / p.OW;
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                             if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
                         }
                         size_t row = (size_t)m;
-                        if (p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
+                        if (MODE == MODE_DGRAD && p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
                             const int img = m / (p.OH * p.OW);
                             const int rem = m - img * (p.OH * p.OW);
                             const int oi = rem / p.OW;
@@ -731,7 +733,7 @@ size_t split16_bytes(const K16Split& sp, long M, int Ng) {
     return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, int NSTAGE>
+template <int MODE, int WM, int WN, int TM, int TN, int NSTAGE, bool BS = false>
 int launch16(const K16Params& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -743,7 +745,7 @@ int launch16(const K16Params& p0, hipStream_t st) {
     size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(bf16);
     const size_t stage = BN >= 64 ? (size_t)(BM / 2) * (BN + 4) * sizeof(uint32_t) : 0;      // output tile of the staged epilogue (bf16 row pairs)
     if (stage > smem) smem = stage;
-    auto kern = conv16_kernel<MODE, WM, WN, TM, TN, NSTAGE>;
+    auto kern = conv16_kernel<MODE, WM, WN, TM, TN, NSTAGE, BS>;
     SSCG_ENSURE_SMEM((kern), smem);
     if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
@@ -764,6 +766,17 @@ int launch16(const K16Params& p0, hipStream_t st) {
 
 template <int MODE>
 int dispatch16(const K16Params& p, int tuning, hipStream_t st) {
+    if (MODE == MODE_DGRAD && p.bn_sums != nullptr) {       // the instances that carry the backward sums' epilogue
+        switch (choose16(p.M, p.Ng, p.Ktot, tuning)) {
+            case CFG_128x128: return launch16<MODE_DGRAD, 2, 2, 2, 2, 2, true>(p, st);
+            case CFG_64x64: return launch16<MODE_DGRAD, 2, 2, 1, 1, 2, true>(p, st);
+            case CFG_128x32: return launch16<MODE_DGRAD, 4, 1, 1, 1, 2, true>(p, st);
+            case CFG_128x64: return launch16<MODE_DGRAD, 2, 2, 2, 1, 2, true>(p, st);
+            case CFG_128x128_W8: return launch16<MODE_DGRAD, 2, 4, 2, 1, 2, true>(p, st);
+            case CFG_256x128_W8: return launch16<MODE_DGRAD, 4, 2, 2, 2, 2, true>(p, st);
+            default: return SSCG_ERR_BAD_ARG;
+        }
+    }
     switch (choose16(p.M, p.Ng, p.Ktot, tuning)) {
         case CFG_128x128: return launch16<MODE, 2, 2, 2, 2, 2>(p, st);
         case CFG_64x64: return launch16<MODE, 2, 2, 1, 1, 2>(p, st);
