@@ -592,6 +592,34 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         }
         return;
     }
+    if (STAGE_OUT && partial && (p.Ng & 3) == 0) {
+        // A partial tile of a split-K tail (fp32 sums for the reduction pass) leaves through LDS as well: [row][BN + 4] floats, then
+        // 16-byte row segments (conv_split.hip: the tail's 100-200 workgroups are the launch's last; their MFMA-layout stores - 32 to
+        // 64 four-byte stores per lane, each wave-instruction touching 2 x 128 bytes - were what the launch ended on)
+        constexpr int OLDF = BN + 4;
+        float* otf = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    otf[(row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OLDF + col_w + j * 32 + li] = acc[i][j][e];
+        __syncthreads();
+        constexpr int TPRF = BN / 4, RPPF = NT / TPRF;
+        const int c4 = (tid % TPRF) * 4;
+        const int n = n0 + c4;
+        if (n < p.Ng) {
+            float* const base = p.part + ((long)split * (p.M - p.m_tail0) - p.m_tail0) * (long)p.Ng;
+#pragma unroll 4
+            for (int r = tid / TPRF; r < BM; r += RPPF) {
+                const int m = m0 + r;
+                if (m >= p.M) break;
+                *reinterpret_cast<f32x4*>(base + (size_t)m * p.Ng + n) = *reinterpret_cast<const f32x4*>(otf + r * OLDF + c4);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + col_w + j * 32 + li;
@@ -745,6 +773,8 @@ int launch16(const K16Params& p0, hipStream_t st) {
     size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(bf16);
     const size_t stage = BN >= 64 ? (size_t)(BM / 2) * (BN + 4) * sizeof(uint32_t) : 0;      // output tile of the staged epilogue (bf16 row pairs)
     if (stage > smem) smem = stage;
+    const size_t stage_f = (BN >= 64 && p.splits > 1) ? (size_t)BM * (BN + 4) * sizeof(float) : 0;      // fp32 tile of a split-K tail's partial workgroups
+    if (stage_f > smem) smem = stage_f;
     auto kern = conv16_kernel<MODE, WM, WN, TM, TN, NSTAGE, BS>;
     SSCG_ENSURE_SMEM((kern), smem);
     if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }

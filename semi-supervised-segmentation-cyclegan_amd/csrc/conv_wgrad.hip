@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
 }
 
 // dw[i] = beta * dw[i] + sum_s ws[s][i]  (fixed order => deterministic).  V floats per thread; the split loop is
-// unrolled so that 8 independent loads are in flight per thread (the kernel is a pure stream of splits * |dw| bytes).
+// unrolled so that 16 independent loads are in flight per thread (the kernel is a pure stream of splits * |dw| bytes; a 1x1 layer's
+// 256 K outputs are 256 workgroups = four waves per CU: 8 loads each left a third of the memory system's latency-bandwidth product unused).
 template <int V>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n, int splits,
                                                             float beta) {
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (i >= n) return;
     typedef float vec_t __attribute__((ext_vector_type(V)));
     vec_t s = 0.f;
-#pragma unroll 8
+#pragma unroll 16
     for (int k = 0; k < splits; ++k) s += *reinterpret_cast<const vec_t*>(ws + (size_t)k * n + i);
     vec_t* d = reinterpret_cast<vec_t*>(dw + i);
     *d = (beta != 0.f) ? beta * *d + s : s;
