@@ -932,7 +932,7 @@ extern "C" int sscg_conv2d_dgrad(const sscg_conv_desc* d, const void* dy, const 
     if (d->pad_mode != 0) return SSCG_ERR_UNSUPPORTED;
     if (sscg_thin1x1_dgrad_applies(d, bias, act)) return sscg_thin1x1_dgrad(d, dy, wt, dx, (hipStream_t)stream);
     if (sscg_conv16_dgrad_applies(d)) return sscg_conv16_dgrad(d, dy, wt, bias, dx, act, slope, ws, ws_bytes, (hipStream_t)stream);
-    if (sscg_convs_dgrad_applies(d)) return sscg_convs_dgrad(d, dy, wt, bias, dx, act, slope, ws, ws_bytes, (hipStream_t)stream);
+    if (sscg_convs_dgrad_applies(d) && act != SSCG_ACT_TANH) return sscg_convs_dgrad(d, dy, wt, bias, dx, act, slope, ws, ws_bytes, (hipStream_t)stream);      // (the split family's epilogue knows none / ReLU / LeakyReLU)
     if (d->y_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return SSCG_ERR_UNSUPPORTED;
     KcParams p = {};
     p.src = reinterpret_cast<const float*>(dy); p.wgt = reinterpret_cast<const float*>(wt); p.bias = bias; p.dst = dx;

@@ -130,6 +130,13 @@ template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_w
 __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
+// activations of this family's epilogue: none / ReLU / LeakyReLU (a tanh head has 3 output channels and never comes here -
+// sscg_convs_fwd_applies; its software expansion would sit 32-64 times in every instance's epilogue)
+__device__ __forceinline__ float ks_act(float v, int act, float slope) {
+    const float neg = act == SSCG_ACT_RELU ? 0.f : (act == SSCG_ACT_LRELU ? v * slope : v);
+    return v > 0.f ? v : neg;
+}
+
 // ---- agent-scope accessors and the "last arrival" ticket of the in-kernel tails
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -699,7 +706,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                     const double d = (double)pre;
                     if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
                 }
-                const float v = partial ? pre : sscg_act(pre, ep.act, ep.slope);
+                const float v = partial ? pre : ks_act(pre, ep.act, ep.slope);
                 if (staged) {           // (rows / columns past the tensor are staged too: the store phase drops them)
                     ot[(row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OLD + col_w + j * 32 + li] = v;
                 } else if (m < ep.M && nok) {
@@ -1228,7 +1235,7 @@ bool sscg_convs_fwd_applies(const sscg_conv_desc* d) {
     // (>= 16 output channels: the 128x32 class serves the 21 / 20-channel heads; 1- and 3-channel heads keep conv_igemm.hip's 4-column MFMA)
     static const bool heads = getenv("SSCG_KS_NO_HEADS") == nullptr;       // A/B aid: heads back on the exact kernel
     return d->x_dtype == SSCG_F32 && d->w_dtype == SSCG_BF16X3 && d->y_dtype == SSCG_F32 && d->C % BKS == 0 && d->C <= 4096 &&
-           (heads ? d->K >= 16 : (d->K >= 32 && d->K % 4 == 0)) && ks_extents_ok(d, false);
+           (heads ? d->K >= 16 : (d->K >= 32 && d->K % 4 == 0)) && d->act != SSCG_ACT_TANH && ks_extents_ok(d, false);
 }
 
 bool sscg_convs_dgrad_applies(const sscg_conv_desc* d) {
