@@ -373,6 +373,11 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
         ++f_chunk;
         f_k += BKS;
     };
+    // the first two k-tiles are requested HERE, before the matrix-core side is set up: the ~150 instructions of that set-up (fragment
+    // addresses, 32-64 accumulator registers to clear) run under the copies' latency instead of in front of it
+    const int nk = kt1 - kt0;
+    if (nk > 0) request_tile();               // tile 0 -> stage 0
+    if (nk > 1) request_tile();               // tile 1 -> stage 1
 
     // ---- matrix-core side
     const int lane = tid & 63;
@@ -501,15 +506,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    const int nk = kt1 - kt0;
     if (nk > 0) {
-        request_tile();                       // tile 0 -> stage 0
-        if (nk > 1) {
-            request_tile();                   // tile 1 -> stage 1
-            wait_vm<NPIECE>();
-        } else {
-            wait_vm<0>();
-        }
+        if (nk > 1) wait_vm<NPIECE>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         read_frags(0, 0, 0);
         wait_lgkm<0>();
