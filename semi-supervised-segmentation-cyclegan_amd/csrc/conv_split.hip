@@ -89,8 +89,6 @@ struct KsParams {
     float slope;
     int tiles_n, tiles;
     int splits, ksplit, full_tiles, m_tail0;
-    int from_part;                   // 1 = the tail's SECOND launch (one workgroup per tail tile, no k-loop): the partial tiles' sum, in split order,
-                                     // takes the accumulators' place in the staged tile and the tile goes through the epilogue as a whole one
     float* __restrict__ part;        // [splits][M - m_tail0][Ng] when splits > 1
     double* __restrict__ stats;      // fused normalisation statistics: [tiles_m * WM][2][Ng][2] doubles, or null
     int stat_L;
@@ -132,8 +130,8 @@ template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_w
 __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
-// activations of this family's epilogue: none / ReLU / LeakyReLU (a tanh head has 3 output channels and never comes here -
-// sscg_convs_fwd_applies; its software expansion would sit 32-64 times in every instance's epilogue)
+// activations of this family's epilogue: none / ReLU / LeakyReLU; tanh (the ResNet generators' 3- and 21-channel heads) only in the
+// heads' 32-column class - its software expansion would sit 32-64 times in every other instance's epilogue (sscg_convs_fwd_applies)
 __device__ __forceinline__ float ks_act(float v, int act, float slope) {
     const float neg = act == SSCG_ACT_RELU ? 0.f : (act == SSCG_ACT_LRELU ? v * slope : v);
     return v > 0.f ? v : neg;
@@ -187,9 +185,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     const int kgrp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NT)) : 0;
     int split = 0, tile;
     bool partial = false;
-    if (p.from_part) {
-        tile = p.full_tiles + (int)blockIdx.x;
-    } else if ((int)blockIdx.x < p.full_tiles) {
+    if ((int)blockIdx.x < p.full_tiles) {
         tile = xcd_remap(blockIdx.x, p.full_tiles);
     } else {
         const int ntail = p.tiles - p.full_tiles;
@@ -288,7 +284,6 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     const int nk_all = p.Ktot / BKS;                         // Cs % 32 == 0: a k-tile never straddles a tap
     int kt0 = partial ? split * p.ksplit : 0;
     int kt1 = partial ? min(nk_all, kt0 + p.ksplit) : nk_all;
-    if (p.from_part) kt1 = kt0;                              // (no reduction here: the partial tiles hold it)
     int nk_pad = 0;                                          // KG > 1: barriers of the longer group's loop
     if (KG > 1) {
         nk_pad = (kt1 - kt0 + 1) / 2;
@@ -619,6 +614,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     constexpr int SREC_OFF = BM * OLD * 4;     // in-kernel tails: the waves' statistics meet behind the staged tile, [WM][BN][4] doubles
     __shared__ int s_flag;
     const bool fold = KS_TAILS && KG == 1 && ep.tickets != nullptr;
+    const bool want_bsums = MODE == MODE_DGRAD && ep.bn_sums != nullptr;        // (never with split-K: the host plans these launches unsplit)
     float* const ot = reinterpret_cast<float*>(smem_raw);
     if (partial && fold) {
         // ---- tail tile, in-kernel: every partial workgroup leaves its accumulators in the workspace; the LAST of the tile's `splits`
@@ -661,12 +657,11 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
         partial = false;
     }
     const bool want_stats = MODE == MODE_FWD && ep.stats != nullptr && !partial;      // (a data gradient never takes forward statistics)
-    const bool want_bsums = MODE == MODE_DGRAD && ep.bn_sums != nullptr && !partial;  // (a partial tile's rows get theirs in the tail's second launch)
     int gb = 0x7fffffff;
     if (want_stats) gb = (fd_div(m0, e_gl) + 1) * ep.stat_L;
     int bg = 0;
     if (want_bsums) { bg = fd_div(m0, e_gl); gb = (bg + 1) * ep.bn_L; }
-    const bool slow_stats = want_stats && (!KS_FAST_STATS || ep.from_part || m0 + BM > gb || m0 + BM > ep.M);
+    const bool slow_stats = want_stats && (!KS_FAST_STATS || m0 + BM > gb || m0 + BM > ep.M);
     const bool fast_stats = want_stats && !slow_stats;
     // Only the heads' class (32 columns) serves Ng % 4 != 0 (ks_choose routes such launches to it) and stores element by element then;
     // everywhere else the tile - a partial one of a split-K tail too - leaves through LDS as 16-byte row segments
@@ -677,34 +672,6 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     const bool reg_slow = slow_stats && !staged;
     const bool reg_stats = fast_stats || reg_slow;
     if (staged || (fold && want_stats)) __syncthreads();           // every wave has read its last fragments
-    if (ep.from_part) {
-        // the tail's second launch (staged classes only): thread t owns four channels of rows t / TPR + k * RPP, as in the store phase
-        constexpr int TPRF = BN / 4, RPPF = NT / TPRF, PSF = BM / RPPF;
-        const int c4f = (tid % TPRF) * 4;
-        const int nf = n0 + c4f;
-        if (nf < ep.Ng) {
-            f32x4 sum[PSF];
-#pragma unroll
-            for (int ps = 0; ps < PSF; ++ps) sum[ps] = 0.f;
-            const size_t slice = (size_t)(ep.M - ep.m_tail0) * ep.Ng;
-            const float* const p0 = ep.part + (size_t)(m0 - ep.m_tail0 + tid / TPRF) * ep.Ng + nf;
-#pragma unroll 2
-            for (int k = 0; k < ep.splits; ++k) {
-#pragma unroll
-                for (int ps = 0; ps < PSF; ++ps)
-                    if (m0 + tid / TPRF + ps * RPPF < ep.M) sum[ps] += *reinterpret_cast<const f32x4*>(p0 + k * slice + (size_t)ps * RPPF * ep.Ng);
-            }
-            f32x4 bv4 = 0.f;
-            if (ep.bias) bv4 = *reinterpret_cast<const f32x4*>(ep.bias + nf);
-#pragma unroll
-            for (int ps = 0; ps < PSF; ++ps) {
-                f32x4 v = sum[ps] + bv4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ks_act(v[e], ep.act, ep.slope);
-                *reinterpret_cast<f32x4*>(ot + (tid / TPRF + ps * RPPF) * OLD + c4f) = v;
-            }
-        }
-    } else
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + col_w + j * 32 + li;
@@ -737,7 +704,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                     const double d = (double)pre;
                     if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
                 }
-                const float v = partial ? pre : ks_act(pre, ep.act, ep.slope);
+                const float v = partial ? pre : (ANY_NG ? sscg_act(pre, ep.act, ep.slope) : ks_act(pre, ep.act, ep.slope));      // (tanh: the heads' class only)
                 if (staged) {           // (rows / columns past the tensor are staged too: the store phase drops them)
                     ot[(row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OLD + col_w + j * 32 + li] = v;
                 } else if (m < ep.M && nok) {
@@ -1140,9 +1107,6 @@ KsSplit ks_plan(long M, int Ng, int Ktot, int tuning, long stat_L = 0) {
     return r;
 }
 
-// the tail's second launch (convs_kernel with from_part) serves every class that stages its tiles: all but the heads' 32-column class
-bool ks_tail_relaunch(long M, int Ng, int Ktot, int tuning) { return (Ng & 3) == 0 && ks_choose(M, Ng, Ktot, tuning) != KS_128x32; }
-
 size_t ks_split_bytes(const KsSplit& sp, long M, int Ng) {
     return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
@@ -1175,15 +1139,7 @@ int launch_ks(const KsParams& p0, hipStream_t st) {
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);
     SSCG_LAUNCH_CHECK();
-    if (p.splits > 1 && !p.tickets && BN != 32 && (p.Ng & 3) == 0) {
-        // The tail's second launch - the same kernel, one workgroup per tail tile, no k-loop: the partial tiles' sum goes through the
-        // epilogue as a whole tile (bias, activation, the fan-in addend, normalisation statistics and backward sums included: launches
-        // that take backward sums keep their tail split, worth 7-27 us each - profiles/r05_experiments.txt item 17).
-        KsParams q = p;
-        q.from_part = 1;
-        hipLaunchKernelGGL(kern, dim3(p.tiles - p.full_tiles), dim3(NT), smem, st, q);
-        SSCG_LAUNCH_CHECK();
-    } else if (p.splits > 1 && !p.tickets) {     // (with tickets the tail tiles are finished inside the launch)
+    if (p.splits > 1 && !p.tickets) {     // (with tickets the tail tiles are finished inside the launch)
         const size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
         float* yt = p.dst + (size_t)p.m_tail0 * p.Ng;
         if (p.xstats)
@@ -1277,7 +1233,7 @@ bool sscg_convs_fwd_applies(const sscg_conv_desc* d) {
     // (>= 16 output channels: the 128x32 class serves the 21 / 20-channel heads; 1- and 3-channel heads keep conv_igemm.hip's 4-column MFMA)
     static const bool heads = getenv("SSCG_KS_NO_HEADS") == nullptr;       // A/B aid: heads back on the exact kernel
     return d->x_dtype == SSCG_F32 && d->w_dtype == SSCG_BF16X3 && d->y_dtype == SSCG_F32 && d->C % BKS == 0 && d->C <= 4096 &&
-           (heads ? d->K >= 16 : (d->K >= 32 && d->K % 4 == 0)) && d->act != SSCG_ACT_TANH && ks_extents_ok(d, false);
+           (heads ? d->K >= 16 : (d->K >= 32 && d->K % 4 == 0)) && (d->act != SSCG_ACT_TANH || d->K <= 32) && ks_extents_ok(d, false);
 }
 
 bool sscg_convs_dgrad_applies(const sscg_conv_desc* d) {
@@ -1292,10 +1248,6 @@ bool sscg_convs_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* wm
     *bm = KS_BM[cfg];
     *wm = KS_WM[cfg];
     *tiles_n = cdiv(d->K, KS_BN[cfg]);
-    if (ks_tail_relaunch(M, d->K, d->R * d->S * d->C, d->tuning)) {       // the tail tiles write their records like whole tiles (second launch)
-        *splits = 1; *full_tiles = cdiv(M, KS_BM[cfg]) * cdiv(d->K, KS_BN[cfg]); *m_tail0 = (int)M;
-        return true;
-    }
     KsSplit sp = ks_plan(M, d->K, d->R * d->S * d->C, d->tuning, L);
     *splits = sp.splits; *full_tiles = sp.full_tiles; *m_tail0 = sp.m_tail0;
     return true;
@@ -1326,8 +1278,7 @@ int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const 
     p.src_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->C * sizeof(float));
     p.wgt_bytes = (unsigned)(((size_t)2 * p.wplane + (size_t)d->K * d->R * d->S * d->C) * sizeof(bf16));
     ks_dense_taps(p);
-    // (statistics of a split tail: from its second launch for the staged classes - any group geometry; else one extra group of records)
-    KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, d->tuning, (stats && !ks_tail_relaunch(p.M, p.Ng, p.Ktot, d->tuning)) ? stat_L : 0);
+    KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, d->tuning, stats ? stat_L : 0);
     if (sp.splits > 1 && (!ws || ws_bytes < ks_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
@@ -1341,8 +1292,8 @@ int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const 
 }
 
 // Backward sums of the normalisation layer in front, from this data gradient's epilogue: plain stride-1 / dilated data gradients of the
-// split family, groups at least one tile tall (a tile then meets at most one group boundary).  A split-K tail keeps its split: the
-// tail's second launch (convs_kernel, from_part) takes the sums of those tiles.
+// split family, groups at least one tile tall (a tile then meets at most one group boundary).  The launch is planned WITHOUT the
+// tail split-K (its partial tiles would need the sums in the reduction as well).
 bool sscg_convs_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, int* wm, int* chunks) {
     if (!sscg_convs_dgrad_applies(d) || ks_dgrad_by_parity(d) || d->stride != 1) return false;
     const long M = (long)d->N * d->H * d->W;
@@ -1409,8 +1360,7 @@ int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, co
         }
         return SSCG_OK;
     }
-    // fused sums: the tail's second launch takes them for the tail tiles; the heads' class (its reduction pass knows no sums) stays unsplit
-    KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, (fused && !ks_tail_relaunch(p.M, p.Ng, p.Ktot, d->tuning)) ? ((d->tuning & 0xff) | 0x100) : d->tuning);
+    KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, fused ? ((d->tuning & 0xff) | 0x100) : d->tuning);     // fused sums: never split
     if (sp.splits > 1 && (!ws || ws_bytes < ks_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
