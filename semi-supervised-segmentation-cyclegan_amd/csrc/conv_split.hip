@@ -1042,6 +1042,8 @@ int ks_choose(long M, int Ng, int Ktot, int tuning) { return ks_w2_or(ks_choose_
 static int ks_choose_plan(long M, int Ng, int Ktot, int tuning) {
     static const int T128_SHORT = ks_env("SSCG_KS_T128_SHORT", 1024);   // min 128x128 tiles for that class on a short reduction
     static const int K128 = ks_env("SSCG_KS_K128", 512);               // min reduction length for the 128x128 class
+    static const int T128_NARROW = ks_env("SSCG_KS_T128_NARROW", 512);  // ... with one column block of 128x128 tiles (Ng <= 128)
+    static const int K128_NARROW = ks_env("SSCG_KS_K128_NARROW", 256);  // min reduction length for the 128x128 class where it has >= T128_SHORT / T128_NARROW tiles
     static const int K12864 = ks_env("SSCG_KS_K12864", 1024);          // min reduction length for the 128x64 class
     static const int T12864 = ks_env("SSCG_KS_T12864", 0);             // min 128x64 tiles for that class (0: no condition)
     if (Ng & 3) return KS_128x32;         // the only class that stores element by element (rows of Ng floats are no multiple of 16 bytes)
@@ -1049,10 +1051,13 @@ static int ks_choose_plan(long M, int Ng, int Ktot, int tuning) {
     if (forced >= 0 && forced < KS_NCFG && Ng >= KS_BN[forced] / 2) return forced;
     const long tm = cdiv(M, 128);
     if (Ng <= 32) return KS_128x32;       // heads: 21 / 20 output channels (the ResNet generators' 7x7 heads, the DeepLab classifiers)
-    if (Ng <= 64) return tm >= 384 ? KS_128x64 : KS_64x64;          // (>= 384 tiles: never the two-group form)
+    if (Ng <= 64) return tm >= 256 ? KS_128x64 : KS_64x64;          // (one 128x64 tile per CU and more; re-swept in round 5: 265-tile maps gain 4-10 %)
     const long t128 = tm * cdiv(Ng, 128);
-    if (Ng <= 128) return (t128 >= T128_SHORT && Ktot >= K128) ? KS_128x128 : KS_64x64;
-    if (t128 >= (Ktot >= 1024 ? 512 : T128_SHORT) && Ktot >= K128) return KS_128x128;
+    // (re-swept after the epilogue diet, profiles/r05_tile_classes_after_diet.txt: with a cheap epilogue the 128x128 class pays from 512
+    // tiles on for reductions of 512 and more - 256 for one column block -, from 1024 tiles on for 256, and from 4096 tiles on - the
+    // HBM-bound 524288-row maps of the PixelDiscriminator - whatever the reduction)
+    if (Ng <= 128) return ((t128 >= T128_NARROW && Ktot >= K128_NARROW) || t128 >= 4096) ? KS_128x128 : KS_64x64;
+    if (t128 >= (Ktot >= K128 ? 512 : T128_SHORT) && Ktot >= K128_NARROW) return KS_128x128;
     if (Ktot >= K12864 && tm * cdiv(Ng, 64) >= T12864) return ks_k2_or(KS_128x64, tm * cdiv(Ng, 64), Ktot);
     return KS_64x64;
 }

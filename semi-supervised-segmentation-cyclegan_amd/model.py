@@ -250,6 +250,7 @@ class semisuper_cycleGAN(object):
         if fork:
             with torch.cuda.stream(lane):
                 lane.wait_event(gsi_second)
+                fake_img_all = fake_img
                 fake_img, fake_img_d, fake_img_l1 = F.split(fake_img, 3)             # consumers: Gsi, Di, L1
                 self._mark("fork Gsi(fake_img): start")
                 recon_logits = self.Gsi(fake_img)                                    # :410
@@ -258,6 +259,7 @@ class semisuper_cycleGAN(object):
             fake_img.record_stream(main)
             recon_logits.record_stream(main)
         else:
+            fake_img_all = fake_img
             fake_img, fake_img_d, fake_img_l1 = F.split(fake_img, 3)                 # consumers: Gsi, Di, L1
             recon_logits = self.Gsi(fake_img)                                        # :410
         extra_terms, extra_weights, extras = [], [], {}
@@ -300,6 +302,12 @@ class semisuper_cycleGAN(object):
             [lab_loss_CE, lab_loss_MSE, img_gen_loss, gt_gen_loss, img_cycle_loss, gt_cycle_loss] + extra_terms,
             [a.lab_CE_weight, a.lab_MSE_weight, a.adversarial_weight, a.adversarial_weight, 1.0, a.lamda_gt] + extra_weights)
         self._mark("main: backward start")
+        if _PHASES:     # when each pass's backward STARTS (the gradient at its output arrives): host clock + an event on the stream the engine runs it on
+            for name, t in (("bwd: d recon_logits (fork Gsi(fake_img) backward starts)", recon_logits), ("bwd: d recon_img (main Gis(fake_gt) backward starts)", recon_img),
+                            ("bwd: d fake_img summed (fork Gis(onehot) backward starts)", fake_img_all), ("bwd: d fake_gt (main head + Gsi(unl, l) backward starts)", fake_gt),
+                            ("bwd: d lab_logits / fake_logits reached", fake_logits)):
+                if t is not None and t.requires_grad:
+                    t.register_hook(lambda g, name=name: self._mark(name))
         F.backward(gen_loss)                                                         # :472
         self._mark("main: backward issued / main's part done")
         if _UNUSED_AT == "late":
