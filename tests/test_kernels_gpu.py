@@ -1,5 +1,7 @@
 """Kernel-level parity: every HIP kernel (through the C ABI) against the torch CPU op the reference
 calls at that site, evaluated in fp64.  Tolerances are relative to the largest reference magnitude."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1407,3 +1409,21 @@ def test_in_kernel_tails_equal_the_separate_launches(case, F, dev):
     finally:
         F.TAILS[0] = was
         F.set_conv_precision("f32")
+
+
+@pytest.mark.gpu
+def test_tails_variant_build_folds_and_equals_the_separate_launches():
+    """The same assertions on the -DKS_TAILS=1 build of conv_split.hip (libsscg_tails.so, built by __graft_entry__.build()): there the
+    ABI v15 entry points really fold the tail tiles' reduction and the finalize step into the conv launch (tickets); the product build
+    compiles those paths out (measured slower) and issues the small launches itself.  In a process of its own (another library)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "semi-supervised-segmentation-cyclegan_amd", "libsscg_tails.so")
+    if not os.path.exists(lib):
+        pytest.skip("libsscg_tails.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = dict(os.environ, SSCG_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "in_kernel_tails_equal or every_tile_class or fused_store_phases"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]

@@ -21,7 +21,7 @@ SHAPES = [(32, 256, 64, 128, 256, 3, 1, 1, 1), (16, 256, 33, 65, 256, 3, 1, 2, 2
           (32, 64, 128, 256, 128, 3, 2, 1, 1), (32, 128, 64, 128, 256, 3, 2, 1, 1), (16, 64, 128, 256, 128, 4, 2, 1, 1),
           (16, 128, 64, 128, 256, 4, 2, 1, 1), (16, 256, 32, 64, 512, 4, 1, 1, 1)]
 # name, forced tile class (100 + cfg; 0xff = planner), tune flags (1 = LDS-DMA pieces spread over the MFMA groups)
-VARIANTS = [("plan", None, 0), ("128x128w8", 4, 0), ("64x64", 1, 0)]      # (name, forced tile class or None, -)
+VARIANTS = [("plan", None, 0), ("128x128w8", 4, 0), ("64x64", 1, 0), ("128x128", 0, 0), ("128x64", 3, 0)]      # (name, forced tile class or None, -)
 
 
 def timeit(fn, n=20):
