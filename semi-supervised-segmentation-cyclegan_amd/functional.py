@@ -2071,7 +2071,11 @@ def split_batch(x, k):
 
 
 def split(x, n=2):
-    """n aliases of x whose gradients are summed by `sscg_add` (no-op outside a gradient-recording forward)."""
+    """n aliases of x whose gradients are summed by `sscg_add` (no-op outside a gradient-recording forward).
+    CONTRACT: every alias has exactly ONE consumer (that is what the aliases are for: a tensor read by k nodes is split k ways).  With
+    n == 2 the second consumer's data gradient may add the first one's gradient in its own store phase (`_Join`); an alias that is read
+    twice after all breaks that bookkeeping - `_Join.deposit` notices the second deposit and leaves the sum to SplitFn.backward
+    (`broken`), and where the fold has already happened SplitFn.backward raises rather than return a silently wrong sum."""
     if n < 2 or not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * n
     join = _Join(n, getattr(x, "_sscg_norm", None)) if (FUSE_JOIN[0] and n == 2) else None
