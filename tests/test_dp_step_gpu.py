@@ -105,7 +105,10 @@ def test_dp_step_world_size_2_shared_gpu(dev, tmp_path):
     gradient kernel it depends on would change the bits below.  Both must reproduce ONE lockstep simulation bit for bit."""
     ctx = mp.get_context("spawn")
     runs = {}
-    for buckets in (0, 4):
+    # (the bucketed pair doubles the processes on the box - 100 s of the suite on a slow host: by default only where asked for;
+    # the bucketed exchange keeps its CPU world-2 test, tests/test_parallel_gloo.py, and its RCCL bitwise test, tests/test_schedule_gpu.py)
+    variants = (0, 4) if os.environ.get("SSCG_TEST_DP_BUCKETS_GLOO") == "1" else (0,)
+    for buckets in variants:
         out = tmp_path / ("b%d" % buckets)
         out.mkdir()
         port = _free_port()
@@ -117,12 +120,13 @@ def test_dp_step_world_size_2_shared_gpu(dev, tmp_path):
             p.join(900)
             assert p.exitcode == 0, "rank process failed (exit code %s, buckets %d)" % (p.exitcode, buckets)
     res = {b: (torch.load(str(out / "rank0.pt")), torch.load(str(out / "rank1.pt"))) for b, (out, _) in runs.items()}
-    r0, r1 = res[4]
-    # every bucket went out, in one order on both ranks, and not all of them from finish() (which walks them last-to-first
-    # after the backward)
-    assert r0["buckets"] == 4 and sorted(r0["bucket_order"]) == list(range(4)) and r0["bucket_order"] == r1["bucket_order"]
-    assert r0["bucket_order"] != [3, 2, 1, 0], r0["bucket_order"]
-    print("bucket launch order:", r0["bucket_order"])
+    if 4 in res:
+        r0, r1 = res[4]
+        # every bucket went out, in one order on both ranks, and not all of them from finish() (which walks them last-to-first
+        # after the backward)
+        assert r0["buckets"] == 4 and sorted(r0["bucket_order"]) == list(range(4)) and r0["bucket_order"] == r1["bucket_order"]
+        assert r0["bucket_order"] != [3, 2, 1, 0], r0["bucket_order"]
+        print("bucket launch order:", r0["bucket_order"])
     sim = None
     for buckets, (r0, r1) in res.items():
         sim = _check_against_lockstep(r0, r1, dev, sim)
