@@ -28,12 +28,19 @@ GRADS = ("d_fake_gt", "d_fake_img")
 def oracle_second_pass(tag, C, H, B):
     """fp64 first pass -> fp32-rounded forcing inputs -> the oracle's second pass in fp64 (truth) and fp32 (the reference's arithmetic)."""
     l_img, l_gt, unl_img = FX.step_batch(tag, 0, C, H, H, B)
-    o64 = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float64, tag), crop=(H, H))
-    fake_img, fake_gt, _ = o64.first_pass(l_img.double(), l_gt, unl_img.double(), want_lab=False)
-    fake_img, fake_gt = fake_img.float(), fake_gt.float()
-    r64 = o64.second_pass(fake_img.double(), fake_gt.double(), l_gt, unl_img.double())
-    o32 = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float32, tag), crop=(H, H))
-    r32 = o32.second_pass(fake_img, fake_gt, l_gt, unl_img)
+    # (torch's CPU convolutions on these small maps lose time beyond ~32 threads - bench.py's cpu_baseline measured 52 s per step on 128
+    # threads against 10.5 s on 64: the checker runs on at most 32)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))
+    try:
+        o64 = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float64, tag), crop=(H, H))
+        fake_img, fake_gt, _ = o64.first_pass(l_img.double(), l_gt, unl_img.double(), want_lab=False)
+        fake_img, fake_gt = fake_img.float(), fake_gt.float()
+        r64 = o64.second_pass(fake_img.double(), fake_gt.double(), l_gt, unl_img.double())
+        o32 = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float32, tag), crop=(H, H))
+        r32 = o32.second_pass(fake_img, fake_gt, l_gt, unl_img)
+    finally:
+        torch.set_num_threads(threads)
     return (l_img, l_gt, unl_img, fake_img, fake_gt), r64, r32
 
 
