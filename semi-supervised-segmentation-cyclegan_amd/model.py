@@ -201,6 +201,7 @@ class semisuper_cycleGAN(object):
             onehot_gt.record_stream(lane)
         elif not self.stack_gis:
             fake_img = self.interp(self.Gis(onehot_gt))                              # :385,390
+        fake_img_all = None
         if self.stack_gsi:
             # Gsi(unl_img) and Gsi(l_img) (:386-387) as ONE pass over both batches: every BatchNorm normalises the two
             # halves separately and advances its running statistics twice, in order (arch.batch_groups) - the same
