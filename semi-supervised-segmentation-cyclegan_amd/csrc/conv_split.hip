@@ -1040,7 +1040,8 @@ static int ks_choose_plan(long M, int Ng, int Ktot, int tuning);
 static int ks_w2_or(int cfg);
 int ks_choose(long M, int Ng, int Ktot, int tuning) { return ks_w2_or(ks_choose_plan(M, Ng, Ktot, tuning)); }
 static int ks_choose_plan(long M, int Ng, int Ktot, int tuning) {
-    static const int T128_SHORT = ks_env("SSCG_KS_T128_SHORT", 1024);   // min 128x128 tiles for that class on a short reduction
+    static const int T128_SHORT = ks_env("SSCG_KS_T128_SHORT", 512);    // min 128x128 tiles for that class on a short reduction (1024 until round 5: alone the
+                                                                        // 552-tile 1x1 256 -> 1024 is 8 % faster on 64x64 tiles, in the four-lane step the larger tiles win: -0.9 ms)
     static const int K128 = ks_env("SSCG_KS_K128", 512);               // min reduction length for the 128x128 class
     static const int T128_NARROW = ks_env("SSCG_KS_T128_NARROW", 512);  // ... with one column block of 128x128 tiles (Ng <= 128)
     static const int K128_NARROW = ks_env("SSCG_KS_K128_NARROW", 256);  // min reduction length for the 128x128 class where it has >= T128_SHORT / T128_NARROW tiles
@@ -1054,8 +1055,8 @@ static int ks_choose_plan(long M, int Ng, int Ktot, int tuning) {
     if (Ng <= 64) return tm >= 256 ? KS_128x64 : KS_64x64;          // (one 128x64 tile per CU and more; re-swept in round 5: 265-tile maps gain 4-10 %)
     const long t128 = tm * cdiv(Ng, 128);
     // (re-swept after the epilogue diet, profiles/r05_tile_classes_after_diet.txt: with a cheap epilogue the 128x128 class pays from 512
-    // tiles on for reductions of 512 and more - 256 for one column block -, from 1024 tiles on for 256, and from 4096 tiles on - the
-    // HBM-bound 524288-row maps of the PixelDiscriminator - whatever the reduction)
+    // tiles on for reductions of 256 and more, and from 4096 tiles on - the HBM-bound 524288-row maps of the PixelDiscriminator -
+    // whatever the reduction)
     if (Ng <= 128) return ((t128 >= T128_NARROW && Ktot >= K128_NARROW) || t128 >= 4096) ? KS_128x128 : KS_64x64;
     if (t128 >= (Ktot >= K128 ? 512 : T128_SHORT) && Ktot >= K128_NARROW) return KS_128x128;
     if (Ktot >= K12864 && tm * cdiv(Ng, 64) >= T12864) return ks_k2_or(KS_128x64, tm * cdiv(Ng, 64), Ktot);
