@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 15
+#define SSCG_ABI_VERSION 16
 
 /* element types of activation / weight tensors */
 #define SSCG_F32 0
@@ -186,28 +186,6 @@ int sscg_conv2d_dgrad_add(const sscg_conv_desc* d, const void* dy, const void* w
 int sscg_norm_bwd_from_sums(const sscg_conv_desc* d, const void* sums, const void* dy, const void* x, const void* y, const float* mean,
                             const float* rstd, const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta,
                             int dtype, int G, int64_t L, int C, int act, float slope, int flags, void* ws, size_t ws_bytes, void* stream);
-
-/* One call per "Conv -> norm" link in each direction (ABI v15; arch/ops.py:40-57, arch/generators.py:345-365): what the pairs
- * sscg_conv2d_fwd_stats + sscg_norm_stats_from_conv and sscg_conv2d_dgrad_bsums + the finalize half of sscg_norm_bwd_from_sums do,
- * with the small launches between them gone where the kernel family serves the geometry (fp32 tensors on the split family, maps
- * of at most 160 tile rows - DeepLab's 33x33 maps -, G <= 4): the tail tiles' split-K reduction and the layer's statistics /
- * backward coefficients are finished INSIDE the convolution launch by the last workgroup to arrive (tickets, fixed summation
- * order: bit-reproducible).  Elsewhere the same small launches as before are issued by the call itself.  Either way, on return
- * (stream order) mean / rstd (and the running statistics), resp. coef [G][C][2], dgamma [C], dbeta [C] (written) are complete.
- * tickets: SSCG_TAIL_TICKETS ints, zero before the call and left zero by it, that no other launch IN FLIGHT uses (one array per
- * stream is enough: launches of a stream do not overlap).  NULL = never fold.
- * sscg_norm_bwd_from_coef: the apply half of sscg_norm_bwd_from_sums (coef from sscg_conv2d_dgrad_bsums_fin). */
-#define SSCG_TAIL_TICKETS 1024
-int sscg_conv2d_fwd_norm_stats(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int G, int64_t L,
-                               void* stats, size_t stats_bytes, float eps, float* mean, float* rstd, float* running_mean,
-                               float* running_var, float momentum, int* tickets, void* ws, size_t ws_bytes, void* stream);
-int sscg_conv2d_dgrad_bsums_fin(const sscg_conv_desc* d, const void* dy, const void* wt, void* dx, const void* nx, const void* nz,
-                                const void* addend, const float* mean, const float* rstd, const float* gamma, const float* beta, int G,
-                                int64_t L, int act, float slope, void* sums, size_t sums_bytes, float* coef, float* dgamma, float* dbeta,
-                                int* tickets, void* ws, size_t ws_bytes, void* stream);
-int sscg_norm_bwd_from_coef(const float* coef, const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
-                            const float* gamma, const float* beta, void* dx, void* dres, int dtype, int G, int64_t L, int C, int act,
-                            float slope, void* stream);
 
 int sscg_rstd_from_var(const float* var, float* rstd, int n, float eps, void* stream);
 /* backward of norm_apply (+ of the statistics): dx always; dres (= masked dy) if non-NULL;

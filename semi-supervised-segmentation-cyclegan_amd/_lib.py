@@ -9,8 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 15
-TAIL_TICKETS = 1024      # SSCG_TAIL_TICKETS of include/sscg.h
+ABI_VERSION = 16
 
 F32, BF16, BF16X3 = 0, 1, 2     # SSCG_F32 / SSCG_BF16 / SSCG_BF16X3 (split weight operand)
 
@@ -57,9 +56,6 @@ SIGNATURES = {
     "sscg_conv2d_dgrad_add_applies": (_i, [_dp]),
     "sscg_conv2d_dgrad_add": (_i, [_dp, _p, _p, _p, _p, _p, _sz, _p]),
     "sscg_norm_bwd_from_sums": (_i, [_dp, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _p, _sz, _p]),
-    "sscg_conv2d_fwd_norm_stats": (_i, [_dp, _p, _p, _p, _p, _i, _i64, _p, _sz, _f, _p, _p, _p, _p, _f, _p, _p, _sz, _p]),
-    "sscg_conv2d_dgrad_bsums_fin": (_i, [_dp, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p, _sz, _p, _p, _p, _p, _p, _sz, _p]),
-    "sscg_norm_bwd_from_coef": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _p]),
     "sscg_conv2d_wgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_wgrad": (_i, [_dp, _p, _p, _p, _f, _p, _sz, _p]),
     "sscg_weight_krsc_to_crsk": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),

@@ -845,14 +845,13 @@ extern "C" size_t sscg_conv2d_fwd_stats_workspace(const sscg_conv_desc* d) {
 }
 
 static int conv_fwd_impl(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
-                         double* xstats, void* ws, size_t ws_bytes, void* stream, const sscg_fin* fin = nullptr, int* folded = nullptr) {
-    if (folded) *folded = 0;
+                         double* xstats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return SSCG_ERR_BAD_ARG;
     if (!stats && sscg_thin1x1_fwd_applies(d)) return sscg_thin1x1_fwd(d, x, w, bias, y, (hipStream_t)stream);
     if (sscg_conv16_fwd_applies(d)) return sscg_conv16_fwd(d, x, w, bias, y, stats, stat_L, xstats, ws, ws_bytes, (hipStream_t)stream);
-    if (sscg_convs_fwd_applies(d)) return sscg_convs_fwd(d, x, w, bias, y, stats, stat_L, xstats, ws, ws_bytes, (hipStream_t)stream, fin, folded);
+    if (sscg_convs_fwd_applies(d)) return sscg_convs_fwd(d, x, w, bias, y, stats, stat_L, xstats, ws, ws_bytes, (hipStream_t)stream);
     if (d->x_dtype != SSCG_F32 || d->w_dtype != SSCG_F32) return SSCG_ERR_UNSUPPORTED;
     KcParams p = {};
     p.src = reinterpret_cast<const float*>(x); p.wgt = reinterpret_cast<const float*>(w); p.bias = bias; p.dst = y;
@@ -885,25 +884,6 @@ extern "C" int sscg_conv2d_fwd_stats(const sscg_conv_desc* d, const void* x, con
     // rows that went through split-K: their statistics are produced by the split reduction itself (records after the main ones)
     double* xr = sp.xrec > 0 ? reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + sp.main_bytes) : nullptr;
     return conv_fwd_impl(d, x, w, bias, y, reinterpret_cast<double*>(stats), (long)L, xr, ws, ws_bytes, stream);
-}
-
-extern "C" int sscg_conv2d_fwd_norm_stats(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int G,
-                                          int64_t L, void* stats, size_t stats_bytes, float eps, float* mean, float* rstd,
-                                          float* running_mean, float* running_var, float momentum, int* tickets, void* ws,
-                                          size_t ws_bytes, void* stream) {
-    int rc = check_desc(d);
-    if (rc) return rc;
-    StatPlan sp;
-    if (!fwd_stats_plan(d, G, (long)L, &sp)) return SSCG_ERR_UNSUPPORTED;
-    if (!stats || stats_bytes < sp.bytes) return SSCG_ERR_WORKSPACE;
-    if (!mean || !rstd || (running_mean != nullptr) != (running_var != nullptr)) return SSCG_ERR_BAD_ARG;
-    double* xr = sp.xrec > 0 ? reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + sp.main_bytes) : nullptr;
-    sscg_fin fin = {tickets, G, mean, rstd, running_mean, running_var, eps, momentum};
-    int folded = 0;
-    rc = conv_fwd_impl(d, x, w, bias, y, reinterpret_cast<double*>(stats), (long)L, xr, ws, ws_bytes, stream, tickets ? &fin : nullptr, &folded);
-    if (rc || folded) return rc;
-    return sscg_finalize_conv_stats(reinterpret_cast<const double*>(stats), sp.valid_tiles, sp.bm, sp.wm, xr, sp.xrec, sp.xgroup, G, (long)L,
-                                    d->K, eps, mean, rstd, running_mean, running_var, momentum, (hipStream_t)stream);
 }
 
 extern "C" int sscg_norm_stats_from_conv(const sscg_conv_desc* d, const void* stats, int G, int64_t L, float eps, float* mean,
@@ -1002,36 +982,12 @@ extern "C" int sscg_conv2d_dgrad_bsums(const sscg_conv_desc* d, const void* dy, 
     const size_t need = sscg_conv2d_dgrad_bsums_bytes(d, G, L);
     if (need == 0) return SSCG_ERR_UNSUPPORTED;
     if (sums_bytes < need) return SSCG_ERR_WORKSPACE;
-    sscg_bsums bs = {nx, nz, mean, rstd, gamma, beta, sums, G, (long)L, act, slope, nullptr, nullptr, nullptr, nullptr};
+    sscg_bsums bs = {nx, nz, mean, rstd, gamma, beta, sums, G, (long)L, act, slope};
     if (sscg_conv16_dgrad_applies(d)) {
         if (nz || addend) return SSCG_ERR_UNSUPPORTED;          // (the bf16 kernel: sums of residual-free units only)
         return sscg_conv16_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, &bs);
     }
     return sscg_convs_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, &bs, addend);
-}
-
-extern "C" int sscg_conv2d_dgrad_bsums_fin(const sscg_conv_desc* d, const void* dy, const void* wt, void* dx, const void* nx, const void* nz,
-                                           const void* addend, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                           int G, int64_t L, int act, float slope, void* sums, size_t sums_bytes, float* coef, float* dgamma,
-                                           float* dbeta, int* tickets, void* ws, size_t ws_bytes, void* stream) {
-    if (!d || !dy || !wt || !dx || !nx || !mean || !rstd || !sums || !coef) return SSCG_ERR_BAD_ARG;
-    if ((gamma != nullptr) != (beta != nullptr)) return SSCG_ERR_BAD_ARG;
-    if (act != SSCG_ACT_NONE && act != SSCG_ACT_RELU && act != SSCG_ACT_LRELU) return SSCG_ERR_UNSUPPORTED;
-    const size_t need = sscg_conv2d_dgrad_bsums_bytes(d, G, L);
-    if (need == 0) return SSCG_ERR_UNSUPPORTED;
-    if (sums_bytes < need) return SSCG_ERR_WORKSPACE;
-    sscg_bsums bs = {nx, nz, mean, rstd, gamma, beta, sums, G, (long)L, act, slope, coef, dgamma, dbeta, tickets};
-    int folded = 0, rc;
-    if (sscg_conv16_dgrad_applies(d)) {
-        if (nz || addend) return SSCG_ERR_UNSUPPORTED;
-        rc = sscg_conv16_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, &bs);
-    } else {
-        rc = sscg_convs_dgrad(d, dy, wt, nullptr, dx, SSCG_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, &bs, addend, &folded);
-    }
-    if (rc || folded) return rc;
-    int bm, wm, chunks;
-    if (!bsums_geometry(d, G, L, &bm, &wm, &chunks)) return SSCG_ERR_UNSUPPORTED;
-    return sscg_finalize_bwd(reinterpret_cast<const double*>(sums), coef, dgamma, dbeta, G, d->C, chunks, (long)L, 1, bm, wm, (hipStream_t)stream);
 }
 
 // dx = dgrad(dy, wt) + addend: the fan-in of a tensor with two consumers (a residual block's input: conv1 and the shortcut) joins in

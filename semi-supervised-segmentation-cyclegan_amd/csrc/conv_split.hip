@@ -41,16 +41,6 @@ namespace {
 #ifndef KS_LATE_WAIT
 #define KS_LATE_WAIT 0
 #endif
-// In-kernel tails (the ABI v15 entries fold their small launches into the conv launch): compiled OUT by default - the ticket paths
-// cost the kernel +5.4 ms per config-2 step even when no launch uses them (134.3 against 128.9 ms, same box, interleaved:
-// profiles/r05_experiments.txt item 13) and +3 ms more when used.  -DKS_TAILS=1 builds them (tools/variant_lib.sh; the tests run
-// the same assertions on either build).
-#ifndef KS_TAILS
-#define KS_TAILS 0
-#endif
-#ifndef KS_LAUNDER
-#define KS_LAUNDER 0       // the epilogue re-reads its parameters from the kernel-argument segment (0: A/B aid)
-#endif
 #ifndef KS_LB4
 #define KS_LB4 1           // 64x64 class: hold the kernel to 128 registers (4 workgroups per CU, what its 40 KB of LDS allow) - two accumulator sets take it to 134
 #endif
@@ -106,21 +96,6 @@ struct KsParams {
     double* __restrict__ bn_sums;        // [G][bn_chunks][Ng][2]
     int bn_L, bn_G, bn_chunks, bn_act;
     float bn_slope;
-    // In-kernel tails (tickets != null; launches of at most KS_TAIL_TILES tile rows): the LAST partial workgroup of a tail tile sums the
-    // tile's partial results (fixed order) and finishes it as a whole tile - no reduce launch -, and the LAST tile of a column block
-    // turns the column's records into the layer's statistics (forward) / backward coefficients (data gradient) - no finalize launch.
-    // Everything a workgroup reads from another one (partial tiles, records) is written and read at agent scope (sc1: the XCDs' L2s
-    // are not coherent with each other inside a launch); the sums are taken in a fixed order, not in arrival order.
-    int* __restrict__ tickets;           // [tiles_n] column tickets, then one per tail tile; zero before the launch and after it
-    int tiles_m, fin_G;
-    float* __restrict__ fin_mean;        // forward: [G][Ng]
-    float* __restrict__ fin_rstd;
-    float* __restrict__ fin_rmean;       // [Ng] or null
-    float* __restrict__ fin_rvar;
-    float fin_eps, fin_momentum;
-    float* __restrict__ fin_coef;        // data gradient: [G][Ng][2]
-    float* __restrict__ fin_dgamma;      // [Ng] or null (written)
-    float* __restrict__ fin_dbeta;
     FastDiv div_tn, div_gl;              // by tiles_n; by stat_L / bn_L (whichever the launch uses)
     FastDiv div_hw, div_w;               // by OH * OW and by OW (launch_ks): a row's (image, y, x) without integer divisions (~30 VALU operations each)
 };
@@ -137,31 +112,9 @@ __device__ __forceinline__ float ks_act(float v, int act, float slope) {
     return v > 0.f ? v : neg;
 }
 
-// ---- agent-scope accessors and the "last arrival" ticket of the in-kernel tails
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// Every thread of the workgroup calls this after its agent-scope stores: true in ALL threads of the workgroup that arrives last of
-// `expected`.  (vmcnt(0): the write-through stores are acknowledged before the ticket is taken.)
-__device__ __forceinline__ bool last_arrival(int* ticket, int expected, int* flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    return *flag == expected - 1;
-}
-constexpr int KS_TAIL_TILES = 160;       // tile rows a column's last workgroup walks (8712- and 17424-row maps: 69 / 137 tiles of 128 rows)
-
-// KG = 2: TWO wave groups of WM * WN waves share the tile and halve its reduction (k-tiles [0, n/2) and [n/2, n)), each with its own
-// LDS stages; the second group's accumulators join the first's through LDS before the epilogue.  For launches whose tile count
-// barely exceeds the CU count (8712-row maps x 256 output channels = 276 tiles of 128 x 64: ONE 4-wave workgroup per CU, one wave
-// per SIMD - every LDS wait, barrier and split sequence of that wave is exposed): two waves per SIMD without the partial tiles
-// and the reduce pass of a split-K over workgroups.
-template <int MODE, int WM, int WN, int TM, int TN, int KG = 1>
-__global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG == 1) ? 4 : 2)) void convs_kernel(KsParams p) {      // (HIP: the second figure is WAVES PER SIMD)
-    constexpr int NT = WM * WN * 64;          // threads of one wave group
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) void convs_kernel(KsParams p) {      // (HIP: the second figure is WAVES PER SIMD)
+    constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int NSTAGE = 2;
@@ -177,12 +130,9 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     constexpr int B_STAGE = 3 * B_PLANE;
     constexpr int NPIECE = PA + PB;
 
-    constexpr int GROUP_LDS = NSTAGE * (A_STAGE + B_STAGE);
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2] A images, then [2][3] B plane images
 
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // per wave group: [2] A images, then [2][3] B plane images
-
-    const int tid = KG > 1 ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x;                 // thread inside its wave group
-    const int kgrp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NT)) : 0;
+    const int tid = (int)threadIdx.x;
     int split = 0, tile;
     bool partial = false;
     if ((int)blockIdx.x < p.full_tiles) {
@@ -282,13 +232,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     };
 
     const int nk_all = p.Ktot / BKS;                         // Cs % 32 == 0: a k-tile never straddles a tap
-    int kt0 = partial ? split * p.ksplit : 0;
-    int kt1 = partial ? min(nk_all, kt0 + p.ksplit) : nk_all;
-    int nk_pad = 0;                                          // KG > 1: barriers of the longer group's loop
-    if (KG > 1) {
-        nk_pad = (kt1 - kt0 + 1) / 2;
-        if (kgrp == 0) kt1 = kt0 + nk_pad; else kt0 = kt0 + nk_pad;
-    }
+    const int kt0 = partial ? split * p.ksplit : 0;
+    const int kt1 = partial ? min(nk_all, kt0 + p.ksplit) : nk_all;
     const int f_nchunk = p.Cs / BKS;
     int f_chunk, f_ky, f_kx;
     {
@@ -324,7 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     f_k += f_chunk * BKS;
 
     typedef __attribute__((address_space(3))) char lds_char;
-    lds_char* const lds0 = (lds_char*)smem_raw + kgrp * GROUP_LDS;
+    lds_char* const lds0 = (lds_char*)smem_raw;
     const int lds_wave = __builtin_amdgcn_readfirstlane(wave_id * 1024);      // this wave's 1 KB of every loader pass
     const int lds_wave_b = __builtin_amdgcn_readfirstlane((wave_id % (RPB / 16)) * 1024);
     auto request_tile = [&]() {
@@ -534,10 +479,6 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
             half_tile(1, false);
         }
     }
-    if (KG > 1) {       // the groups' loops meet at workgroup barriers: the shorter one (one k-tile less, or none) keeps the count
-        for (int i = nk; i < nk_pad; ++i) __builtin_amdgcn_s_barrier();
-    }
-
     if (ACC2) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -545,40 +486,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
             for (int j = 0; j < TN; ++j) acc[i][j] += acc_lo[i][j];
     }
 
-    if (KG > 1) {
-        // the second group's sums join the first's through its own (now dead) stage images, register by register, lane by lane:
-        // a fixed order, so the result does not depend on which group finished first
-        __syncthreads();                        // every wave of both groups has read its last fragments
-        float* const mb = reinterpret_cast<float*>(smem_raw + GROUP_LDS) + (wave_id * TM * TN * 16) * 64 + (tid & 63);
-        if (kgrp == 1) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) mb[((i * TN + j) * 16 + e) * 64] = acc[i][j][e];
-        }
-        __syncthreads();
-        if (kgrp == 1) return;                  // (a barrier waits for the surviving waves only)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] += mb[((i * TN + j) * 16 + e) * 64];
-    }
-
-    // The epilogue reads its parameters through a laundered kernel-argument pointer: hipcc loads every kernel argument at the top of the
-    // kernel and keeps it in SGPRs across the k-loop (a dozen pointers and scalars of the fused store phases: 20-130 SGPR spills in the
-    // loop's shadow); behind the opaque move below the loads cannot be hoisted, the loop keeps its registers.
-#if KS_LAUNDER
-    typedef const __attribute__((address_space(4))) KsParams* KsArgs;          // (the constant address space: scalar loads)
-    KsArgs ka_ = (KsArgs)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka_));
-    const __attribute__((address_space(4))) KsParams& ep = *ka_;
-#else
     const KsParams& ep = p;
-#endif
     const FastDiv e_gl = {ep.div_gl.mul, ep.div_gl.shift, ep.div_gl.d}, e_hw = {ep.div_hw.mul, ep.div_hw.shift, ep.div_hw.d},
                   e_w = {ep.div_w.mul, ep.div_w.shift, ep.div_w.d};
     if (KS_ABLATE & 8) {        // timing ablation: no epilogue (one store per lane keeps the accumulators alive); WRONG results
@@ -611,51 +519,9 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
 #define KS_STAGE_OUT 1
 #endif
     constexpr int OLD = BN + 4;
-    constexpr int SREC_OFF = BM * OLD * 4;     // in-kernel tails: the waves' statistics meet behind the staged tile, [WM][BN][4] doubles
-    __shared__ int s_flag;
-    const bool fold = KS_TAILS && KG == 1 && ep.tickets != nullptr;
+    constexpr int SREC_OFF = BM * OLD * 4;     // the row lanes' statistics of a straddling tile meet behind the staged tile, [NT / BN][BN][4] doubles
     const bool want_bsums = MODE == MODE_DGRAD && ep.bn_sums != nullptr;        // (never with split-K: the host plans these launches unsplit)
     float* const ot = reinterpret_cast<float*>(smem_raw);
-    if (partial && fold) {
-        // ---- tail tile, in-kernel: every partial workgroup leaves its accumulators in the workspace; the LAST of the tile's `splits`
-        // workgroups to arrive sums the partial tiles in split order (whoever is last: the same sum) back into its accumulators and
-        // goes on as the workgroup of a whole tile
-        const int n_l = n0 + col_w + li;
-        const int r_l = m0 + row_w + 4 * lh - ep.m_tail0;
-        const unsigned off0 = (unsigned)r_l * (unsigned)ep.Ng + (unsigned)n_l;       // (the workspace of a tail is a few MB: 32-bit offsets)
-        float* const mine = ep.part + (size_t)split * (ep.M - ep.m_tail0) * ep.Ng;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int dr = i * 32 + (e & 3) + 8 * (e >> 2);
-                    if (r_l + dr + ep.m_tail0 < ep.M && n_l + j * 32 < ep.Ng) st_agent(mine + (off0 + (unsigned)dr * (unsigned)ep.Ng + j * 32), acc[i][j][e]);
-                }
-        int* const tk = ep.tickets + ep.tiles_n + (tile - ep.full_tiles);
-        if (!last_arrival(tk, ep.splits, &s_flag)) return;
-        if (tid == 0) st_agent(tk, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        for (int k = 0; k < ep.splits; ++k) {
-            const float* const pk = ep.part + (size_t)k * (ep.M - ep.m_tail0) * ep.Ng;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int dr = i * 32 + (e & 3) + 8 * (e >> 2);
-                        if (r_l + dr + ep.m_tail0 < ep.M && n_l + j * 32 < ep.Ng) acc[i][j][e] += ld_agent(pk + (off0 + (unsigned)dr * (unsigned)ep.Ng + j * 32));
-                    }
-        }
-        partial = false;
-    }
     const bool want_stats = MODE == MODE_FWD && ep.stats != nullptr && !partial;      // (a data gradient never takes forward statistics)
     int gb = 0x7fffffff;
     if (want_stats) gb = (fd_div(m0, e_gl) + 1) * ep.stat_L;
@@ -671,7 +537,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
     // tile, in a loop over its rows (store phase below) - in registers (64 unrolled fp64 updates per wave tile) only where nothing is staged
     const bool reg_slow = slow_stats && !staged;
     const bool reg_stats = fast_stats || reg_slow;
-    if (staged || (fold && want_stats)) __syncthreads();           // every wave has read its last fragments
+    if (staged) __syncthreads();           // every wave has read its last fragments
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + col_w + j * 32 + li;
@@ -727,29 +593,11 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
         if (reg_stats) {
             s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);      // the lane halves hold different rows of a column
             s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-            if (fold) {
-                if (lh == 0) {
-                    double* sr = reinterpret_cast<double*>(smem_raw + SREC_OFF) + (size_t)(wm * BN + col_w + j * 32 + li) * 4;
-                    sr[0] = s0; sr[1] = q0; sr[2] = s1; sr[3] = q1;
-                }
-            } else if (lh == 0 && nok) {
+            if (lh == 0 && nok) {
                 double* rec = ep.stats + ((size_t)(tile_m * WM + wm) * 2) * ep.Ng * 2;
                 rec[(size_t)n * 2] = s0; rec[(size_t)n * 2 + 1] = q0;
                 rec[((size_t)ep.Ng + n) * 2] = s1; rec[((size_t)ep.Ng + n) * 2 + 1] = q1;
             }
-        }
-    }
-    if (fold && reg_stats) {
-        // ONE record per tile ([tile row][2 slots][Ng][2] doubles): the wave rows' sums meet in LDS, in wave-row order
-        __syncthreads();
-        if (tid < BN && n0 + tid < ep.Ng) {
-            const double* sr = reinterpret_cast<const double*>(smem_raw + SREC_OFF) + (size_t)tid * 4;
-            double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) { a += sr[w * BN * 4]; b += sr[w * BN * 4 + 1]; c += sr[w * BN * 4 + 2]; d += sr[w * BN * 4 + 3]; }
-            double* rec = ep.stats + ((size_t)tile_m * 2 * ep.Ng + (n0 + tid)) * 2;
-            st_agent(rec, a); st_agent(rec + 1, b);
-            st_agent(rec + (size_t)ep.Ng * 2, c); st_agent(rec + (size_t)ep.Ng * 2 + 1, d);
         }
     }
     if (staged) {
@@ -772,17 +620,12 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
 #pragma unroll
                 for (int l = 0; l < NLS; ++l) { a += sr[(l * BN + tid) * 4]; b += sr[(l * BN + tid) * 4 + 1]; cc += sr[(l * BN + tid) * 4 + 2]; d += sr[(l * BN + tid) * 4 + 3]; }
                 const int nn = n0 + tid;
-                if (fold) {
-                    double* rec = ep.stats + ((size_t)tile_m * 2 * ep.Ng + nn) * 2;
-                    st_agent(rec, a); st_agent(rec + 1, b);
-                    st_agent(rec + (size_t)ep.Ng * 2, cc); st_agent(rec + (size_t)ep.Ng * 2 + 1, d);
-                } else {                // the tile's total in its first wave row's record, zeros in the others
+                // the tile's total in its first wave row's record, zeros in the others
 #pragma unroll
-                    for (int w = 0; w < WM; ++w) {
-                        double* rec = ep.stats + ((size_t)(tile_m * WM + w) * 2) * ep.Ng * 2;
-                        rec[(size_t)nn * 2] = w ? 0.0 : a; rec[(size_t)nn * 2 + 1] = w ? 0.0 : b;
-                        rec[((size_t)ep.Ng + nn) * 2] = w ? 0.0 : cc; rec[((size_t)ep.Ng + nn) * 2 + 1] = w ? 0.0 : d;
-                    }
+                for (int w = 0; w < WM; ++w) {
+                    double* rec = ep.stats + ((size_t)(tile_m * WM + w) * 2) * ep.Ng * 2;
+                    rec[(size_t)nn * 2] = w ? 0.0 : a; rec[(size_t)nn * 2 + 1] = w ? 0.0 : b;
+                    rec[((size_t)ep.Ng + nn) * 2] = w ? 0.0 : cc; rec[((size_t)ep.Ng + nn) * 2 + 1] = w ? 0.0 : d;
                 }
             }
         }
@@ -886,96 +729,15 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, ((KS_LB4 && TM * TN == 1 && KG =
                 const int nn = n0 + tid;
                 const int k0 = tile_m - (int)(((long)bg * ep.bn_L) / BM);          // chunk of group g = tile row - first tile row of g
                 double* r0 = ep.bn_sums + (((size_t)bg * ep.bn_chunks + k0) * ep.Ng + nn) * 2;
-                if (fold) { st_agent(r0, a); st_agent(r0 + 1, b); } else { r0[0] = a; r0[1] = b; }
+                r0[0] = a; r0[1] = b;
                 if (m0 + BM > gb && bg + 1 < ep.bn_G) {          // the tile straddles into group g + 1: it is that group's first tile
                     double* r1 = ep.bn_sums + ((size_t)(bg + 1) * ep.bn_chunks * ep.Ng + nn) * 2;
-                    if (fold) { st_agent(r1, c); st_agent(r1 + 1, d); } else { r1[0] = c; r1[1] = d; }
+                    r1[0] = c; r1[1] = d;
                 }
             }
         }
     }
 
-    // ---- column tails: the last tile of this column block finishes the layer's statistics / backward coefficients for its channels
-    if (fold && (ep.stats != nullptr || want_bsums)) {
-        if (!last_arrival(ep.tickets + tile_n, ep.tiles_m, &s_flag)) return;
-        if (tid == 0) st_agent(ep.tickets + tile_n, 0);
-        constexpr int NL = NT / BN;             // record lanes per channel
-        const int c = tid % BN, lane = tid / BN;
-        const int n = n0 + c;
-        const bool nok = n < ep.Ng;
-        double* const sm = reinterpret_cast<double*>(smem_raw);      // [NL][BN][2] (every other use of the LDS is over)
-        double tg = 0.0, tb = 0.0;
-        for (int g = 0; g < ep.fin_G; ++g) {     // (groups in order: the running statistics see them as successive forwards would)
-            double s = 0.0, q = 0.0;
-            const double* base;
-            int cnt;
-            size_t stride;
-            if (want_bsums) {
-                const int tf = (int)(((long)g * ep.bn_L) / BM);
-                cnt = (int)((((long)(g + 1) * ep.bn_L + BM - 1) / BM) - tf);
-                base = ep.bn_sums + ((size_t)g * ep.bn_chunks * ep.Ng + n) * 2;
-                stride = (size_t)ep.Ng * 2;
-            } else {
-                const long lo = (long)g * ep.stat_L, hi = lo + ep.stat_L;
-                const int t_first = (int)((lo + BM - 1) / BM);
-                int t_last = (int)((hi + BM - 1) / BM) - 1;
-                if (t_last > ep.tiles_m - 1) t_last = ep.tiles_m - 1;
-                cnt = t_last - t_first + 1;                      // slot-0 records of the tiles that start inside the group
-                base = ep.stats + ((size_t)t_first * 2 * ep.Ng + n) * 2;
-                stride = (size_t)2 * ep.Ng * 2;
-                if (nok && lane == 0 && g > 0 && t_first >= 1) {             // slot 1 of the tile that straddles the group's lower boundary
-                    const double* r1 = ep.stats + (((size_t)(t_first - 1) * 2 + 1) * ep.Ng + n) * 2;
-                    s += ld_agent(r1); q += ld_agent(r1 + 1);
-                }
-            }
-            if (nok) {
-                int k = lane;
-                for (; k + 3 * NL < cnt; k += 4 * NL) {          // four records in flight
-                    const double* r = base + (size_t)k * stride;
-                    const double a0 = ld_agent(r), b0 = ld_agent(r + 1);
-                    const double a1 = ld_agent(r + NL * stride), b1 = ld_agent(r + NL * stride + 1);
-                    const double a2 = ld_agent(r + 2 * NL * stride), b2 = ld_agent(r + 2 * NL * stride + 1);
-                    const double a3 = ld_agent(r + 3 * NL * stride), b3 = ld_agent(r + 3 * NL * stride + 1);
-                    s += (a0 + a1) + (a2 + a3);
-                    q += (b0 + b1) + (b2 + b3);
-                }
-                for (; k < cnt; k += NL) {
-                    const double* r = base + (size_t)k * stride;
-                    s += ld_agent(r); q += ld_agent(r + 1);
-                }
-            }
-            sm[(lane * BN + c) * 2] = s; sm[(lane * BN + c) * 2 + 1] = q;
-            __syncthreads();
-            if (lane == 0 && nok) {
-                double a = 0.0, b = 0.0;
-#pragma unroll
-                for (int l = 0; l < NL; ++l) { a += sm[(l * BN + c) * 2]; b += sm[(l * BN + c) * 2 + 1]; }
-                const size_t i = (size_t)g * ep.Ng + n;
-                if (want_bsums) {
-                    ep.fin_coef[i * 2] = (float)(a / (double)ep.bn_L);
-                    ep.fin_coef[i * 2 + 1] = (float)(b / (double)ep.bn_L);
-                    tb += a; tg += b;
-                } else {
-                    const double L = (double)ep.stat_L;
-                    const double mu = a / L;
-                    double var = b / L - mu * mu;
-                    if (var < 0.0) var = 0.0;
-                    ep.fin_mean[i] = (float)mu;
-                    ep.fin_rstd[i] = (float)(1.0 / sqrt(var + (double)ep.fin_eps));
-                    if (ep.fin_rmean) {
-                        const double unb = ep.stat_L > 1 ? var * L / (L - 1.0) : var;
-                        ep.fin_rmean[n] = (float)((1.0 - (double)ep.fin_momentum) * (double)ep.fin_rmean[n] + (double)ep.fin_momentum * mu);
-                        ep.fin_rvar[n] = (float)((1.0 - (double)ep.fin_momentum) * (double)ep.fin_rvar[n] + (double)ep.fin_momentum * unb);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        if (want_bsums && lane == 0 && nok) {
-            if (ep.fin_dgamma) ep.fin_dgamma[n] = (float)tg;
-            if (ep.fin_dbeta) ep.fin_dbeta[n] = (float)tb;
-        }
-    }
 }
 
 // y[i] = act(sum_s part[s][i] + bias[i % Ng])   (fixed order => deterministic); 4 floats per thread (Ng % 4 == 0)
@@ -1005,24 +767,19 @@ __global__ __launch_bounds__(256) void ks_reduce1_kernel(const float* __restrict
     y[i] = sscg_act(s + (bias ? bias[(int)(i % Ng)] : 0.f), act, slope);
 }
 
+
 #ifndef KS_STAGE_OUT
 #define KS_STAGE_OUT 1
 #endif
 constexpr bool KS_STAGE_OUT_HOST = KS_STAGE_OUT != 0;      // the addend joins in the staged store phase
 
 // ---- host side: tile classes and the split-K plan of the tail (same policy as conv_igemm.hip)
-enum { KS_128x128 = 0, KS_128x128_R = 1, KS_64x64 = 2, KS_128x64 = 3, KS_64x128 = 4, KS_128x64_K2 = 5, KS_128x32 = 6, KS_64x64_W2 = 7, KS_NCFG = 8 };
-const int KS_BM[KS_NCFG] = {128, 128, 64, 128, 64, 128, 128, 64};
-const int KS_BN[KS_NCFG] = {128, 128, 64, 64, 128, 64, 32, 64};
-const int KS_WM[KS_NCFG] = {2, 4, 2, 4, 2, 4, 4, 2};  // wave rows of a tile = statistics records per tile row
-// The two-wave-group form of the 128x64 tile is built and tested but OFF by default: alone it hides the exposed waits of a launch
-// with one workgroup per CU, but in the four-lane step it costs +4 ms (135.2 against 131.1 ms, interleaved A/B on one box, round 5):
-// 112 KB of LDS and 2 x 208 registers per SIMD leave no room for the other lanes' workgroups on that CU, and those - not idle issue
-// slots - are what fills the chip in the stq.  SSCG_KS_K2=1 switches it on (tools/convs_bench.py).
-static int ks_k2_or(int cfg, long tiles, int Ktot) {
-    static const int on = getenv("SSCG_KS_K2") ? atoi(getenv("SSCG_KS_K2")) : 0;
-    return (on && cfg == KS_128x64 && tiles <= 384 && Ktot >= 1024) ? KS_128x64_K2 : cfg;
-}
+enum { KS_128x128 = 0, KS_64x64 = 1, KS_128x64 = 2, KS_128x32 = 3, KS_NCFG = 4 };
+const int KS_BM[KS_NCFG] = {128, 64, 128, 128};
+const int KS_BN[KS_NCFG] = {128, 64, 64, 32};
+const int KS_WM[KS_NCFG] = {2, 2, 4, 4};  // wave rows of a tile = statistics records per tile row
+// (Built, measured slower and deleted - numbers in profiles/r05_experiments.txt items 3, 12 and r05_tile_classes_after_diet.txt: a 128x128
+// tile of four 32x128 waves, a 64x128 tile, the 128x64 tile as two wave groups halving the reduction, the 64x64 tile as two waves.)
 // A/B aids for the tile-class policy inside the step (the thresholds below were tuned on kernels timed ALONE; in the step the VALU
 // pipe is the contended resource, and classes with fewer split operations per MFMA may win there although they lose alone)
 static int ks_env(const char* name, int dflt) {
@@ -1036,10 +793,7 @@ static int ks_env(const char* name, int dflt) {
 //  * 128x64 (4 waves of 32x64: every A fragment is split by ONE wave) for long reductions on the 8712 / 17424-row maps whose
 //    128x128 tiling would leave CUs idle (135-185 TF/s against 95-168);
 //  * 64x64 for short reductions (1x1 convs with <= 512 source channels: prologue / epilogue bound) and few output channels.
-static int ks_choose_plan(long M, int Ng, int Ktot, int tuning);
-static int ks_w2_or(int cfg);
-int ks_choose(long M, int Ng, int Ktot, int tuning) { return ks_w2_or(ks_choose_plan(M, Ng, Ktot, tuning)); }
-static int ks_choose_plan(long M, int Ng, int Ktot, int tuning) {
+int ks_choose(long M, int Ng, int Ktot, int tuning) {
     static const int T128_SHORT = ks_env("SSCG_KS_T128_SHORT", 512);    // min 128x128 tiles for that class on a short reduction (1024 until round 5: alone the
                                                                         // 552-tile 1x1 256 -> 1024 is 8 % faster on 64x64 tiles, in the four-lane step the larger tiles win: -0.9 ms)
     static const int K128 = ks_env("SSCG_KS_K128", 512);               // min reduction length for the 128x128 class
@@ -1059,15 +813,9 @@ static int ks_choose_plan(long M, int Ng, int Ktot, int tuning) {
     // whatever the reduction)
     if (Ng <= 128) return ((t128 >= T128_NARROW && Ktot >= K128_NARROW) || t128 >= 4096) ? KS_128x128 : KS_64x64;
     if (t128 >= (Ktot >= K128 ? 512 : T128_SHORT) && Ktot >= K128_NARROW) return KS_128x128;
-    if (Ktot >= K12864 && tm * cdiv(Ng, 64) >= T12864) return ks_k2_or(KS_128x64, tm * cdiv(Ng, 64), Ktot);
+    if (Ktot >= K12864 && tm * cdiv(Ng, 64) >= T12864) return KS_128x64;
     return KS_64x64;
 }
-// the 64x64 tile as TWO waves of 32x64 (every A fragment split once, 7 instead of 17 VALU operations per MFMA) instead of four of 32x32
-static int ks_w2_or(int cfg) {
-    static const int on = ks_env("SSCG_KS_W2", 0);
-    return (on && cfg == KS_64x64) ? KS_64x64_W2 : cfg;
-}
-
 struct KsSplit { int splits, ksplit, full_tiles, m_tail0; };
 
 KsSplit ks_plan_raw(long M, int Ng, int Ktot, int tuning) {
@@ -1117,35 +865,26 @@ size_t ks_split_bytes(const KsSplit& sp, long M, int Ng) {
     return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
 
-// in-kernel tails: not for the two-group form (its second group leaves before the epilogue), not where a column's last workgroup
-// would walk more than KS_TAIL_TILES records; the tickets a launch may touch: one per column block + one per tail tile
-bool ks_fold_ok(long M, int Ng, int Ktot, int tuning) {
-    static const int on = KS_TAILS && ks_env("SSCG_KS_TAILS", 1);
-    const int cfg = ks_choose(M, Ng, Ktot, tuning);
-    return on && cfg != KS_128x64_K2 && cdiv(M, KS_BM[cfg]) <= KS_TAIL_TILES && cdiv(Ng, KS_BN[cfg]) + 208 <= SSCG_TAIL_TICKETS;
-}
-
-template <int MODE, int WM, int WN, int TM, int TN, int KG = 1>
+template <int MODE, int WM, int WN, int TM, int TN>
 int launch_ks(const KsParams& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int NT = WM * WN * 64 * KG;
+    constexpr int NT = WM * WN * 64;
     KsParams p = p0;
     p.div_hw = make_fastdiv(p.OH * p.OW);
     p.div_w = make_fastdiv(p.OW);
     p.tiles_n = cdiv(p.Ng, BN);
     p.div_tn = make_fastdiv(p.tiles_n);
     p.div_gl = make_fastdiv((MODE == MODE_DGRAD && p.bn_sums != nullptr) ? p.bn_L : (p.stat_L > 0 ? p.stat_L : 1));
-    p.tiles_m = cdiv(p.M, BM);
-    p.tiles = p.tiles_m * p.tiles_n;
-    const size_t smem = (size_t)KG * 2 * (BM * 128 + 3 * BN * 64);
-    auto kern = convs_kernel<MODE, WM, WN, TM, TN, KG>;
+    p.tiles = cdiv(p.M, BM) * p.tiles_n;
+    const size_t smem = (size_t)2 * (BM * 128 + 3 * BN * 64);
+    auto kern = convs_kernel<MODE, WM, WN, TM, TN>;
     SSCG_ENSURE_SMEM((kern), smem);
     if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);
     SSCG_LAUNCH_CHECK();
-    if (p.splits > 1 && !p.tickets) {     // (with tickets the tail tiles are finished inside the launch)
+    if (p.splits > 1) {
         const size_t n = (size_t)(p.M - p.m_tail0) * p.Ng;
         float* yt = p.dst + (size_t)p.m_tail0 * p.Ng;
         if (p.xstats)
@@ -1164,13 +903,9 @@ template <int MODE>
 int dispatch_ks(const KsParams& p, int tuning, hipStream_t st) {
     switch (ks_choose(p.M, p.Ng, p.Ktot, tuning)) {
         case KS_128x128: return launch_ks<MODE, 2, 2, 2, 2>(p, st);       // 4 waves of 64x64
-        case KS_128x128_R: return launch_ks<MODE, 4, 1, 1, 4>(p, st);     // 4 waves of 32x128: every A fragment split by one wave only
         case KS_64x64: return launch_ks<MODE, 2, 2, 1, 1>(p, st);
-        case KS_128x64: return launch_ks<MODE, 4, 1, 1, 2>(p, st);
-        case KS_64x128: return launch_ks<MODE, 2, 2, 1, 2>(p, st);
-        case KS_128x64_K2: return launch_ks<MODE, 4, 1, 1, 2, 2>(p, st);  // two groups of 4 waves of 32x64, half the reduction each
+        case KS_128x64: return launch_ks<MODE, 4, 1, 1, 2>(p, st);         // 4 waves of 32x64: every A fragment split by one wave only
         case KS_128x32: return launch_ks<MODE, 4, 1, 1, 1>(p, st);        // 4 waves of 32x32: few-channel heads
-        case KS_64x64_W2: return launch_ks<MODE, 2, 1, 1, 2>(p, st);      // 2 waves of 32x64: the 64x64 tile with every A fragment split ONCE
         default: return SSCG_ERR_BAD_ARG;
     }
 }
@@ -1271,9 +1006,8 @@ size_t sscg_convs_dgrad_workspace(const sscg_conv_desc* d) {
 }
 
 int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
-                   double* xstats, void* ws, size_t ws_bytes, hipStream_t st, const sscg_fin* fin, int* folded) {
+                   double* xstats, void* ws, size_t ws_bytes, hipStream_t st) {
     KsParams p = {};
-    if (folded) *folded = 0;
     p.src = reinterpret_cast<const float*>(x); p.wgt = reinterpret_cast<const bf16*>(w); p.wplane = ks_plane(d);
     p.bias = bias; p.dst = reinterpret_cast<float*>(y);
     p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Cs = d->C; p.Ktot = d->R * d->S * d->C;
@@ -1288,12 +1022,6 @@ int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const 
     if (sp.splits > 1 && (!ws || ws_bytes < ks_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
-    if (fin && fin->tickets && fin->G <= 4 && ks_fold_ok(p.M, p.Ng, p.Ktot, d->tuning) && (!stats || (fin->mean && fin->rstd && (long)fin->G * stat_L == p.M))) {
-        p.tickets = fin->tickets; p.fin_G = stats ? fin->G : 0;
-        p.fin_mean = fin->mean; p.fin_rstd = fin->rstd; p.fin_rmean = fin->rmean; p.fin_rvar = fin->rvar;
-        p.fin_eps = fin->eps; p.fin_momentum = fin->momentum;
-        if (folded) *folded = 1;
-    }
     return dispatch_ks<MODE_FWD>(p, d->tuning, st);
 }
 
@@ -1313,10 +1041,8 @@ bool sscg_convs_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, 
 }
 
 int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs, const void* addend, int* folded) {
+                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs, const void* addend) {
     KsParams p = {};
-    bool fused = false;
-    if (folded) *folded = 0;
     if (addend) {
         if (bias || act != SSCG_ACT_NONE || !KS_STAGE_OUT_HOST) return SSCG_ERR_UNSUPPORTED;
         p.addend = reinterpret_cast<const float*>(addend);
@@ -1328,7 +1054,6 @@ int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, co
         p.bn_sums = reinterpret_cast<double*>(bs->sums); p.bn_L = (int)bs->L; p.bn_G = bs->G; p.bn_chunks = chunks;
         p.bn_act = bs->act; p.bn_slope = bs->slope;
         p.bn_z = reinterpret_cast<const float*>(bs->nz);
-        fused = true;
     }
     p.src = reinterpret_cast<const float*>(dy); p.wgt = reinterpret_cast<const bf16*>(wt); p.wplane = ks_plane(d);
     p.bias = bias; p.dst = reinterpret_cast<float*>(dx);
@@ -1366,15 +1091,13 @@ int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, co
         }
         return SSCG_OK;
     }
-    KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, fused ? ((d->tuning & 0xff) | 0x100) : d->tuning);     // fused sums: never split
+    // Launches with fused sums are never split: the idle second round of a 276-tile launch costs ~16 us ALONE, but in the step the other
+    // lanes' kernels fill it - a tail split whose reduction took the sums for its rows (built in round 6, bit-reproducible, 3x3 256 d2
+    // 148 -> 121 us alone) left the step where it was (127.9 / 128.1 against 127.4 / 127.4 ms; profiles/r06_experiments.txt item 2).
+    KsSplit sp = ks_plan(p.M, p.Ng, p.Ktot, bs ? ((d->tuning & 0xff) | 0x100) : d->tuning);
     if (sp.splits > 1 && (!ws || ws_bytes < ks_split_bytes(sp, p.M, p.Ng))) return SSCG_ERR_WORKSPACE;
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
-    if (fused && bs->tickets && bs->coef && bs->G <= 4 && ks_fold_ok(p.M, p.Ng, p.Ktot, d->tuning)) {
-        p.tickets = bs->tickets; p.fin_G = bs->G;
-        p.fin_coef = bs->coef; p.fin_dgamma = bs->dgamma; p.fin_dbeta = bs->dbeta;
-        if (folded) *folded = 1;
-    }
     return dispatch_ks<MODE_DGRAD>(p, d->tuning, st);
 }
 

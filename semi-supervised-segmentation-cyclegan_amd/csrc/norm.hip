@@ -835,28 +835,6 @@ int sscg_finalize_bwd(const double* sums, float* coef, float* dgamma, float* dbe
     return SSCG_OK;
 }
 
-extern "C" int sscg_norm_bwd_from_coef(const float* coef, const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
-                                       const float* gamma, const float* beta, void* dx, void* dres, int dtype, int G, int64_t L, int C, int act,
-                                       float slope, void* stream) {
-    if (!coef || !dy || !x || !mean || !rstd || !dx || G <= 0 || L <= 0 || C <= 0 || (dtype != SSCG_F32 && dtype != SSCG_BF16)) return SSCG_ERR_BAD_ARG;
-    if (act != SSCG_ACT_NONE && act != SSCG_ACT_RELU && act != SSCG_ACT_LRELU) return SSCG_ERR_UNSUPPORTED;
-    if (act != SSCG_ACT_NONE && !y && dres) return SSCG_ERR_BAD_ARG;      // a residual joined the forward: the mask needs y
-    BwdApplyParams q = {};
-    q.dy = dy; q.x = x; q.y = y; q.mean = mean; q.rstd = rstd; q.gamma = gamma; q.beta = beta;
-    q.coef = coef;
-    q.dx = dx; q.dres = dres; q.L = L; q.C = C; q.act = act; q.slope = slope;
-    const int vec = vec_for(C, dtype);
-    if ((size_t)G * L * C / vec >= ((size_t)1 << 31)) return SSCG_ERR_UNSUPPORTED;
-    q.total = (uint32_t)((size_t)G * L * C / vec);
-    q.div_cg = make_fastdiv(C / vec);
-    q.div_l = make_fastdiv((int)L);
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == SSCG_BF16) launch_bwd_apply<__bf16>(q, vec, st);
-    else launch_bwd_apply<float>(q, vec, st);
-    SSCG_LAUNCH_CHECK();
-    return SSCG_OK;
-}
-
 // ---- PixelDiscriminator tail: norm -> activation -> 1x1 conv to ONE channel (arch/discriminators.py:72-75)
 static bool head_ok(int C) { return C >= 16 && C <= 256 && (C & (C - 1)) == 0; }
 

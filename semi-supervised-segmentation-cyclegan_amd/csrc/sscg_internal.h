@@ -26,19 +26,8 @@ bool sscg_convs_dgrad_applies(const sscg_conv_desc* d);
 bool sscg_convs_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* wm, int* tiles_n, int* splits, int* full_tiles, int* m_tail0);
 size_t sscg_convs_fwd_workspace(const sscg_conv_desc* d, long stat_L);
 size_t sscg_convs_dgrad_workspace(const sscg_conv_desc* d);
-// in-kernel tails of the split family (conv_split.hip): where a launch is served, its tail tiles are reduced and its statistics
-// finished inside the launch (`folded` = 1); `tickets`: SSCG_TAIL_TICKETS zeroed ints no other launch in flight uses
-struct sscg_fin {
-    int* tickets;
-    int G;
-    float* mean;             // [G][K]
-    float* rstd;
-    float* rmean;            // [K] or null
-    float* rvar;
-    float eps, momentum;
-};
 int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
-                   double* xstats, void* ws, size_t ws_bytes, hipStream_t st, const sscg_fin* fin = nullptr, int* folded = nullptr);
+                   double* xstats, void* ws, size_t ws_bytes, hipStream_t st);
 // the backward sums of the normalisation layer whose output a data gradient differentiates, taken in that launch's epilogue
 struct sscg_bsums {
     const void* nx;          // the layer's input [G * L][C]
@@ -52,15 +41,10 @@ struct sscg_bsums {
     long L;
     int act;
     float slope;
-    // in-kernel finalize (conv_split.hip; all null = a separate finalize launch): [G][C][2] coefficients, dgamma / dbeta (written)
-    float* coef;
-    float* dgamma;
-    float* dbeta;
-    int* tickets;
 };
 bool sscg_convs_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm, int* wm, int* chunks);
 int sscg_convs_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
-                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs = nullptr, const void* addend = nullptr, int* folded = nullptr);
+                     void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs = nullptr, const void* addend = nullptr);
 // conv_igemm.hip: record geometry of sscg_conv2d_dgrad_bsums for this descriptor (false = the fusion does not apply)
 bool sscg_bsums_records(const sscg_conv_desc* d, int G, int64_t L, int* bm, int* wm, int* chunks);
 int sscg_krsc_to_crsk_split(const float* w, void* wt, int K, int RS, int C, hipStream_t st);

@@ -76,21 +76,6 @@ class _Workspace:
 
 _WS = _Workspace()
 
-# In-kernel tails of the split family (include/sscg.h, ABI v15): a conv launch finishes its tail tiles and the statistics / backward
-# coefficients of the norm layer beside it by itself - ~900 reduce / finalize launches fewer per step.  The tickets of a launch: one
-# zeroed array per (device, stream) - launches of one stream do not overlap, and each leaves its tickets zero.
-TAILS = [os.environ.get("SSCG_TAILS", "0") != "0"]
-_TICKETS = {}
-
-
-def _tickets(device):
-    key = (device, _raw_stream(device.index if device.index is not None else _cur_dev()))
-    t = _TICKETS.get(key)
-    if t is None:
-        t = _TICKETS[key] = torch.zeros(_lib.TAIL_TICKETS, dtype=torch.int32, device=device)     # (zeroed on the stream that will use it)
-    return t
-
-
 _HIPRT = []
 
 
@@ -748,38 +733,13 @@ def norm_stats_from_conv(cs, per_sample_glc, eps, running_mean=None, running_var
 
 def conv2d_fwd_norm(x, w, bias, stride, pad, dil, pad_mode, out_f32, glc, eps, running_mean=None, running_var=None, momentum=0.1):
     """(y, mean, rstd): y = conv(x, w) + bias with the batch statistics of the normalisation layer that follows (view [G][L][C] of y;
-    running statistics updated) - ONE library call, and where the kernel family serves it one launch (in-kernel tails).  mean is None
-    when no conv epilogue takes statistics for this geometry (the caller runs a statistics pass over y)."""
+    running statistics updated): the conv's epilogue takes the statistics, one small launch finalises them.  mean is None when no conv
+    epilogue takes statistics for this geometry (the caller runs a statistics pass over y)."""
     g, l, c = glc
-    if not TAILS[0]:
-        y, cs = conv2d_fwd(x, w, bias, stride, pad, dil, pad_mode, ACT_NONE, 0.0, out_f32, stats=(g, l))
-        if cs is None:
-            return y, None, None
-        mean, rstd = norm_stats_from_conv(cs, glc, eps, running_mean, running_var, momentum)
-        return y, mean, rstd
-    if x.dtype == torch.float32:
-        cp = _padded_stem(x.shape, w.shape, stride, pad, dil, pad_mode, 0)
-        if cp:
-            d0 = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, ACT_NONE, 0.0, F32, BF16X3, F32, _prec(), 0)
-            return _timed("fwd", d0, lambda: _unprofiled(lambda: conv2d_fwd_norm(resize_channels(x, cp), _padded_weight(w, cp), bias, stride, pad, dil,
-                                                                                  pad_mode, out_f32, glc, eps, running_mean, running_var, momentum)))
-    wop, wdt, wplane = _fwd_operands(x, w, (stride, pad, dil, pad_mode))
-    ydt = _out_dtype(out_f32)
-    d = make_desc(x.shape, w.shape, stride, pad, dil, pad_mode, ACT_NONE, 0.0, _dt(x), wdt, _DT[ydt], _prec(), wplane)
-    y = empty_nhwc(d.N, d.K, d.P, d.Q, x.device, ydt)
-    ws = _WS.get(_ws_bytes(d, "fwd"), x.device)
-    nb = _stats_bytes(d, g, l)
-    if not nb:
-        _timed("fwd", d, lambda: check(lib.sscg_conv2d_fwd(C.byref(d), x.data_ptr(), wop.data_ptr(), _ptr(bias), y.data_ptr(),
-                                                           ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_fwd"))
+    y, cs = conv2d_fwd(x, w, bias, stride, pad, dil, pad_mode, ACT_NONE, 0.0, out_f32, stats=(g, l))
+    if cs is None:
         return y, None, None
-    sbuf = torch.empty(nb, dtype=torch.uint8, device=x.device)
-    mean = torch.empty((g, c), dtype=torch.float32, device=x.device)
-    rstd = torch.empty((g, c), dtype=torch.float32, device=x.device)
-    tk = _tickets(x.device)
-    _timed("fwd", d, lambda: check(lib.sscg_conv2d_fwd_norm_stats(
-        C.byref(d), x.data_ptr(), wop.data_ptr(), _ptr(bias), y.data_ptr(), g, l, sbuf.data_ptr(), nb, eps, mean.data_ptr(), rstd.data_ptr(),
-        _ptr(running_mean), _ptr(running_var), momentum, tk.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "sscg_conv2d_fwd_norm_stats"))
+    mean, rstd = norm_stats_from_conv(cs, glc, eps, running_mean, running_var, momentum)
     return y, mean, rstd
 
 
@@ -859,17 +819,6 @@ def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NO
         if nb:
             sums = torch.empty(nb, dtype=torch.uint8, device=dy.device)
             fused_reads = dx.numel() * dx.element_size() * (1 + (1 if res else 0) + (1 if addend is not None else 0))      # nx [, z] [, addend]
-            if TAILS[0]:
-                # the layer's backward coefficients [G][C][2] and dgamma [C], dbeta [C] come out of this call (of the launch itself where
-                # the family serves it): norm_bwd_from_sums only applies them
-                fin = torch.empty(g * c * 2 + 2 * c, dtype=torch.float32, device=dy.device)
-                tk = _tickets(dy.device)
-                _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad_bsums_fin(
-                    C.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), nx.data_ptr(), z.data_ptr() if res else None, _ptr(addend),
-                    mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta), g, l, nact, nslope, sums.data_ptr(), nb, fin.data_ptr(),
-                    fin.data_ptr() + 4 * g * c * 2, fin.data_ptr() + 4 * (g * c * 2 + c), tk.data_ptr(), ws.data_ptr(), ws.numel(),
-                    _stream()), "sscg_conv2d_dgrad_bsums_fin"), extra_bytes=fused_reads)
-                return dx, (d, sums, res, fin), joinable
             _timed("dgrad", d, lambda: check(lib.sscg_conv2d_dgrad_bsums(
                 C.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), nx.data_ptr(), z.data_ptr() if res else None, _ptr(addend),
                 mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta), g, l, nact, nslope, sums.data_ptr(), nb, ws.data_ptr(),
@@ -1008,15 +957,6 @@ def norm_bwd_from_sums(rec, dy, x, mean, rstd, gamma, beta, per_sample, act, slo
     g, l, c = _glc(x, per_sample)
     dx = torch.empty_like(x, memory_format=CL)
     dres = torch.empty_like(x, memory_format=CL) if want_dres else None
-    fin = rec[3] if len(rec) > 3 else None
-    if fin is not None:         # the data gradient's call left the coefficients (and dgamma / dbeta behind them): apply only
-        if dgamma is not None and dgamma.data_ptr() != fin.data_ptr() + 4 * g * c * 2:
-            dgamma.copy_(fin[g * c * 2:g * c * 2 + c])
-            dbeta.copy_(fin[g * c * 2 + c:])
-        check(lib.sscg_norm_bwd_from_coef(fin.data_ptr(), dy.data_ptr(), x.data_ptr(), _ptr(y), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
-                                          _ptr(beta), dx.data_ptr(), _ptr(dres), _same_dtype(x, dy), g, l, c, act, slope, _stream()),
-              "sscg_norm_bwd_from_coef")
-        return dx, dres
     ws = _WS.get(g * c * 8, x.device)
     check(lib.sscg_norm_bwd_from_sums(C.byref(d), sums.data_ptr(), dy.data_ptr(), x.data_ptr(), _ptr(y), mean.data_ptr(), rstd.data_ptr(),
                                       _ptr(gamma), _ptr(beta), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _same_dtype(x, dy), g, l,

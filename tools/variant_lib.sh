@@ -6,10 +6,12 @@ SUF=$1; SRC=$2; DEFS=$3
 CS=$(cd "$(dirname "$0")/../semi-supervised-segmentation-cyclegan_amd/csrc" && pwd)
 cd $CS
 EXTRA=""; [ "$SRC" = "conv_split.hip" ] && EXTRA="-fno-slp-vectorize"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA $DEFS -c $SRC -o /tmp/variant_$SUF.o
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}; ARCH=${ARCH:-gfx950}
+OBJ=$(mktemp -d)/variant_$SUF.o          # (private: concurrent variant builds do not collide)
+$HIPCC --offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA $DEFS -c $SRC -o $OBJ
 OBJS=""
 for f in conv_igemm conv_bf16 conv_split conv_thin conv_wgrad norm pointwise loss_optim; do
-  if [ "$f.hip" = "$SRC" ]; then OBJS="$OBJS /tmp/variant_$SUF.o"; else OBJS="$OBJS $f.o"; fi
+  if [ "$f.hip" = "$SRC" ]; then OBJS="$OBJS $OBJ"; else OBJS="$OBJS $f.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsscg_$SUF.so $OBJS
+$HIPCC --offload-arch=$ARCH -shared -fPIC -o ../libsscg_$SUF.so $OBJS
 ls -la ../libsscg_$SUF.so
