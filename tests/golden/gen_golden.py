@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 REF = "/root/reference"
 sys.dont_write_bytecode = True
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REF)
 warnings.filterwarnings("ignore")
 
@@ -496,11 +497,106 @@ def g6_perceptual(meta):
     meta["g6_perceptual"] = {"loss_f32": float(out["loss/f32"]), "loss_f64": float(out["loss/f64"])}
 
 
+# ------------------------------------------------------------------ G8: the reference's own data_utils code
+from data_trees import data_trees  # noqa: E402  (tests/golden/data_trees.py: shared with tests/test_data_utils.py)
+
+
+def g8_data(meta):
+    """The reference's data_utils imported live (its `scipy.misc` import stubbed; torchvision's transform classes stay absent): the
+    seeded labeled / unlabeled / val / test selections of the three datasets for several ratios, the item protocol (sample names,
+    label paths, Cityscapes encode_segmap on the way out) under identity transforms, encode_segmap / Relabel / ToLabel on every
+    8-bit label id.  The build's data_utils must reproduce every one of them (asserted here, and by tests/test_data_utils.py against
+    the written g8_data.json with the recorded directory listings replayed)."""
+    import importlib.util
+    import shutil
+    import scipy
+    sys.modules.setdefault("scipy.misc", types.ModuleType("scipy.misc"))
+    scipy.misc = sys.modules["scipy.misc"]
+    import data_utils as rdu                       # the reference's package (REF is on sys.path)
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("sscg_amd", os.path.join(ROOT, "semi-supervised-segmentation-cyclegan_amd", "__init__.py"),
+                                                  submodule_search_locations=[os.path.join(ROOT, "semi-supervised-segmentation-cyclegan_amd")])
+    bdu = None
+    try:
+        pkg = importlib.util.module_from_spec(spec)
+        sys.modules["sscg_amd"] = pkg
+        spec.loader.exec_module(pkg)
+        bdu = importlib.import_module("sscg_amd.data_utils")
+    except Exception as e:                          # (the package import needs libsscg.so; data_utils itself does not)
+        print("[g8] build package not importable here (%s): reference side only" % type(e).__name__)
+    root = "/tmp/gg_data"
+    shutil.rmtree(root, ignore_errors=True)
+    roots = data_trees(root)
+    ident = {"img": lambda im: np.array(im).shape, "gt": lambda im: torch.from_numpy(np.array(im)).long().unsqueeze(0)}
+    out = {"listings": {}, "splits": {}, "items": {}}
+    # listings as the reference's split code sees them (relative to the tree's root)
+    import utils as rutils
+    city = roots["cityscapes"]
+    for split in ("train", "val", "test"):
+        out["listings"]["cityscapes/" + split] = [os.path.relpath(q, city) for q in rutils.recursive_glob(rootdir=os.path.join(city, "leftImg8bit", split), suffix=".png")]
+    for d in ("training", "testing"):
+        out["listings"]["acdc/" + d] = os.listdir(os.path.join(roots["acdc"], d))
+    classes = {"voc2012": (rdu.VOCDataset, "VOCDataset"), "cityscapes": (rdu.CityscapesDataset, "CityscapesDataset"), "acdc": (rdu.ACDCDataset, "ACDCDataset")}
+    for ds, (rcls, cname) in classes.items():
+        for ratio in (0.5, 0.2, 0.1, 0.8):
+            for name in ("label", "unlabel", "val", "test"):
+                if name in ("val", "test") and ratio != 0.5:
+                    continue
+                r = rcls(root_path=roots[ds], name=name, ratio=ratio, transformation=ident, augmentation=None)
+                sel = list(r.imgs) if ds == "voc2012" else list(r.files[name])
+                rel_sel = [str(q) if ds != "cityscapes" else os.path.relpath(str(q), roots[ds]) for q in sel]
+                out["splits"]["%s/%s/%g" % (ds, name, ratio)] = rel_sel
+                if bdu is not None:
+                    b = getattr(bdu, cname)(root_path=roots[ds], name=name, ratio=ratio, transformation=ident, augmentation=None)
+                    assert [str(q) for q in b.items] == [str(q) for q in sel], (ds, name, ratio)
+                if ratio == 0.5:
+                    items = []
+                    for i in range(min(len(r), 5)):
+                        it = r[i]
+                        rec = {"name": it[-1], "img_shape": list(it[0])}
+                        if name != "test":
+                            rec["gt_sum"] = int(it[1].sum())
+                            rec["gt_max"] = int(it[1].max())
+                        items.append(rec)
+                        if bdu is not None:
+                            bi = b[i]
+                            assert bi[-1] == it[-1] and tuple(bi[0]) == tuple(it[0]), (ds, name, i, bi[-1], it[-1])
+                            if name != "test":
+                                assert torch.equal(bi[1], it[1]), (ds, name, i)
+                    out["items"]["%s/%s" % (ds, name)] = items
+    # label tables: every 8-bit id through the reference's own code
+    ids = torch.arange(256, dtype=torch.int64).reshape(1, 16, 16)
+    cds = rdu.CityscapesDataset(root_path=roots["cityscapes"], name="val", ratio=0.5, transformation=ident, augmentation=None)
+    out["encode_segmap"] = cds.encode_segmap(ids.clone()).reshape(-1).tolist()
+    out["relabel_255_0"] = rdu.Relabel(255, 0)(ids.clone()).reshape(-1).tolist()
+    lab_img = Image.fromarray(np.arange(256, dtype=np.uint8).reshape(16, 16))
+    tl = rdu.ToLabel()(lab_img)
+    assert tl.dtype == torch.int64 and tuple(tl.shape) == (1, 16, 16)
+    out["to_label"] = {"dtype": "int64", "shape": list(tl.shape), "values": tl.reshape(-1).tolist()}
+    if bdu is not None:
+        assert bdu.cityscapes_encode(ids.clone()).reshape(-1).tolist() == out["encode_segmap"]
+        assert bdu.label_table("cityscapes").tolist() == out["encode_segmap"]
+        assert bdu.label_table("voc2012").tolist() == out["relabel_255_0"]
+        assert bdu.label_table("acdc").tolist() == list(range(256))
+        assert torch.equal(bdu.ToLabel()(lab_img), tl)
+        print("[g8] build data_utils == reference data_utils on %d selections, %d item lists, 3 label tables" % (len(out["splits"]), len(out["items"])))
+    with open(os.path.join(OUT, "g8_data.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    meta["g8_data"] = {"selections": len(out["splits"]), "item_lists": len(out["items"])}
+
+
 def main():
     if "--only-g6" in sys.argv:           # add the perceptual golden without re-running the half-hour of step goldens
         install_stubs()
         meta = json.load(open(os.path.join(OUT, "meta.json")))
         g6_perceptual(meta)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        return
+    if "--only-g8" in sys.argv:           # the data pipeline's golden alone
+        install_stubs()
+        meta = json.load(open(os.path.join(OUT, "meta.json")))
+        g8_data(meta)
         with open(os.path.join(OUT, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, sort_keys=True)
         return
@@ -523,6 +619,7 @@ def main():
     print("g3 done")
     g4(meta, md)
     g6_perceptual(meta)
+    g8_data(meta)
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote", OUT)

@@ -1,6 +1,8 @@
 """Input pipeline: wire format and split logic of data_utils on small image trees built on the fly.
-The reference's transforms are torchvision's (not installed here, and `data_utils` imports `scipy.misc`): parity is
-pinned on the documented semantics of those transforms and on the reference's own split code, not on a live import."""
+Pinned against the LIVE reference where the reference's code is its own (tests/golden/g8_data.json, written by gen_golden.py g8_data
+from /root/reference/data_utils with `scipy.misc` stubbed): the seeded labeled / unlabeled / val / test selections, the item protocol
+and sample names, encode_segmap / Relabel / ToLabel.  Only torchvision's Resize / CenterCrop / ToTensor / Normalize (absent here)
+remain pinned on their documented semantics."""
 import os
 
 import numpy as np
@@ -213,3 +215,92 @@ def test_cityscapes_layout_label_encoding_and_split(tmp_path, monkeypatch):
     rawds = du.CityscapesDataset(root_path=root, name="label", ratio=0.5, transformation=trd)
     _, gt_u8, _ = rawds[0]
     assert gt_u8.dtype == torch.uint8 and torch.equal(trd["lut"][gt_u8.long()], gt[0])
+
+
+# ------------------------------------------------------------------------------------------ pinned against the LIVE reference (g8)
+def _g8():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_data.json")))
+
+
+def _replay_listings(monkeypatch, du, roots, g8):
+    """os.walk / os.listdir order is a property of the file system: the selections of the golden were drawn from the listings the
+    generating machine returned, so the test replays exactly those."""
+    dl = load_sub("data_utils.dataloader")
+    city, acdc = roots["cityscapes"], roots["acdc"]
+    real_glob, real_listdir = dl.recursive_glob, os.listdir
+
+    def glob(rootdir=".", suffix=""):
+        for split in ("train", "val", "test"):
+            if os.path.normpath(rootdir) == os.path.normpath(os.path.join(city, "leftImg8bit", split)):
+                return [os.path.join(city, q) for q in g8["listings"]["cityscapes/" + split]]
+        return real_glob(rootdir, suffix)
+
+    def listdir(path="."):
+        for d in ("training", "testing"):
+            if os.path.normpath(str(path)) == os.path.normpath(os.path.join(acdc, d)):
+                got = real_listdir(path)
+                assert sorted(got) == sorted(g8["listings"]["acdc/" + d])
+                return list(g8["listings"]["acdc/" + d])
+        return real_listdir(path)
+    monkeypatch.setattr(dl, "recursive_glob", glob)
+    monkeypatch.setattr(os, "listdir", listdir)
+
+
+def test_selections_and_items_equal_the_live_references(tmp_path, monkeypatch):
+    """tests/golden/g8_data.json was written by the REFERENCE's data_utils (dataloader.py:41-64,151-175,311-320 seeded selections for
+    ratios 0.5 / 0.2 / 0.1 / 0.8, :93-117,236-258,362-393 item protocol) run over tests/golden/data_trees.py; the build's datasets
+    must select the same files in the same order and return the same (shape, label map, sample name) items."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from data_trees import data_trees
+    du = load_sub("data_utils")
+    g8 = _g8()
+    roots = data_trees(str(tmp_path))
+    _replay_listings(monkeypatch, du, roots, g8)
+    ident = {"img": lambda im: np.array(im).shape, "gt": lambda im: torch.from_numpy(np.array(im)).long().unsqueeze(0)}
+    cls = {"voc2012": du.VOCDataset, "cityscapes": du.CityscapesDataset, "acdc": du.ACDCDataset}
+    n_sel = 0
+    for key, want in g8["splits"].items():
+        ds, name, ratio = key.split("/")
+        b = cls[ds](root_path=roots[ds], name=name, ratio=float(ratio), transformation=ident, augmentation=None)
+        got = [str(q) if ds != "cityscapes" else os.path.relpath(str(q), roots[ds]) for q in b.items]
+        assert got == want, key
+        n_sel += 1
+        if float(ratio) == 0.5:
+            for i, rec in enumerate(g8["items"]["%s/%s" % (ds, name)]):
+                it = b[i]
+                assert it[-1] == rec["name"] and list(it[0]) == rec["img_shape"], (key, i)
+                if name != "test":
+                    assert int(it[1].sum()) == rec["gt_sum"] and int(it[1].max()) == rec["gt_max"], (key, i)
+    assert n_sel == 30
+
+
+def test_label_tables_equal_the_live_references():
+    """CityscapesDataset.encode_segmap (dataloader.py:272-279), Relabel(255, 0) and ToLabel (data_utils/__init__.py:25-51) on every
+    8-bit id, as the reference's own code returned them - against the host transforms and the 256-entry tables sscg_label_lut applies."""
+    du = load_sub("data_utils")
+    g8 = _g8()
+    ids = torch.arange(256, dtype=torch.int64).reshape(1, 16, 16)
+    assert du.cityscapes_encode(ids.clone()).reshape(-1).tolist() == g8["encode_segmap"]
+    assert du.label_table("cityscapes").tolist() == g8["encode_segmap"]
+    assert du.Relabel(255, 0)(ids.clone()).reshape(-1).tolist() == g8["relabel_255_0"]
+    assert du.label_table("voc2012").tolist() == g8["relabel_255_0"]
+    tl = du.ToLabel()(Image.fromarray(np.arange(256, dtype=np.uint8).reshape(16, 16)))
+    assert str(tl.dtype) == "torch." + g8["to_label"]["dtype"] and list(tl.shape) == g8["to_label"]["shape"]
+    assert tl.reshape(-1).tolist() == g8["to_label"]["values"]
+
+
+@pytest.mark.gpu
+def test_device_label_tables_equal_the_live_references():
+    """sscg_label_lut with the build's tables on every 8-bit id (uint8 batch on the MI355X) = what the reference's encode_segmap /
+    Relabel returned for it (g8_data.json)."""
+    du, F = load_sub("data_utils"), load_sub("functional")
+    g8 = _g8()
+    dev = torch.device("cuda:0")
+    u8 = torch.arange(256, dtype=torch.uint8).reshape(1, 16, 16).repeat(3, 1, 1).to(dev)
+    for ds, key in (("cityscapes", "encode_segmap"), ("voc2012", "relabel_255_0")):
+        out = F.label_lut(u8, du.label_table(ds).to(dev))
+        assert out.dtype == torch.int64 and tuple(out.shape) == (3, 1, 16, 16)
+        for b in range(3):
+            assert out[b].reshape(-1).tolist() == g8[key]
