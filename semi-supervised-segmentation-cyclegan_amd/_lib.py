@@ -134,14 +134,30 @@ def _load():
         raise ImportError("libsscg.so ABI version %d != binding version %d" % (v, ABI_VERSION))
     if os.environ.get("SSCG_TRACE"):
         return _Traced(lib)
-    if os.environ.get("SSCG_RACECHECK"):        # debug: log every launch into the stream-ordering checker (racecheck.py)
-        from . import racecheck
+    if os.environ.get("SSCG_RACECHECK"):        # debug: log every launch into the stream-ordering checker (tools/racecheck.py)
+        racecheck = dev_tool("racecheck")
         racecheck.install()
         return racecheck._Checked(lib)
     if os.environ.get("SSCG_FUZZ"):             # debug: schedule fuzzer (racecheck.fuzz(seed) switches it on)
-        from . import racecheck
-        return racecheck._Fuzzed(lib)
+        return dev_tool("racecheck")._Fuzzed(lib)
     return lib
+
+
+def dev_tool(name):
+    """A development tool from the repository's tools/ directory (not part of the library: the stream-ordering checker and schedule
+    fuzzer wrap the ctypes handle when SSCG_RACECHECK / SSCG_FUZZ ask for them), loaded once under its plain module name."""
+    import importlib.util
+    import sys
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(os.path.dirname(_HERE), "tools", name + ".py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    if spec is None or not os.path.exists(path):
+        raise ImportError("development tool %s not found at %s" % (name, path))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
 
 
 class _Traced:

@@ -992,209 +992,11 @@ struct Wg16Params {
     FastDiv div_pq, div_q;
 };
 
-// 8 pixels x 8 channels (eight 16-byte rows, channel pairs packed in words) -> 8 channels x 8 pixels (eight 16-byte rows)
-struct U4 { uint32_t v[4]; };
-__device__ __forceinline__ void transpose_8x8(const U4 r[8], U4 out[8]) {
-    // v_perm_b32 D, S0, S1, sel: byte i of D = byte sel[i] of the 8-byte value {S0 (bytes 4-7), S1 (bytes 0-3)}
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {          // word w of a row = channels 2w (low half), 2w+1 (high half)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {   // pixel pair (2jj, 2jj+1)
-            out[2 * w].v[jj] = __builtin_amdgcn_perm(r[2 * jj + 1].v[w], r[2 * jj].v[w], 0x05040100u);       // (odd.lo << 16) | even.lo
-            out[2 * w + 1].v[jj] = __builtin_amdgcn_perm(r[2 * jj + 1].v[w], r[2 * jj].v[w], 0x07060302u);   // (odd.hi << 16) | even.hi
-        }
-    }
-}
-
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void wgrad16_kernel(Wg16Params p) {
-    constexpr int BM = WM * TM * 32;
-    constexpr int BN = WN * TN * 32;
-    static_assert(WM * WN == 4 && BM + BN <= 256, "4 waves per workgroup; one 8x8 piece per thread");
-
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    bf16* As = reinterpret_cast<bf16*>(smem_raw);      // [2][BM][64]: row = output channel k, 64 pixels contiguous
-    bf16* Bs = As + 2 * BM * BKP;                       // [2][BN][64]: row = (tap, c)
-
-    const int tid = threadIdx.x;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = lin / p.tiles;
-    const int tl = lin - split * p.tiles;
-    const int tile_n = tl % p.tiles_n;
-    const int tile_m = tl / p.tiles_n;
-    const int m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
-    const int p_begin = split * p.chunk;
-    const int p_end = min(p.npix, p_begin + p.chunk);
-    const bool reflect = p.pad_mode == 1;
-
-    // One piece per thread: 8 pixels (block pb of the k-step) x 8 channels (group grp).  Eight consecutive lanes hold the
-    // eight pixel blocks of one channel group: a global load instruction reads 8 x 16 B = one 128-byte line per pixel row
-    // and eight channel groups, a ds_write_b128 lane group fills one whole 128-byte LDS row (conflict free).
-    const bool active = tid < BM + BN;
-    const bool isA = tid < BM;                  // wave-uniform: BM, BN are multiples of 64
-    const int qq = isA ? tid : tid - BM;
-    const int grp = qq >> 3;
-    const int pb = qq & 7;
-    bool col_ok = false;
-    const bf16* base = p.dy;
-    int tdy = 0, tdx = 0;
-    if (active) {
-        if (isA) {
-            const int m = m0 + grp * 8;
-            col_ok = m < p.Kc;
-            base = p.dy + (col_ok ? m : 0);
-        } else {
-            const int n = n0 + grp * 8;
-            col_ok = n < p.Ng;
-            const int nn = col_ok ? n : 0;
-            const int tap = nn / p.C;
-            const int c = nn - tap * p.C;
-            const int ky = tap / p.S;
-            const int kx = tap - ky * p.S;
-            tdy = ky * p.dil - p.pad;
-            tdx = kx * p.dil - p.pad;
-            base = p.x + c;
-        }
-    }
-
-    U4 stage[8];
-    // masked rows (past the pixel range, padding) read a page of zeros: the staged registers need no select afterwards and are
-    // not touched (= not waited for) until the MFMAs of the current tile have been issued
-    const bf16* const zero16 = reinterpret_cast<const bf16*>(sscg_zero_page16);
-    auto load_tile = [&](int pt) {
-        if (!active) return;
-        const int pix0 = pt + pb * 8;
-        if (isA) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int pix = pix0 + j;
-                const bool ok = col_ok && pix < p_end;
-                const bf16* src = ok ? base + (size_t)pix * p.Kc : zero16;
-                const uint4 v = *reinterpret_cast<const uint4*>(src);
-                stage[j].v[0] = v.x; stage[j].v[1] = v.y; stage[j].v[2] = v.z; stage[j].v[3] = v.w;
-            }
-        } else {
-            // decode the first pixel, then walk (ox, oy, img) incrementally
-            const int pp = pix0 < p_end ? pix0 : 0;
-            int img = fd_div(pp, p.div_pq);
-            const int rem = pp - img * (p.P * p.Q);
-            int oy = fd_div(rem, p.div_q);
-            int ox = rem - oy * p.Q;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bool ok = col_ok && (pix0 + j) < p_end;
-                int sy = oy * p.stride + tdy;
-                int sx = ox * p.stride + tdx;
-                int ry = sy < 0 ? -sy : sy;
-                int rx = sx < 0 ? -sx : sx;
-                ry = ry >= p.H ? 2 * (p.H - 1) - ry : ry;
-                rx = rx >= p.W ? 2 * (p.W - 1) - rx : rx;
-                sy = reflect ? ry : sy;
-                sx = reflect ? rx : sx;
-                ok = ok & ((unsigned)sy < (unsigned)p.H) & ((unsigned)sx < (unsigned)p.W);
-                const bf16* src = ok ? base + (size_t)((img * p.H + sy) * p.W + sx) * p.C : zero16;
-                const uint4 v = *reinterpret_cast<const uint4*>(src);
-                stage[j].v[0] = v.x; stage[j].v[1] = v.y; stage[j].v[2] = v.z; stage[j].v[3] = v.w;
-                // next pixel, branch-free (a branch here splits the loads over basic blocks and the compiler then waits for each)
-                ++ox;
-                const bool wx = ox == p.Q;
-                ox = wx ? 0 : ox;
-                oy += wx ? 1 : 0;
-                const bool wy = oy == p.P;
-                oy = wy ? 0 : oy;
-                img += wy ? 1 : 0;
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-        if (!active) return;
-        U4 out[8];
-        transpose_8x8(stage, out);
-        bf16* img = isA ? As + buf * BM * BKP : Bs + buf * BN * BKP;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int row = grp * 8 + c;
-            uint4 w = {out[c].v[0], out[c].v[1], out[c].v[2], out[c].v[3]};
-            *reinterpret_cast<uint4*>(img + row * BKP + ((pb ^ swz(row)) * 8)) = w;
-        }
-    };
-
-    const int wave = tid >> 6;
-    const int lane = tid & 63;
-    const int li = lane & 31;
-    const int lh = lane >> 5;
-    const int wm = wave / WN;
-    const int wn = wave % WN;
-    const int row_w = wm * TM * 32;
-    const int col_w = wn * TN * 32;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nsteps = (p_end - p_begin + BKP - 1) / BKP;
-    if (nsteps > 0) {
-        load_tile(p_begin);
-        store_tile(0);
-    }
-    __syncthreads();
-    const int sw = swz(li);
-    for (int it = 0; it < nsteps; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nsteps) load_tile(p_begin + (it + 1) * BKP);      // global loads fly under the MFMAs
-        const bf16* a = As + buf * BM * BKP + (row_w + li) * BKP;
-        const bf16* b = Bs + buf * BN * BKP + (col_w + li) * BKP;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int off = ((kk * 2 + lh) ^ sw) * 8;
-            bf16x8 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * BKP + off);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * BKP + off);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);      // MFMAs first, then the transpose + LDS stores of the next tile, then the barrier
-        if (it + 1 < nsteps) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-
-    float* out = p.out + (size_t)split * p.Kc * p.Ng;
-    const bool direct = (p.splits == 1);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + col_w + j * 32 + li;
-        if (n >= p.Ng) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < p.Kc) {
-                    const size_t o = (size_t)m * p.Ng + n;
-                    float v = acc[i][j][e];
-                    if (direct && p.beta != 0.f) v += p.beta * out[o];
-                    out[o] = v;
-                }
-            }
-        }
-    }
-}
-
 // ---- weight gradient, LDS-DMA + transpose-read version -------------------------------------------------------------------------
 // The operands are [pixel][channel] in HBM: contiguous along the OUTPUT axes, strided along the reduction (pixels), while an
-// MFMA operand is 8 consecutive k (= pixels) of one output row.  wgrad16_kernel above transposes 8x8 pieces in registers and
-// pays 32 v_perm + 8 ds_write_b128 per thread and k-step (the ds_write path alone is ~400 of a k-step's 512 MFMA cycles).
-// gfx950's `ds_read_b64_tr_b16` transposes on the way OUT of LDS instead: a 16-lane group reads a [4 pixels][16 channels]
+// MFMA operand is 8 consecutive k (= pixels) of one output row.  (Rounds 1-5 kept a first version that transposed 8x8 pieces in
+// registers - 32 v_perm + 8 ds_write_b128 per thread and k-step, the ds_write path alone ~400 of a k-step's 512 MFMA cycles: 350-450
+// against 480-780 TF/s; deleted in round 6.)  gfx950's `ds_read_b64_tr_b16` transposes on the way OUT of LDS: a 16-lane group reads a [4 pixels][16 channels]
 // block (lane i supplies the address of 4 consecutive channels of pixel i >> 2) and lane i receives the 4 pixels of channel i.
 // So the [pixel][channel] rows go to LDS as they are, by LDS-DMA (no staging registers, no ds_write), NSTAGE - 1 k-tiles in
 // flight, and the fragments come from two transpose-reads per operand.
@@ -1461,21 +1263,6 @@ Wg16Plan plan_wg16(const sscg_conv_desc* d) {
     return pl;
 }
 
-template <int WM, int WN, int TM, int TN>
-int launch_wg16(Wg16Params p, int splits, hipStream_t st) {
-    constexpr int BM = WM * TM * 32;
-    constexpr int BN = WN * TN * 32;
-    p.tiles_n = cdiv(p.Ng, BN);
-    p.tiles = cdiv(p.Kc, BM) * p.tiles_n;
-    p.splits = splits;
-    const size_t smem = (size_t)(2 * BM * BKP + 2 * BN * BKP) * sizeof(bf16);
-    auto kern = wgrad16_kernel<WM, WN, TM, TN>;
-    SSCG_ENSURE_SMEM((kern), smem);
-    hipLaunchKernelGGL(kern, dim3(p.tiles * splits), dim3(256), smem, st, p);
-    SSCG_LAUNCH_CHECK();
-    return SSCG_OK;
-}
-
 template <int WM, int WN, int TM, int TN, int NSTAGE>
 int launch_wg16t(Wg16Params p, int splits, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
@@ -1522,9 +1309,7 @@ int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* 
     int rc;
     const int flags = (d->wgrad_tuning >> 24) & 0xff;
     const int variant = (flags >> 1) & 7;                // tools/conv16_bench.py: 0 = default
-    if (flags & 1) {                                     // register-transposing kernel (kept for comparison)
-        rc = pl.cfg == 0 ? launch_wg16<2, 2, 2, 2>(p, pl.splits, st) : launch_wg16<2, 2, 1, 1>(p, pl.splits, st);
-    } else if (pl.cfg == 0) {
+    if (pl.cfg == 0) {
         // 128x128 tile as 8 waves of 64x32: 4 waves per SIMD with two workgroups per CU (550 -> 665 TF/s on the 256-ch 3x3)
         rc = variant == 1 ? launch_wg16t<2, 2, 2, 2, 2>(p, pl.splits, st) : launch_wg16t<2, 4, 2, 1, 2>(p, pl.splits, st);
     } else {

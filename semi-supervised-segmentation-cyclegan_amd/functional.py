@@ -240,6 +240,15 @@ def lane_events(device):
 # gradient kernel of this backward pass that accumulates into its arena slice has been queued.  "Last" is known by counting: every
 # forward of a conv whose weight will receive a gradient notes one use (_note_use), every backward of one takes it back (_note_done).
 GRAD_READY = [None]
+# grad mode of the CALLER of the autograd.Function being applied (inside forward() it is always off): ctx.needs_input_grad is True
+# for a trainable weight under torch.no_grad() as well, but such a forward never sees a backward - it must neither count a use nor keep
+# pre-norm activations alive for one (the unused Gis(lab_gt) pass of a step, evaluation, validation)
+_CALLER_GRAD = [True]
+
+
+def _will_backward(ctx, i=None):
+    need = any(ctx.needs_input_grad) if i is None else ctx.needs_input_grad[i]
+    return bool(need) and _CALLER_GRAD[0]
 
 
 def _note_use(*params):
@@ -646,7 +655,7 @@ def resize_channels(x, c_new):
     """[N, C, H, W] (channels-last) or a [K, C, R, S] weight -> the same with c_new channels: zero-padded or cut (fp32)."""
     x = x if x.is_contiguous(memory_format=CL) else x.contiguous(memory_format=CL)
     n, c, h, w = x.shape
-    y = torch.empty((n, c_new, h, w), dtype=torch.float32, device=x.device).contiguous(memory_format=CL)
+    y = empty_nhwc(n, c_new, h, w, x.device)
     check(lib.sscg_resize_channels(x.data_ptr(), y.data_ptr(), n * h * w, c, c_new, _stream()), "sscg_resize_channels")
     return y
 
@@ -678,7 +687,7 @@ def _padded_head(xshape, wshape, stride, pad, dil):
 def _pad_filters(w, k_new):
     """[K, C, R, S] -> [k_new, C, R, S] with zero filters appended (a device copy of the K * R * S * C leading elements)."""
     w = w if w.is_contiguous(memory_format=CL) else w.contiguous(memory_format=CL)
-    wp = torch.empty((k_new,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device).contiguous(memory_format=CL)
+    wp = empty_nhwc(k_new, w.shape[1], w.shape[2], w.shape[3], w.device)
     fill_(wp, 0.0)
     wp[:w.shape[0]].copy_(w)
     return wp
@@ -1496,7 +1505,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.wref = w
         ctx.bref = bias
-        if ctx.needs_input_grad[1]:
+        if _will_backward(ctx, 1):
             _note_use(w, bias)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         # (mean, rstd) are non-differentiable outputs: left alone, autograd hands backward() two zero-filled tensors for them -
@@ -1751,14 +1760,14 @@ class ConvNormActFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.wref, ctx.bref, ctx.gref, ctx.betaref = w, bias, gamma, beta
-        if ctx.needs_input_grad[1]:
+        if _will_backward(ctx, 1):
             _note_use(w, bias)
         need_z = act != ACT_NONE and (residual is not None or act not in (ACT_RELU, ACT_LRELU))
         ctx.save_for_backward(x, w, y, z if need_z else None, mean, rstd, gamma, beta)
         ctx.res_join = getattr(residual, "_sscg_join", None) if (residual is not None and FUSE_JOIN[0]) else None
         # (only for a forward that will see a backward: the attribute keeps y, mean, rstd alive as long as z lives - the frozen
         # generators, evaluation and validation would hold every pre-norm activation for nothing)
-        if (FUSE_BSUMS[0] and any(ctx.needs_input_grad) and act in (ACT_NONE, ACT_RELU, ACT_LRELU)
+        if (FUSE_BSUMS[0] and _will_backward(ctx) and act in (ACT_NONE, ACT_RELU, ACT_LRELU)
                 and (residual is None or FUSE_JOIN[0])):
             # for the consumer's data gradient (_conv_backward): what this unit's backward reduction needs besides dz; last entry: the
             # mask cannot be recomputed from y (a residual joined before the activation) - it is read off z, the consumer's own input
@@ -1806,7 +1815,7 @@ class ConvNormActHeadFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_hbias = hbias is not None
         ctx.wref, ctx.bref, ctx.gref, ctx.betaref, ctx.hwref, ctx.hbref = w, bias, gamma, beta, hw, hbias
-        if ctx.needs_input_grad[1]:
+        if _will_backward(ctx, 1):
             _note_use(w, bias)
         ctx.save_for_backward(x, w, y, mean, rstd, gamma, beta, hw32)
         return out
@@ -1860,6 +1869,7 @@ class ConvNormActHeadFn(torch.autograd.Function):
 def conv_norm_act_head(x, w, bias, stride, pad, dil, pad_mode, gamma, beta, hw, hbias, running_mean, running_var, per_sample, eps,
                        momentum, act, slope):
     """conv -> norm (batch statistics) -> activation -> 1x1 conv to one channel, as one node (PixelDiscriminator's tail)."""
+    _CALLER_GRAD[0] = torch.is_grad_enabled()
     return ConvNormActHeadFn.apply(x, w, bias, gamma, beta, hw, hbias, running_mean, running_var,
                                    (stride, pad, dil, pad_mode, per_sample, eps, momentum, act, slope))
 
@@ -1979,28 +1989,6 @@ class BatchSplitFn(torch.autograd.Function):
             else:
                 out[i * n:(i + 1) * n].copy_(g)
         return out, None
-
-
-class CatBatchFn(torch.autograd.Function):
-    """Two batches stacked along N (device copies); the gradient is the two halves."""
-
-    @staticmethod
-    def forward(ctx, a, b):
-        a, b = to_nhwc(a), to_nhwc(b)
-        ctx.na = a.shape[0]
-        out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device).contiguous(memory_format=CL)
-        out[:ctx.na].copy_(a)
-        out[ctx.na:].copy_(b)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        g = to_nhwc(g)
-        return (g[:ctx.na] if ctx.needs_input_grad[0] else None), (g[ctx.na:] if ctx.needs_input_grad[1] else None)
-
-
-def cat_batch(a, b):
-    return CatBatchFn.apply(a, b)
 
 
 def split_batch(x, k):
@@ -2305,6 +2293,7 @@ class WeightedSumFn(torch.autograd.Function):
 # functional spellings
 def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0, out_f32=True):
     """out_f32 matters in bf16 mode only: True keeps the result fp32 (network heads), False makes it a bf16 activation."""
+    _CALLER_GRAD[0] = torch.is_grad_enabled()
     return Conv2dFn.apply(x, w, bias, stride, pad, dil, pad_mode, act, slope, out_f32, None)
 
 
@@ -2324,6 +2313,7 @@ def backward(loss):
 def conv_norm_act(x, w, bias, stride, pad, dil, pad_mode, gamma, beta, residual, running_mean, running_var, per_sample, eps, momentum,
                   act=ACT_NONE, slope=0.0):
     """conv -> norm (batch statistics) [+ residual] -> activation as one autograd node (training-mode normalisation only)."""
+    _CALLER_GRAD[0] = torch.is_grad_enabled()
     return ConvNormActFn.apply(x, w, bias, gamma, beta, residual, running_mean, running_var,
                                (stride, pad, dil, pad_mode, per_sample, eps, momentum, act, slope))
 
@@ -2331,6 +2321,7 @@ def conv_norm_act(x, w, bias, stride, pad, dil, pad_mode, gamma, beta, residual,
 def conv2d_norm_stats(x, w, bias, stride, pad, dil, pad_mode, norm):
     """Convolution whose epilogue also produces the statistics of the normalisation layer `norm` = (per_sample, eps,
     running_mean, running_var, momentum) that follows it.  Returns (y, mean, rstd); mean/rstd None = not fused."""
+    _CALLER_GRAD[0] = torch.is_grad_enabled()
     return Conv2dFn.apply(x, w, bias, stride, pad, dil, pad_mode, ACT_NONE, 0.0, False, norm)
 
 

@@ -29,6 +29,9 @@ _DBG_TOPWAIT = [x for x in os.environ.get("SSCG_DBG_TOPWAIT", "").split(",") if 
 _PHASES = os.environ.get("SSCG_PHASE_EVENTS") == "1"      # diagnostic: timed events around the passes of a step (tools/phases.py)
 _FROZEN_AT = os.environ.get("SSCG_FROZEN_AT", "early")
 _UNUSED_AT = os.environ.get("SSCG_UNUSED_AT", "early")
+for _name, _v in (("SSCG_FROZEN_AT", _FROZEN_AT), ("SSCG_UNUSED_AT", _UNUSED_AT)):
+    if _v not in ("early", "mid", "late"):      # (a typo would silently skip a pass: BN running statistics diverge from model.py:409)
+        raise ValueError("%s=%r: expected early, mid or late" % (_name, _v))
 
 
 def _check_bf16_widths(args):
@@ -97,9 +100,6 @@ class semisuper_cycleGAN(object):
         self.as_written = getattr(args, "as_written", True)         # keep the reference's unused forwards
         self.fork_forward = getattr(args, "fork_forward", True)     # two stream lanes for the trainable generator passes
         self.stack_gsi = getattr(args, "stack_gsi", True)           # the two independent Gsi passes as one grouped-BN pass
-        # Gis(onehot_gt) and Gis(fake_gt) (:385, :408) as ONE grouped-BN pass behind the Gsi pass, everything on the main lane
-        # (no fork lane): convolutions over 17424 instead of 8712 rows, one DeepLab pass of launches fewer per direction
-        self.stack_gis = bool(getattr(args, "stack_gis", os.environ.get("SSCG_STACK_GIS", "0") == "1"))
         # D step on its own stream: it then overlaps the NEXT step's generator forwards (which read no discriminator
         # weight until :431).  Opt-in, because the three discriminator losses a step returns are then produced on that
         # stream: callers read them after `sync_losses()` (train() and bench.py do).
@@ -180,7 +180,7 @@ class semisuper_cycleGAN(object):
                 return self.old_Gis(fake)                                            # :422
         resnet_recon_img = F.run_on_side_stream(l_img.device, (unl_img, l_img), frozen_branch) if _FROZEN_AT == "early" else None
         dev = l_img.device
-        fork = F.SideStream.enabled and self.fork_forward and not self.stack_gis
+        fork = F.SideStream.enabled and self.fork_forward
         self._wait_operand_copies(torch.cuda.current_stream(dev))
         if fork:
             # Two lanes: Gis(onehot) -> Gsi(fake_img) on the fork stream, Gsi(unl) -> Gsi(l_img) -> Gis(fake_gt) here.
@@ -199,7 +199,7 @@ class semisuper_cycleGAN(object):
                 gis_first = torch.cuda.Event()
                 gis_first.record(lane)
             onehot_gt.record_stream(lane)
-        elif not self.stack_gis:
+        else:
             fake_img = self.interp(self.Gis(onehot_gt))                              # :385,390
         fake_img_all = None
         if self.stack_gsi:
@@ -223,19 +223,11 @@ class semisuper_cycleGAN(object):
         fake_gt, _ = F.upsample_softmax_ce(fake_logits, self.crop)
         if fork:
             main.wait_event(gis_first)
-        if self.stack_gis:
-            # :385 and :408 in one pass: group 0 = onehot_gt, group 1 = fake_gt - every BatchNorm of Gis normalises the two halves
-            # separately and advances its running statistics twice in the reference's order (:385 before :408)
-            fake_gt, fake_gt_gis = F.split(fake_gt, 2)
-            with arch.batch_groups(2):
-                gis_both = self.Gis(F.cat_batch(onehot_gt, fake_gt_gis))
-            fake_lo, recon_lo = F.split_batch(gis_both, 2)
-            fake_img = self.interp(fake_lo)                                          # :385,390
-            recon_img = self.interp(recon_lo)                                        # :408,413
-        else:
-            self._mark("main Gis(fake_gt): start")
-            recon_img = self.interp(self.Gis(fake_gt))                               # :408,413
-            self._mark("main Gis(fake_gt): end")
+        # (Gis(onehot_gt) and Gis(fake_gt) as ONE grouped-BatchNorm pass on the main lane was built in round 4 and measured slower than
+        # the two lanes; deleted in round 6)
+        self._mark("main Gis(fake_gt): start")
+        recon_img = self.interp(self.Gis(fake_gt))                               # :408,413
+        self._mark("main Gis(fake_gt): end")
         # :409 - output unused by the reference, but it advances Gis' BN running stats (after those of the :408 pass
         # above, which the side stream waits for).  Nothing reads the result: it runs beside the critical path and is
         # joined before the optimiser touches Gis' weights.

@@ -20,7 +20,7 @@ from oracle import fixtures as FX  # noqa: E402
 
 md = importlib.import_module(PKG_NAME + ".model")
 F = importlib.import_module(PKG_NAME + ".functional")
-rc = importlib.import_module(PKG_NAME + ".racecheck")
+rc = importlib.import_module(PKG_NAME + "._lib").dev_tool("racecheck")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 2

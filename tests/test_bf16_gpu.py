@@ -145,12 +145,12 @@ def test_conv_bf16_every_tile_class(case, cfg, dev, bf16_mode):
         F.TUNING[0], F.WGRAD_TUNING[0] = old
 
 
-@pytest.mark.parametrize("flags", [(0, "transpose-read"), (1, "register-transposing"), (2, "transpose-read/8 waves")], ids=lambda f: f[1].replace(" ", ""))
+@pytest.mark.parametrize("flags", [(0, "transpose-read"), (2, "transpose-read/8 waves")], ids=lambda f: f[1].replace(" ", ""))
 @pytest.mark.parametrize("case", [(8, 256, 33, 33, 256, 3, 1, 2, 2), (2, 64, 65, 65, 64, 3, 1, 1, 1), (2, 256, 33, 33, 1024, 1, 1, 0, 1),
                                   (2, 128, 32, 32, 256, 4, 2, 1, 1), (3, 72, 19, 23, 136, 3, 1, 1, 1)],
                          ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_s%d_p%d_d%d" % c)
 def test_wgrad_bf16_every_kernel(case, flags, dev, bf16_mode):
-    """Weight gradient kernels: LDS-DMA + ds_read_b64_tr_b16 (default; 4 or 8 waves) and the register-transposing one."""
+    """Weight gradient kernels: LDS-DMA + ds_read_b64_tr_b16 (default; 4 or 8 waves)."""
     F = bf16_mode
     n, c, h, w, k, r, s, p, d = case
     g = torch.Generator().manual_seed(9)

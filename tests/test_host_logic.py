@@ -191,11 +191,12 @@ def test_bench_cpu_baseline_leg_runs_and_reports(monkeypatch):
     finally:
         torch.set_num_threads(threads)
     assert r["kind"] == "port" and r["unit"] == "img/s" and r["value"] > 0 and r["cores"] >= 1
-    assert "32x32" in r["sample"] and "2 timed steps at the fastest setting" in r["sample"] and r["cpu_model"] in r["sample"]
+    assert "32x32" in r["sample"] and "3 timed steps at the fastest setting" in r["sample"] and r["cpu_model"] in r["sample"]
+    assert r["timed_steps"] >= 3 and r["warmup_steps"] == 1 and r["all_physical_cores"]["cores"] == r["physical_cores"]
     assert r["elided_dead_work"]["value"] > 0 and str(r["cores"]) in r["probe_seconds_per_step"]
     json.dumps(r)
-    # the thread-count search on a stub clock: 32 -> 64 pays (10 s -> 6 s), so all physical cores are tried too (9 s: over-subscribed);
-    # the fastest setting (64) is the one reported, from its two timed steps
+    # on a stub clock: one warm-up step per thread count (32, 64, all 128 physical cores), three timed steps on all cores (9 s each:
+    # inside the budget), three at the fastest setting (64), one elided step
     cost = {32: 10.0, 64: 6.0, 128: 9.0}
     clock = [0.0]
     calls = []
@@ -205,13 +206,20 @@ def test_bench_cpu_baseline_leg_runs_and_reports(monkeypatch):
         clock[0] += cost[threads] * (1.0 if as_written else 0.9)
     monkeypatch.setattr(bench, "cpu_thread_candidates", lambda physical: [32, 64, 128])
     r = bench.cpu_baseline({"dataset": "voc2012", "C": 21, "H": 256, "W": 256}, step_fn=step, now=lambda: clock[0])
-    assert calls == [32, 64, 128, 64, 64, 64] and r["cores"] == 64 and abs(r["seconds_per_step"] - 6.0) < 1e-9
-    assert abs(r["value"] - 2 / 6.0) < 1e-4
-    # 32 -> 64 does not pay: the physical-core probe is skipped
-    cost[64] = 9.5
+    assert calls == [32, 64, 128, 128, 128, 128, 64, 64, 64, 64] and r["cores"] == 64 and abs(r["seconds_per_step"] - 6.0) < 1e-9
+    assert abs(r["value"] - 2 / 6.0) < 1e-4 and r["timed_steps"] == 3
+    assert r["all_physical_cores"] == {"cores": 128, "value": round(2 / 9.0, 4), "seconds_per_step": 9.0, "timed_steps": 3, "warmup_steps": 1}
+    # an over-subscribed all-cores step (52 s: BENCH_r02) is timed once more, not three times
+    cost[128] = 52.0
     calls.clear()
     r = bench.cpu_baseline({"dataset": "voc2012", "C": 21, "H": 256, "W": 256}, step_fn=step, now=lambda: clock[0])
-    assert calls == [32, 64, 64, 64, 64] and r["cores"] == 64
+    assert calls == [32, 64, 128, 128, 64, 64, 64, 64] and r["cores"] == 64 and r["all_physical_cores"]["timed_steps"] == 1
+    assert abs(r["all_physical_cores"]["seconds_per_step"] - 52.0) < 1e-9
+    # all cores fastest: its three timed steps are the headline's
+    cost[128] = 5.0
+    calls.clear()
+    r = bench.cpu_baseline({"dataset": "voc2012", "C": 21, "H": 256, "W": 256}, step_fn=step, now=lambda: clock[0])
+    assert calls == [32, 64, 128, 128, 128, 128, 128] and r["cores"] == 128 and r["timed_steps"] == 3
 
 
 def test_plan_sizes_follow_the_descriptor_tuning():

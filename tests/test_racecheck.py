@@ -5,7 +5,7 @@ from conftest import ROOT, load_sub
 
 
 def _core():
-    return load_sub("racecheck").RaceCore()
+    return load_sub("_lib").dev_tool("racecheck").RaceCore()
 
 
 def _launch(c, s, reads=(), writes=(), what="k"):
@@ -125,7 +125,7 @@ def test_engine_handover_merges_the_producers_clock():
 
 
 def test_read_write_table_covers_the_abi():
-    rc, lib = load_sub("racecheck"), load_sub("_lib")
+    rc, lib = load_sub("_lib").dev_tool("racecheck"), load_sub("_lib")
     table = rc.parse_header(os.path.join(ROOT, "include", "sscg.h"))
     assert set(table) == set(lib.SIGNATURES)
     for name, row in table.items():

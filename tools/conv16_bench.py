@@ -62,9 +62,9 @@ for (n, c, h, w, k, r, s, p, d) in SHAPES:
             row += " | %-9s f %6.1f d %6.1f" % (name, flops / tf / 1e9, flops / td / 1e9)
         finally:
             F.TUNING[0], F.WGRAD_TUNING[0] = old
-    # weight gradient: register-transposing kernel (flag 1) vs LDS-DMA + transpose-read kernel with 2 (default) / 3-4 copy stages
+    # weight gradient: LDS-DMA + transpose-read kernel, 8 waves (default) / 4 waves, pixel-split variants
     dw_ref = None
-    for name, tune in (("wg-old", 1), ("wg8-768", 0), ("wg4", 2), ("wg8-512", 4 << 4), ("wg8-1024", 8 << 4), ("wg8-1536", 12 << 4), ("wg8-384", 3 << 4)):
+    for name, tune in (("wg8-768", 0), ("wg4", 2), ("wg8-512", 4 << 4), ("wg8-1024", 8 << 4), ("wg8-1536", 12 << 4), ("wg8-384", 3 << 4)):
         old = F.tuning(wgrad_flags=tune)
         try:
             dw = F.conv2d_wgrad(x, gy, wt.shape, s, p, d)
