@@ -103,6 +103,9 @@ def main():
     local = dp.local_rank if dp else 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # before anything is built: per-rank batch >= 2, one physical device per rank, LOCAL_RANK = the device in use
+    # (collective; a refusal costs seconds, not a warmed-up model)
+    par.preflight(dp, bsz, shared_gpu_ok=bool(os.environ.get("SSCG_DP_SHARED_GPU")))
 
     import main as cli                   # the product CLI's own defaults (oracle/ is used by the cpu_baseline leg only)
     args = cli.get_args(["--model", "semisupervised_cycleGAN", "--dataset", cfg["dataset"], "--crop_height", str(H), "--crop_width", str(W),
@@ -178,7 +181,27 @@ def main():
 
     for i in range(a.warmup):
         run(i)
+    # device memory must not grow inside the timed region (hipMalloc serialises the device; at N > 1 it also stalls the ranks that
+    # wait in the all-reduce): torch's caching allocator holds every buffer of the step (the library's workspaces are torch
+    # tensors too), so `reserved` before and after the K steps says whether the region allocated.  A region that grew is timed again
+    # (once: the pools are warm then); the line carries what happened.
+    torch.cuda.synchronize()
+    reserved0 = torch.cuda.memory_reserved(dev)
     dt, losses = timed(a.warmup, a.steps)
+    grew = torch.cuda.memory_reserved(dev) - reserved0
+    retimed = False
+    if dp is not None and world > 1:
+        grew = int(par.max_over_ranks(float(grew)))       # every rank takes the same branch
+    if grew > 0:
+        reserved0 = torch.cuda.memory_reserved(dev)
+        dt, losses = timed(a.warmup, a.steps)
+        retimed = True
+        grew2 = torch.cuda.memory_reserved(dev) - reserved0
+        if dp is not None and world > 1:
+            grew2 = int(par.max_over_ranks(float(grew2)))
+        if grew2 > 0:
+            raise SystemExit("bench.py: device memory still grows inside the timed region (+%d bytes reserved after a second pass of %d "
+                             "steps) - raise --warmup" % (grew2, a.steps))
     if os.environ.get("SSCG_PHASE_EVENTS") == "1" and rank == 0:
         # diagnostic: one more step with timed events around its passes (model.py _mark) - when each pass ran on the GPU and when
         # the host issued it, without a tracer's overhead
@@ -204,13 +227,15 @@ def main():
         "step_frac_of_mfma_peak": round(bsz * cfg["tflop_per_pair"] * a.steps / dt / peak, 4),
         "mfma_peak_tflops": peak,
         "host_issue_ms_per_step": round(1e3 * host[0], 2),
+        "timed_region_alloc": {"reserved_growth_bytes_first_pass": int(grew), "retimed": retimed, "reserved_bytes": int(torch.cuda.memory_reserved(dev))},
     }
     if host_bound_case is not None:
         out["host_bound_case"] = host_bound_case
     if dp:
         # the evidence beside `n_gpus` (= WORLD_SIZE of the environment): what the process group saw - one physical device per rank,
         # the collective library's version, every rank's own step time (collective call: every rank takes part)
-        census = par.rank_census(1e3 * own[0])
+        census = par.rank_census(1e3 * own[0], host_issue_ms=1e3 * host[0], affinity=dp.affinity)
+        census["gradient_buckets"] = par.dp_buckets(world)
         out["rccl"] = census
         if census["distinct_devices"] != census["world_size"] and not os.environ.get("SSCG_DP_SHARED_GPU"):
             raise SystemExit("bench.py: %d ranks on %d distinct devices %s - not a %d-GPU measurement (SSCG_DP_SHARED_GPU=1 marks the "
@@ -376,9 +401,22 @@ def spawn_ranks(n):
         have = 0
     if have < n:
         env.update(SSCG_DP_SHARED_GPU="1", SSCG_DP_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    rc = 1
+    for attempt in range(3):          # the port was free a moment ago; somebody may have taken it since (EADDRINUSE in the launcher): try another
+        if attempt:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(r.stderr)
+        rc = r.returncode
+        if rc == 0 or not ("EADDRINUSE" in r.stderr or "address already in use" in r.stderr.lower()):
+            break
+        print("bench.py: rendezvous port %d was taken (attempt %d), retrying on another" % (port, attempt + 1), file=sys.stderr)
+    return rc
 
 
 def pmc_traffic(fam):

@@ -78,8 +78,12 @@ class SemiSupOracle:
 
     def __init__(self, n_classes, state_dicts, lr=2e-4, lab_CE_weight=1.0, lab_MSE_weight=1.0, adversarial_weight=1.0,
                  discriminator_weight=1.0, lamda_gt=0.1, norm="instance", use_dropout=False, crop=(64, 64), as_written=False, q=None,
-                 variants=(), lamda_img=0.5):
+                 variants=(), lamda_img=0.5, gen_net="deeplab", dis_net="pixel"):
         self.C = n_classes
+        # the build's --honour_nets: model.py:215-222 hard-codes netG='deeplab' / netD='pixel' and never reads
+        # --gen_net / --dis_net (main.py:43-44); with the flag honoured the SAME step runs on what define_Gen / define_Dis build for
+        # those names (arch/generators.py:404-418 resnet_{6,9}blocks; arch/discriminators.py:42-63,83-92 n_layers).  Default = as written.
+        self.gen_net, self.dis_net = gen_net, dis_net
         # loss terms the reference has commented out (the build's --variants), restated as the commented lines read:
         #   "l1_cycle"   model.py:453  img_cycle_loss = L1(recon_img, unl_img), weighted like the other image-cycle term (lamda_img)
         #   "lab_gt_dis" model.py:439,447  gt_label_gen_loss = MSE(Ds(lab_gt), ones), an adversarial term (adversarial_weight)
@@ -94,8 +98,8 @@ class SemiSupOracle:
         self.norm = norm
         self.use_dropout = use_dropout
         self.crop = crop
-        g_params = _trainable(self.sd["Gis"], deeplab_trainable_keys(self.sd["Gis"])) + \
-            _trainable(self.sd["Gsi"], deeplab_trainable_keys(self.sd["Gsi"]))
+        gen_keys = deeplab_trainable_keys if gen_net == "deeplab" else (lambda sd_: list(sd_.keys()))   # InstanceNorm carries no state
+        g_params = _trainable(self.sd["Gis"], gen_keys(self.sd["Gis"])) + _trainable(self.sd["Gsi"], gen_keys(self.sd["Gsi"]))
         d_params = _trainable(self.sd["Di"], list(self.sd["Di"].keys())) + _trainable(self.sd["Ds"], list(self.sd["Ds"].keys()))
         self.g_params, self.d_params = g_params, d_params
         self.g_opt = torch.optim.Adam(g_params, lr=lr, betas=(0.5, 0.999))   # model.py:286
@@ -110,7 +114,16 @@ class SemiSupOracle:
         return nets.resnet_generator(self.sd[name], x, 9, tanh, self.norm, self.use_dropout, q=self.q)
 
     def _dis(self, name, x):
+        if self.dis_net == "n_layers" and name != "old_Di":                 # old_Di stays netD='pixel' (model.py:229-230)
+            return nets.nlayer_discriminator(self.sd[name], x, 3, self.norm, q=self.q)
         return nets.pixel_discriminator(self.sd[name], x, self.norm, q=self.q)
+
+    def _gen(self, name, x):
+        """Gis / Gsi as the step calls them (model.py:385-387,408-410)."""
+        if self.gen_net == "deeplab":
+            return nets.deeplab(self.sd[name], x, True, q=self.q)
+        n_blocks = 9 if "9blocks" in self.gen_net else 6
+        return nets.resnet_generator(self.sd[name], x, n_blocks, not self.gen_net.endswith("_softmax"), self.norm, self.use_dropout, q=self.q)
 
     def step(self, l_img, l_gt, unl_img, collect=None):
         C, sd, w, q = self.C, self.sd, self.w, self.q
@@ -120,16 +133,16 @@ class SemiSupOracle:
         for p in self.d_params:
             p.requires_grad_(False)                                        # set_grad(..., False) :379
         lab = l_gt.squeeze(1)
-        fake_img = self.interp(nets.deeplab(sd["Gis"], one_hot(l_gt, C, l_img.dtype), True, q=q))   # :385,390
-        fake_gt = self.interp(nets.deeplab(sd["Gsi"], unl_img, True, q=q))                            # :386,391
-        lab_gt = self.interp(nets.deeplab(sd["Gsi"], l_img, True, q=q))                               # :387,392
+        fake_img = self.interp(self._gen("Gis", one_hot(l_gt, C, l_img.dtype)))   # :385,390
+        fake_gt = self.interp(self._gen("Gsi", unl_img))                            # :386,391
+        lab_gt = self.interp(self._gen("Gsi", l_img))                               # :387,392
         lab_loss_CE = TF.cross_entropy(lab_gt, lab)                                              # :398
         lab_gt = torch.softmax(lab_gt, 1)                                                        # :401
         fake_gt = torch.softmax(fake_gt, 1)                                                      # :402
-        recon_img = self.interp(nets.deeplab(sd["Gis"], fake_gt, True, q=q))                          # :408,413
+        recon_img = self.interp(self._gen("Gis", fake_gt))                          # :408,413
         with torch.no_grad():
-            nets.deeplab(sd["Gis"], lab_gt.detach(), True, q=q)        # :409 result unused, but advances Gis' BN running stats
-        recon_gt = self.interp(nets.deeplab(sd["Gsi"], fake_img, True, q=q))                          # :410,415
+            self._gen("Gis", lab_gt.detach())        # :409 result unused, but advances Gis' BN running stats
+        recon_gt = self.interp(self._gen("Gsi", fake_img))                          # :410,415
         with torch.no_grad():
             resnet_fake_gt = torch.softmax(self._old_g("old_Gsi", unl_img, False), 1)            # :418,421
             resnet_recon_img = self._old_g("old_Gis", resnet_fake_gt, True)                      # :422
@@ -193,9 +206,9 @@ class SemiSupOracle:
         fake_img = interp(Gis(onehot(l_gt))), fake_gt = softmax(interp(Gsi(unl_img))), lab_gt = softmax(interp(Gsi(l_img)))."""
         C, sd, q = self.C, self.sd, self.q
         with torch.no_grad():
-            fake_img = self.interp(nets.deeplab(sd["Gis"], one_hot(l_gt, C, l_img.dtype), True, q=q))     # :385,390
-            fake_gt = torch.softmax(self.interp(nets.deeplab(sd["Gsi"], unl_img, True, q=q)), 1)           # :386,391,402
-            lab_gt = torch.softmax(self.interp(nets.deeplab(sd["Gsi"], l_img, True, q=q)), 1) if want_lab else None   # :387,392,401
+            fake_img = self.interp(self._gen("Gis", one_hot(l_gt, C, l_img.dtype)))     # :385,390
+            fake_gt = torch.softmax(self.interp(self._gen("Gsi", unl_img)), 1)           # :386,391,402
+            lab_gt = torch.softmax(self.interp(self._gen("Gsi", l_img)), 1) if want_lab else None   # :387,392,401
         return fake_img, fake_gt, lab_gt
 
     def second_pass(self, fake_img, fake_gt, l_gt, unl_img):
@@ -211,8 +224,8 @@ class SemiSupOracle:
         mse = lambda x, t: ((x - t) ** 2).mean()
         fake_gt = fake_gt.detach().clone().requires_grad_(True)
         fake_img = fake_img.detach().clone().requires_grad_(True)
-        recon_img = self.interp(nets.deeplab(sd["Gis"], fake_gt, True, q=q))                               # :408,413
-        recon_gt = self.interp(nets.deeplab(sd["Gsi"], fake_img, True, q=q))                               # :410,415
+        recon_img = self.interp(self._gen("Gis", fake_gt))                               # :408,413
+        recon_gt = self.interp(self._gen("Gsi", fake_img))                               # :410,415
         img_cycle_loss = mse(self._dis("old_Di", recon_img), 1.0)                                          # :432,452
         gt_cycle_loss = TF.cross_entropy(recon_gt, l_gt.squeeze(1))                                        # :455
         d_fake_gt, = torch.autograd.grad(img_cycle_loss, fake_gt)

@@ -2401,5 +2401,5 @@ def weighted_sum(terms, weights):
 
 if os.environ.get("SSCG_RACECHECK"):     # debug: model the autograd engine's stream hand-over for the ordering checker
     import sys as _sys
-    from . import racecheck as _racecheck
-    _racecheck.wrap_functions(_sys.modules[__name__])
+    from ._lib import dev_tool as _dev_tool
+    _dev_tool("racecheck").wrap_functions(_sys.modules[__name__])

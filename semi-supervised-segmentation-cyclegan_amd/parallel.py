@@ -30,7 +30,16 @@ class DataParallel:
                 torch.cuda.set_device(self.local_rank)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+            try:
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+            except Exception as e:          # a port somebody else holds, a launcher that died: say where the rendezvous was, not only torch's trace
+                raise RuntimeError("rank %d/%d: no %s process group at %s:%s (%s: %s) - a MASTER_PORT clash shows up here; pick a free "
+                                   "port (bench.py --gpus N without a launcher finds one itself)" % (
+                                       self.rank, self.world_size, backend, os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"],
+                                       type(e).__name__, e)) from e
+        # the rank's host thread issues ~5 000 launches per step: keep it (and everything it spawns) on the cores of the GPU's own
+        # NUMA node - eight ranks on two sockets otherwise share one scheduler domain and cross the socket link for every doorbell
+        self.affinity = pin_to_device_node(self.local_rank) if torch.cuda.is_available() else None
         if torch.cuda.is_available():
             # side lanes made before the group existed are low-priority streams: beside RCCL's stream those cost +30 % (functional.side_priority)
             from . import functional as F
@@ -64,7 +73,7 @@ class DataParallel:
         """SSCG_DP_BUCKETS=n (n > 1): exchange `opt`'s gradient arena in n buckets, each as soon as the backward pass has queued the
         last gradient kernel of its parameters (reverse-order overlap with the backward).  Call before the step's
         forwards; `sync_grads_async` then returns the handles of the buckets already in flight plus the rest."""
-        n = int(os.environ.get("SSCG_DP_BUCKETS", "0"))
+        n = dp_buckets(self.world_size)
         if n < 2:
             return
         b = getattr(opt, "_sscg_buckets", None)
@@ -167,6 +176,96 @@ class GradBuckets:
         return self.works
 
 
+DEFAULT_BUCKETS = 4
+
+
+def dp_buckets(world_size):
+    """Number of reverse-order gradient buckets: SSCG_DP_BUCKETS when set (0 / 1 = the one-piece exchange after the backward), else
+    DEFAULT_BUCKETS whenever a process group exists (round 6: at world size 8 the ring moves 2 * 7/8 * 343 MB per rank over xGMI;
+    in four pieces three of them are on the wire while the backward still computes)."""
+    v = os.environ.get("SSCG_DP_BUCKETS")
+    if v is not None and v != "":
+        return int(v)
+    return DEFAULT_BUCKETS if dist.is_initialized() else 0
+
+
+def device_pci_address(index):
+    """dddd:bb:dd.f of a visible device (torch's device properties carry domain / bus / device; GPUs are function 0)."""
+    p = torch.cuda.get_device_properties(index)
+    return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+
+
+def parse_cpulist(text):
+    """'0-31,64-95' -> sorted list of CPU numbers (the sysfs cpulist format)."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus)
+
+
+def device_node_cpus(index, sysfs="/sys"):
+    """(numa_node, cpus) of the GPU's PCI function as the kernel reports them (`numa_node`, `local_cpulist`); (None, []) when sysfs
+    has no answer (containers without the PCI tree, numa_node == -1 with an empty list)."""
+    try:
+        base = os.path.join(sysfs, "bus/pci/devices", device_pci_address(index))
+        node = int(open(os.path.join(base, "numa_node")).read())
+        cpus = parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
+        if node < 0:
+            node = None
+        return node, cpus
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None, []
+
+
+def pin_to_device_node(index, sysfs="/sys"):
+    """Restrict this process (the issue thread and whatever it spawns later) to the CPUs local to GPU `index`, intersected with
+    the affinity it already has (a launcher's or a container's cpuset wins).  SSCG_DP_PIN=0 leaves the affinity alone.
+    Returns what was done: {"numa_node", "cpus": count, "pinned": bool}."""
+    node, cpus = device_node_cpus(index, sysfs)
+    info = {"numa_node": node, "cpus": len(os.sched_getaffinity(0)), "pinned": False}
+    if os.environ.get("SSCG_DP_PIN", "1") == "0" or not cpus:
+        return info
+    want = set(cpus) & os.sched_getaffinity(0)
+    if not want or want == os.sched_getaffinity(0):
+        return info
+    try:
+        os.sched_setaffinity(0, want)
+    except OSError:
+        return info
+    info.update(cpus=len(want), pinned=True)
+    return info
+
+
+def preflight(dp, batch_per_rank, shared_gpu_ok=False):
+    """Fail before any step runs, with one clear message, on what would make an N-GPU figure meaningless or crash it late:
+    per-rank batch below 2 (model.py:435's squeeze_(0) drops the batch dimension at B = 1), ranks that do not sit
+    on N distinct devices, a rank whose device is not the one its LOCAL_RANK names.  Collective: every rank calls it."""
+    if batch_per_rank < 2:
+        raise SystemExit("preflight: per-rank batch %d < 2 - the step needs B >= 2 on every rank (reference model.py:435 squeezes the "
+                         "batch dimension away at B = 1; BASELINE's DDP configurations are 64 / 8 = 8 and 32 / 8 = 4)" % batch_per_rank)
+    if dp is None:
+        return None
+    me = {"rank": dp.rank, "device": device_identity(), "local_rank": dp.local_rank,
+          "current": torch.cuda.current_device() if torch.cuda.is_available() else -1, "affinity": getattr(dp, "affinity", None)}
+    rows = [None] * dist.get_world_size()
+    if dist.get_world_size() > 1:
+        dist.all_gather_object(rows, me)
+    else:
+        rows = [me]
+    rows.sort(key=lambda r: r["rank"])
+    distinct = len(set(r["device"] for r in rows))
+    if distinct != len(rows) and not shared_gpu_ok:
+        raise SystemExit("preflight: %d ranks on %d distinct devices %s - not a %d-GPU job (SSCG_DP_SHARED_GPU=1 marks the one-GPU test "
+                         "rig)" % (len(rows), distinct, [r["device"] for r in rows], len(rows)))
+    for r in rows:
+        if r["current"] >= 0 and r["current"] != r["local_rank"]:
+            raise SystemExit("preflight: rank %d computes on device %d but LOCAL_RANK says %d" % (r["rank"], r["current"], r["local_rank"]))
+    return rows
+
+
 def _refresh_operand_copies(opt):
     """The optimiser's operand copies of its parameters (bf16 shadow / split planes) follow a broadcast of the arena."""
     if opt.arena16 is not None:
@@ -227,11 +326,12 @@ def collective_version():
     return backend, torch.__version__
 
 
-def rank_census(ms_per_step):
+def rank_census(ms_per_step, host_issue_ms=None, affinity=None):
     """What the job actually ran on, gathered from every rank (bench.py's `rccl` object): world size as the process group sees it,
     the physical device of each rank, how many DISTINCT devices that is, the collective library's version and every rank's own
     ms per step.  The bench line's `n_gpus` is WORLD_SIZE from the environment; this is the evidence beside it."""
-    me = {"rank": int(os.environ.get("RANK", "0")), "device": device_identity(), "ms_per_step": round(float(ms_per_step), 3)}
+    me = {"rank": int(os.environ.get("RANK", "0")), "device": device_identity(), "ms_per_step": round(float(ms_per_step), 3),
+          "host_issue_ms": None if host_issue_ms is None else round(float(host_issue_ms), 2), "affinity": affinity}
     if dist.is_initialized() and dist.get_world_size() > 1:
         rows = [None] * dist.get_world_size()
         dist.all_gather_object(rows, me)
@@ -241,7 +341,9 @@ def rank_census(ms_per_step):
     lib, ver = collective_version()
     return {"backend": lib, "version": ver, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
             "distinct_devices": len(set(r["device"] for r in rows)), "devices": [r["device"] for r in rows],
-            "per_rank_ms": [r["ms_per_step"] for r in rows]}
+            "per_rank_ms": [r["ms_per_step"] for r in rows],
+            "per_rank_host_issue_ms": [r.get("host_issue_ms") for r in rows],
+            "per_rank_affinity": [r.get("affinity") for r in rows]}
 
 
 def max_over_ranks(value):

@@ -99,15 +99,16 @@ class _Deferred:
 
 
 def test_dp_step_world_size_2_shared_gpu(dev, tmp_path):
-    """Two exchanges of the generator arena, each by its own pair of ranks (the four processes run side by side): in one piece after
-    the backward (the default), and with SSCG_DP_BUCKETS=4 - four all-reduces, each as soon as the backward has queued the last
+    """Two exchanges of the generator arena, each by its own pair of ranks (the four processes run side by side): with
+    SSCG_DP_BUCKETS=4 (the default under a process group since round 6) - four all-reduces, each as soon as the backward has queued the last
     gradient kernel of its parameters (parallel.GradBuckets); gloo reads a bucket on the host, so an all-reduce issued before a
-    gradient kernel it depends on would change the bits below.  Both must reproduce ONE lockstep simulation bit for bit."""
+    gradient kernel it depends on would change the bits below - and, on request, in one piece after the backward
+    (SSCG_DP_BUCKETS=0).  Both must reproduce ONE lockstep simulation bit for bit."""
     ctx = mp.get_context("spawn")
     runs = {}
-    # (the bucketed pair doubles the processes on the box - 100 s of the suite on a slow host: by default only where asked for;
-    # the bucketed exchange keeps its CPU world-2 test, tests/test_parallel_gloo.py, and its RCCL bitwise test, tests/test_schedule_gpu.py)
-    variants = (0, 4) if os.environ.get("SSCG_TEST_DP_BUCKETS_GLOO") == "1" else (0,)
+    # (a second pair doubles the processes on the box - 100 s of the suite on a slow host: the one-piece exchange only where asked
+    # for; it keeps its RCCL bitwise test, tests/test_schedule_gpu.py::test_sixty_steps...)
+    variants = (4, 0) if os.environ.get("SSCG_TEST_DP_ONE_PIECE_GLOO") == "1" else (4,)
     for buckets in variants:
         out = tmp_path / ("b%d" % buckets)
         out.mkdir()

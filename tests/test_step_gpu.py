@@ -202,6 +202,42 @@ def test_opt_in_nets_and_loss_variants(dev):
         assert not torch.equal(next(getattr(m, k).parameters()).detach(), w0), k
 
 
+def test_honoured_nets_step_vs_oracle_golden(dev):
+    """--honour_nets 1 --gen_net resnet_9blocks --dis_net n_layers (the reference parses both flags, main.py:43-44, and model.py:215-222
+    never reads them): ResNet-9 generators (arch/generators.py:404-418) and PatchGAN discriminators (arch/discriminators.py:42-63) as the
+    TRAINED nets, no dropout, against the oracle's step with the nets swapped (oracle/step.py gen_net= / dis_net=; golden "hn" of
+    g7_first_steps.json).  InstanceNorm nets carry no chaos (oracle fp32 vs fp64 <= 3.3e-7 on every loss): all nine first-step losses
+    are held to 1e-3 - the chained ones included - and the L2 norms of the generators' and discriminators' gradients to 1e-3."""
+    import json
+    md = load_sub("model")
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_first_steps.json")))["hn"]
+    C, H, Wd = G["C"], G["H"], G["W"]
+    args = FX.make_args(dataset="voc2012", crop_height=H, crop_width=Wd, batch_size=2, gpu_ids=[dev.index or 0],
+                        checkpoint_dir="/tmp/sscg_test_ckpt_hn", as_written=True)
+    args.honour_nets, args.gen_net, args.dis_net, args.no_dropout = 1, G["gen_net"], G["dis_net"], True
+    m = quiet(md.semisuper_cycleGAN, args)
+    for k, sd in FX.semisup_state_dicts(C, torch.float32, "hn", G["gen_net"], G["dis_net"]).items():
+        getattr(m, k).load_state_dict(sd, strict=True)
+    l_img, l_gt, unl_img = FX.step_batch("hn", 0, C, H, Wd, 2)
+    np.random.seed(0)
+    out = m.step(l_img.to(dev), l_gt.to(dev), unl_img.to(dev))
+    m.sync_losses()
+    torch.cuda.synchronize()
+    got = {k: float(v) for k, v in out.items()}
+    r64 = G["oracle_f64"]
+    assert set(got) == set(r64)
+    print()
+    for k in r64:
+        e = abs(got[k] - r64[k]) / abs(r64[k])
+        print("%-20s hip %.6f oracle64 %.6f  e64 %.1e" % (k, got[k], r64[k], e))
+        assert e < 1e-3, (k, e)
+    for name, opt in (("g", m.g_optimizer), ("d", m.d_optimizer)):
+        n = float(opt.grad.double().norm())
+        n64 = G["%s_grad_norm_f64" % name]
+        print("%s gradient norm: hip %.6e oracle64 %.6e rel %.1e" % (name, n, n64, abs(n - n64) / n64))
+        assert abs(n - n64) / n64 < 1e-3, name
+
+
 def test_variant_step_vs_oracle_golden(dev):
     """--variants l1_cycle,lab_gt_dis with the reference's default networks: the two loss terms the reference has commented out
     (model.py:453; :439,:447) against the oracle's restatement of those lines (oracle/step.py `variants=`, golden "var" of
