@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSCG_ABI_VERSION 16
+#define SSCG_ABI_VERSION 17
 
 /* element types of activation / weight tensors */
 #define SSCG_F32 0
@@ -101,6 +101,18 @@ int sscg_conv2d_fwd_stats(const sscg_conv_desc* d, const void* x, const void* w,
                           void* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream);
 int sscg_norm_stats_from_conv(const sscg_conv_desc* d, const void* stats, int G, int64_t L, float eps, float* mean, float* rstd,
                               float* running_mean, float* running_var, float momentum, void* stream);
+
+/* PixelDiscriminator's front half as ONE launch (arch/discriminators.py:70-73: nn.Conv2d(input_nc, ndf, 1) -> nn.LeakyReLU(0.2) ->
+ * nn.Conv2d(ndf, 2 ndf, 1) [-> the statistics of the InstanceNorm / BatchNorm layer at :73]).  `d` describes the SECOND conv (C = 64
+ * source channels, 1x1, stride 1, no padding, fp32 tensors, w = its SSCG_BF16X3 split planes); `xf` [N*H*W][cin] fp32 is the FIRST
+ * conv's input, (w1 [64][cin], b1 [64] or NULL, slope1) its parameters and LeakyReLU slope.  The 64-channel map between the two convs
+ * is formed per workgroup in LDS (exact fp32 FMAs) and is written to `h1` ([N*H*W][64] fp32) only when the caller passes it (a
+ * backward pass that wants it stored) - the launch itself never reads it back.  G > 0: `stats` receives the records of
+ * sscg_conv2d_fwd_stats for `d` (same size, finalised by sscg_norm_stats_from_conv).  sscg_conv2d_front_applies: cin in {3, 4, 20, 21}
+ * and a geometry whose tile class carries the fused prologue (else run the two convs separately). */
+int sscg_conv2d_front_applies(const sscg_conv_desc* d, int cin);
+int sscg_conv2d_front_fwd(const sscg_conv_desc* d, const void* xf, int cin, const float* w1, const float* b1, float slope1, void* h1,
+                          const void* w, const float* bias, void* y, int G, int64_t L, void* stats, size_t stats_bytes, void* stream);
 
 /* Data gradient of the same conv (autograd of model.py:472,539), and nn.ConvTranspose2d forward
  * (arch/ops.py:55-56): dx = act(dgrad(dy, wt) + bias).  `wt` = weight re-laid as [C][R][S][K]

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSCG_LIB") or os.path.join(_HERE, "libsscg.so")   # SSCG_LIB: kernel-ablation builds (tools/)
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 F32, BF16, BF16X3 = 0, 1, 2     # SSCG_F32 / SSCG_BF16 / SSCG_BF16X3 (split weight operand)
 
@@ -49,6 +49,8 @@ SIGNATURES = {
     "sscg_conv2d_fwd_stats_workspace": (_sz, [_dp]),
     "sscg_conv2d_fwd_stats": (_i, [_dp, _p, _p, _p, _p, _i, _i64, _p, _sz, _p, _sz, _p]),
     "sscg_norm_stats_from_conv": (_i, [_dp, _p, _i, _i64, _f, _p, _p, _p, _p, _f, _p]),
+    "sscg_conv2d_front_applies": (_i, [_dp, _i]),
+    "sscg_conv2d_front_fwd": (_i, [_dp, _p, _i, _p, _p, _f, _p, _p, _p, _p, _i, _i64, _p, _sz, _p]),
     "sscg_conv2d_dgrad_workspace": (_sz, [_dp]),
     "sscg_conv2d_dgrad": (_i, [_dp, _p, _p, _p, _p, _i, _f, _p, _sz, _p]),
     "sscg_conv2d_dgrad_bsums_bytes": (_sz, [_dp, _i, _i64]),

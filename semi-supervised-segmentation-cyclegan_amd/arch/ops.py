@@ -288,6 +288,26 @@ def conv_norm_act_head(conv, norm, act, head, x, reflect=0):
                                 rmean, rvar, per_sample, eps, momentum, act.code, act.slope)
 
 
+def _is_pixel_front(conv1, act1, conv2, x):
+    """Conv2d(cin, 64, 1x1) -> LeakyReLU in front of a PixelDiscriminator tail (arch/discriminators.py:70-71): one launch with the
+    tail's conv where the library serves it (fp32 tensors, split mode, cin in {3, 4, 20, 21})."""
+    return (isinstance(conv1, Conv2d) and isinstance(act1, _Act) and act1.code == ACT_LRELU and conv1.kernel_size == 1
+            and conv1.stride == 1 and conv1.padding == 0 and conv1.dilation == 1 and conv2.kernel_size == 1 and conv2.stride == 1
+            and conv2.padding == 0 and conv2.dilation == 1
+            and F.conv2d_front_applies(x, conv1.weight, conv2.weight, 1, 0, 1, PAD_ZEROS))
+
+
+def pixel_disc(conv1, act1, conv, norm, act, head, x):
+    per_sample, eps, rmean, rvar, momentum = norm.stat_spec()
+    if isinstance(norm, BatchNorm2d):
+        norm._pending += _BATCH_GROUPS[0]          # num_batches_tracked, as BatchNorm2d.forward counts it
+        gamma, beta = norm.weight, norm.bias
+    else:
+        gamma = beta = None
+    return F.pixel_disc(x, conv1.weight, conv1.bias, act1.slope, conv.weight, conv.bias, gamma, beta, head.weight, head.bias,
+                        rmean, rvar, per_sample, eps, momentum, act.code, act.slope)
+
+
 ONE_NODE = [os.environ.get("SSCG_ONE_NODE", "1") != "0"]       # A/B aid: conv and norm as two autograd nodes
 
 
@@ -311,6 +331,11 @@ class FusedSequential(nn.Sequential):
             if isinstance(m, (Conv2d, ConvTranspose2d)):
                 nxt = mods[i + 1] if i + 1 < n else None
                 nx2 = mods[i + 2] if i + 2 < n else None
+                if (not reflect and i + 5 < n and isinstance(nx2, Conv2d) and _is_norm(mods[i + 3]) and isinstance(mods[i + 4], _Act)
+                        and _is_pixel_head(nx2, mods[i + 3], mods[i + 4], mods[i + 5]) and _is_pixel_front(m, nxt, nx2, x)):
+                    x = pixel_disc(m, nxt, nx2, mods[i + 3], mods[i + 4], mods[i + 5], x)      # the whole PixelDiscriminator: one node
+                    i += 6
+                    continue
                 if _is_norm(nxt):
                     nx3 = mods[i + 3] if i + 3 < n else None
                     if isinstance(nx2, _Act) and _is_pixel_head(m, nxt, nx2, nx3):
@@ -444,5 +469,5 @@ def set_grad(nets, requires_grad=False):
 import os as _os
 if _os.environ.get("SSCG_RACECHECK"):     # debug: see functional.py (stream-ordering checker)
     import sys as _sys
-    from .. import racecheck as _racecheck
-    _racecheck.wrap_functions(_sys.modules[__name__])
+    from .._lib import dev_tool as _dev_tool
+    _dev_tool("racecheck").wrap_functions(_sys.modules[__name__])

@@ -886,6 +886,31 @@ extern "C" int sscg_conv2d_fwd_stats(const sscg_conv_desc* d, const void* x, con
     return conv_fwd_impl(d, x, w, bias, y, reinterpret_cast<double*>(stats), (long)L, xr, ws, ws_bytes, stream);
 }
 
+// PixelDiscriminator's front half in one launch (arch/discriminators.py:70-73): y = conv2(lrelu(conv1(xf))) [+ conv2's bias] and - with
+// G > 0 - the statistics of the normalisation layer behind it, records as sscg_conv2d_fwd_stats leaves them for `d` (the descriptor
+// of conv2: sscg_norm_stats_from_conv(d, ...) finalises them).  The 64-channel map between the two convs is written only when the caller
+// passes `h1` ([N*H*W][64] fp32: a backward pass that wants it stored), and never read back by this launch.
+extern "C" int sscg_conv2d_front_applies(const sscg_conv_desc* d, int cin) {
+    return d && check_desc(d) == SSCG_OK && sscg_convs_front_applies(d, cin) ? 1 : 0;
+}
+
+extern "C" int sscg_conv2d_front_fwd(const sscg_conv_desc* d, const void* xf, int cin, const float* w1, const float* b1, float slope1,
+                                     void* h1, const void* w, const float* bias, void* y, int G, int64_t L, void* stats,
+                                     size_t stats_bytes, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!xf || !w1 || !w || !y) return SSCG_ERR_BAD_ARG;
+    if (!sscg_convs_front_applies(d, cin)) return SSCG_ERR_UNSUPPORTED;
+    double* st = nullptr;
+    if (G > 0) {
+        StatPlan sp;
+        if (!fwd_stats_plan(d, G, (long)L, &sp) || sp.xrec > 0) return SSCG_ERR_UNSUPPORTED;
+        if (!stats || stats_bytes < sp.bytes) return SSCG_ERR_WORKSPACE;
+        st = reinterpret_cast<double*>(stats);
+    }
+    return sscg_convs_fwd_front(d, xf, cin, w1, b1, slope1, h1, w, bias, y, st, (long)L, (hipStream_t)stream);
+}
+
 extern "C" int sscg_norm_stats_from_conv(const sscg_conv_desc* d, const void* stats, int G, int64_t L, float eps, float* mean,
                                          float* rstd, float* running_mean, float* running_var, float momentum, void* stream) {
     int rc = check_desc(d);

@@ -96,6 +96,13 @@ struct KsParams {
     double* __restrict__ bn_sums;        // [G][bn_chunks][Ng][2]
     int bn_L, bn_G, bn_chunks, bn_act;
     float bn_slope;
+    // fused front conv (CIN > 0; PixelDiscriminator, arch/discriminators.py:70-71): the A operand is not read from memory - row m of it is
+    // lrelu(fr_b1 + fr_w1 . fr_x[m]), the 1x1 conv (CIN -> Cs = 64 channels) + LeakyReLU in front of this one, formed in the prologue
+    const float* __restrict__ fr_x;      // [M][CIN] fp32
+    const float* __restrict__ fr_w1;     // [Cs][CIN]
+    const float* __restrict__ fr_b1;     // [Cs] or null
+    float fr_slope;
+    float* __restrict__ fr_h1;           // [M][Cs] or null: the front conv's output is ALSO written (a backward pass that wants it stored)
     FastDiv div_tn, div_gl;              // by tiles_n; by stat_L / bn_L (whichever the launch uses)
     FastDiv div_hw, div_w;               // by OH * OW and by OW (launch_ks): a row's (image, y, x) without integer divisions (~30 VALU operations each)
 };
@@ -112,7 +119,7 @@ __device__ __forceinline__ float ks_act(float v, int act, float slope) {
     return v > 0.f ? v : neg;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, int CIN = 0>
 __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) void convs_kernel(KsParams p) {      // (HIP: the second figure is WAVES PER SIMD)
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
@@ -128,7 +135,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
     constexpr int A_STAGE = BM * 128;         // bytes
     constexpr int B_PLANE = BN * 64;
     constexpr int B_STAGE = 3 * B_PLANE;
-    constexpr int NPIECE = PA + PB;
+    constexpr bool FRONT = CIN > 0;           // the A tiles (both k-tiles of a 64-channel reduction) are computed, not copied
+    constexpr int NPIECE = (FRONT ? 0 : PA) + PB;
+    static_assert(!FRONT || (MODE == MODE_FWD && (BM == 128 || BM == 64) && NT == 256), "fused front conv: forward, 64- or 128-row tiles, four waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2] A images, then [2][3] B plane images
 
@@ -282,11 +291,13 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
         }
         if ((KS_ABLATE & 1) && f_k > 2 * BKS) { dma_stage ^= 1; ++f_chunk; f_k += BKS; return; }
 #if KS_BUFLD
-        const int so_a = __builtin_amdgcn_readfirstlane(f_chunk * (BKS * 4));
+        if constexpr (!FRONT) {
+            const int so_a = __builtin_amdgcn_readfirstlane(f_chunk * (BKS * 4));
 #pragma unroll
-        for (int q = 0; q < PA; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds0 + dma_stage * A_STAGE + lds_wave + q * (RPA * 128)),
-                                                     16, (int)aptr[q], so_a, 0, 0);
+            for (int q = 0; q < PA; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds0 + dma_stage * A_STAGE + lds_wave + q * (RPA * 128)),
+                                                         16, (int)aptr[q], so_a, 0, 0);
+        }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             const int so_b = __builtin_amdgcn_readfirstlane((int)((pl * p.wplane + f_k) * 2));
@@ -323,6 +334,42 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
     const int nk = kt1 - kt0;
     if (nk > 0) request_tile();               // tile 0 -> stage 0
     if (nk > 1) request_tile();               // tile 1 -> stage 1
+    if constexpr (FRONT) {
+        // (host: Ktot == 64, never split - nk == 2, both A stages are filled here, under the latency of the weight copies.)
+        // Waves 2 s and 2 s + 1 form k-tile s: 128-row tiles - a thread takes all 32 channels of one of the 128 rows; 64-row tiles - 16
+        // channels of one of the 64 rows.  The channels are wave-uniform, so the front conv's weights and bias arrive through scalar
+        // loads; exact fp32 FMAs (CIN <= 21 terms).  The row lands in the image the copies would have left: 16-byte slot q of row r
+        // at slot q ^ ((r >> 1) & 7).
+        const int fwv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int fs = fwv >> 1;
+        constexpr int QN = BM == 128 ? 8 : 4;
+        const int fr = BM == 128 ? (fwv & 1) * 64 + (tid & 63) : (tid & 63);
+        const int q0 = BM == 128 ? 0 : (fwv & 1) * 4;
+        const int fm = m0 + fr;
+        float xr[CIN];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) xr[c] = fm < p.M ? p.fr_x[(size_t)fm * CIN + c] : 0.f;
+        float* const arow_l = reinterpret_cast<float*>(smem_raw + fs * A_STAGE + fr * 128);
+        const float* const w1 = p.fr_w1 + (size_t)fs * BKS * CIN;
+        const float* const b1 = p.fr_b1 ? p.fr_b1 + fs * BKS : nullptr;
+        const int sw = (fr >> 1) & 7;
+#pragma unroll
+        for (int qq = 0; qq < QN; ++qq) {
+            const int q = q0 + qq;
+            f32x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = q * 4 + e;
+                float a = b1 ? b1[k] : 0.f;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) a = fmaf(xr[c], w1[k * CIN + c], a);
+                h[e] = a > 0.f ? a : a * p.fr_slope;
+            }
+            *reinterpret_cast<f32x4*>(arow_l + ((q ^ sw) << 2)) = h;
+            if (p.fr_h1 && tile_n == 0 && fm < p.M) *reinterpret_cast<f32x4*>(p.fr_h1 + (size_t)fm * (2 * BKS) + fs * BKS + q * 4) = h;
+        }
+        __syncthreads();
+    }
 
     // ---- matrix-core side
     const int lane = tid & 63;
@@ -865,7 +912,7 @@ size_t ks_split_bytes(const KsSplit& sp, long M, int Ng) {
     return sp.splits > 1 ? (size_t)sp.splits * (M - sp.m_tail0) * Ng * sizeof(float) : 0;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, int CIN = 0>
 int launch_ks(const KsParams& p0, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -878,7 +925,7 @@ int launch_ks(const KsParams& p0, hipStream_t st) {
     p.div_gl = make_fastdiv((MODE == MODE_DGRAD && p.bn_sums != nullptr) ? p.bn_L : (p.stat_L > 0 ? p.stat_L : 1));
     p.tiles = cdiv(p.M, BM) * p.tiles_n;
     const size_t smem = (size_t)2 * (BM * 128 + 3 * BN * 64);
-    auto kern = convs_kernel<MODE, WM, WN, TM, TN>;
+    auto kern = convs_kernel<MODE, WM, WN, TM, TN, CIN>;
     SSCG_ENSURE_SMEM((kern), smem);
     if (p.splits <= 1) { p.full_tiles = p.tiles; p.m_tail0 = p.M; }
     const int grid = p.full_tiles + (p.tiles - p.full_tiles) * p.splits;
@@ -907,6 +954,16 @@ int dispatch_ks(const KsParams& p, int tuning, hipStream_t st) {
         case KS_128x64: return launch_ks<MODE, 4, 1, 1, 2>(p, st);         // 4 waves of 32x64: every A fragment split by one wave only
         case KS_128x32: return launch_ks<MODE, 4, 1, 1, 1>(p, st);        // 4 waves of 32x32: few-channel heads
         default: return SSCG_ERR_BAD_ARG;
+    }
+}
+
+// the forward with the front conv fused (CIN input channels -> the 64 channels this conv reduces over): 128x128 or 64x64 tiles
+template <int CIN>
+int dispatch_ks_front(const KsParams& p, int tuning, hipStream_t st) {
+    switch (ks_choose(p.M, p.Ng, p.Ktot, tuning)) {
+        case KS_128x128: return launch_ks<MODE_FWD, 2, 2, 2, 2, CIN>(p, st);
+        case KS_64x64: return launch_ks<MODE_FWD, 2, 2, 1, 1, CIN>(p, st);
+        default: return SSCG_ERR_UNSUPPORTED;
     }
 }
 
@@ -1023,6 +1080,46 @@ int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const 
     p.splits = sp.splits; p.ksplit = sp.ksplit; p.full_tiles = sp.full_tiles; p.m_tail0 = sp.m_tail0;
     p.part = reinterpret_cast<float*>(ws);
     return dispatch_ks<MODE_FWD>(p, d->tuning, st);
+}
+
+// PixelDiscriminator's front half as ONE launch (arch/discriminators.py:70-73: Conv2d(cin, 64, 1x1) -> LeakyReLU -> Conv2d(64, 2 ndf, 1x1)
+// [-> the norm layer's statistics]): `d` describes the SECOND conv (C = 64 source channels, 1x1, stride 1, no padding), `xf` is the
+// FIRST conv's input [N*H*W][cin] fp32, (w1 [64][cin], b1 [64] or null, slope1) its parameters.  The 64-channel map never exists in
+// memory: every workgroup forms its rows of it in LDS (exact fp32 FMAs) in front of the split contraction.
+bool sscg_convs_front_applies(const sscg_conv_desc* d, int cin) {
+    if (!(cin == 3 || cin == 4 || cin == 20 || cin == 21)) return false;
+    if (!sscg_convs_fwd_applies(d) || d->C != 2 * BKS || d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->pad_mode != 0 ||
+        d->K % 4 != 0 || d->act == SSCG_ACT_TANH)
+        return false;
+    const long M = (long)d->N * d->P * d->Q;
+    const int cfg = ks_choose(M, d->K, d->C, d->tuning);
+    return (cfg == KS_128x128 || cfg == KS_64x64) && ks_plan(M, d->K, d->C, d->tuning, 0).splits == 1;
+}
+
+int sscg_convs_fwd_front(const sscg_conv_desc* d, const void* xf, int cin, const float* w1, const float* b1, float slope1, void* h1,
+                         const void* w, const float* bias, void* y, double* stats, long stat_L, hipStream_t st) {
+    if (!sscg_convs_front_applies(d, cin)) return SSCG_ERR_UNSUPPORTED;
+    KsParams p = {};
+    p.fr_x = reinterpret_cast<const float*>(xf); p.fr_w1 = w1; p.fr_b1 = b1; p.fr_slope = slope1; p.fr_h1 = reinterpret_cast<float*>(h1);
+    p.src = nullptr; p.wgt = reinterpret_cast<const bf16*>(w); p.wplane = ks_plane(d);
+    p.bias = bias; p.dst = reinterpret_cast<float*>(y);
+    p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Cs = d->C; p.Ktot = d->C;
+    p.SH = d->H; p.SW = d->W; p.OH = d->P; p.OW = d->Q;
+    p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+    p.pad_mode = 0; p.act = d->act; p.slope = d->slope;
+    p.stats = stats; p.stat_L = (int)stat_L; p.xstats = nullptr;
+    p.src_bytes = 0;
+    p.wgt_bytes = (unsigned)(((size_t)2 * p.wplane + (size_t)d->K * d->C) * sizeof(bf16));
+    ks_dense_taps(p);
+    p.splits = 1; p.ksplit = p.Ktot / BKS; p.full_tiles = 0; p.m_tail0 = p.M;      // (launch_ks sets full_tiles / m_tail0 of an unsplit launch)
+    p.part = nullptr;
+    switch (cin) {
+        case 3: return dispatch_ks_front<3>(p, d->tuning, st);
+        case 4: return dispatch_ks_front<4>(p, d->tuning, st);
+        case 20: return dispatch_ks_front<20>(p, d->tuning, st);
+        case 21: return dispatch_ks_front<21>(p, d->tuning, st);
+        default: return SSCG_ERR_UNSUPPORTED;
+    }
 }
 
 // Backward sums of the normalisation layer in front, from this data gradient's epilogue: plain stride-1 / dilated data gradients of the

@@ -13,6 +13,7 @@
 // across workgroups; partial tiles go to a caller-provided workspace and a second kernel reduces them
 // in a fixed order (deterministic: no atomics).
 #include "common.h"
+#include <cstdlib>
 #include "sscg_internal.h"
 
 namespace {
@@ -350,6 +351,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     *d = (beta != 0.f) ? beta * *d + s : s;
 }
 
+// The same sum with the splits dealt out to the four waves of a block (round 6): wave w adds splits w, w + 4, ... of 64 consecutive
+// 16-byte output pieces - with 32 splits every thread has its 8 loads in flight at once and the launch is one memory round trip
+// instead of two, on 4x the workgroups (a 1x1 layer's 256 K outputs: 1024 blocks instead of 256) - the four partial sums meet in LDS
+// in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_w4_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n, int splits,
+                                                               float beta) {
+    __shared__ f32x4 sm[3][64];
+    const int v = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const size_t i = ((size_t)blockIdx.x * 64 + v) * 4;
+    f32x4 s = 0.f;
+    if (i < n) {
+#pragma unroll 8
+        for (int k = sl; k < splits; k += 4) s += *reinterpret_cast<const f32x4*>(ws + (size_t)k * n + i);
+    }
+    if (sl) sm[sl - 1][v] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        s = ((s + sm[0][v]) + sm[1][v]) + sm[2][v];
+        f32x4* d = reinterpret_cast<f32x4*>(dw + i);
+        *d = (beta != 0.f) ? beta * *d + s : s;
+    }
+}
+
 struct WgPlan {
     int cfg;
     int bm, bn;
@@ -636,7 +660,11 @@ bool thin_wgrad_supported_T(int T) { return T == 1 || T == 2 || T == 3 || T == 4
 }  // namespace
 
 int sscg_wgrad_reduce(const float* ws, float* dw, size_t n, int splits, float beta, hipStream_t st) {
-    if (n % 4 == 0 && ((size_t)dw & 15) == 0 && ((size_t)ws & 15) == 0)
+    static const bool w4 = !(getenv("SSCG_WGRAD_REDUCE_W4") && atoi(getenv("SSCG_WGRAD_REDUCE_W4")) == 0);       // A/B aid
+    const bool vec_ok = n % 4 == 0 && ((size_t)dw & 15) == 0 && ((size_t)ws & 15) == 0;
+    if (vec_ok && w4 && splits >= 8 && n / 4 <= 64 * 16384)
+        hipLaunchKernelGGL(wgrad_reduce_w4_kernel, dim3(cdiv((long)(n / 4), 64)), dim3(256), 0, st, ws, dw, n, splits, beta);
+    else if (vec_ok)
         hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(cdiv((long)(n / 4), 256)), dim3(256), 0, st, ws, dw, n, splits, beta);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(cdiv((long)n, 256)), dim3(256), 0, st, ws, dw, n, splits, beta);

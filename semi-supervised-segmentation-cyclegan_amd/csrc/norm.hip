@@ -10,6 +10,7 @@
 // The tensor is viewed as [G][L][C] (see sscg.h).
 #include "common.h"
 #include "sscg_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -394,6 +395,88 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(ApplyParams p) {
     }
 }
 
+// The same pass with a thread bound to ONE channel group (round 6).  The kernel above walks the tensor as a flat list of vectors: every
+// iteration divides its index twice, fetches four parameter vectors beside its one data vector and has that single 16-byte load in
+// flight - 32 KB per CU, 3.3-5.7 TB/s measured (profiles/r05_norm_bench.txt).  Here a block owns `cw` consecutive channel groups
+// (cw = C / VEC up to 256: a whole row or a 4 KB slab of it) x a chunk of one group's rows: the per-channel parameters are loaded
+// once per thread, a thread walks its column with U rows in flight (consecutive lanes still touch consecutive 16 bytes, consecutive
+// row lanes consecutive rows).  Same per-element expression, bit-identical results.  Grid (chunks, C / VEC / cw, G).
+template <typename T, int VEC, int U>
+__global__ __launch_bounds__(256) void norm_apply_slab_kernel(ApplyParams p, int cw_shift, int rows_per_chunk) {
+    const int tid = threadIdx.x;
+    const int col = tid & ((1 << cw_shift) - 1), rl = tid >> cw_shift, rw = 256 >> cw_shift;
+    const int c = (((int)blockIdx.y << cw_shift) + col) * VEC;
+    const int g = blockIdx.z;
+    float mu[VEC], rs[VEC], ga[VEC], be[VEC];
+    const size_t s = (size_t)g * p.C + c;
+    ldv<float, VEC>(p.mean + s, mu);
+    ldv<float, VEC>(p.rstd + s, rs);
+    if (p.gamma) {
+        ldv<float, VEC>(p.gamma + c, ga);
+        ldv<float, VEC>(p.beta + c, be);
+    }
+    const size_t base = (size_t)g * p.L * p.C + c;
+    const T* px = reinterpret_cast<const T*>(p.x) + base;
+    const T* pr = p.res ? reinterpret_cast<const T*>(p.res) + base : nullptr;
+    T* py = reinterpret_cast<T*>(p.y) + base;
+    const long r_begin = (long)blockIdx.x * rows_per_chunk;
+    const long r_end = r_begin + rows_per_chunk < p.L ? r_begin + rows_per_chunk : p.L;
+    for (long r = r_begin + rl; r < r_end; r += (long)rw * U) {
+        float xv[U][VEC], rv[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long rr = r + (long)u * rw;
+            if (rr < r_end) {
+                ldv<T, VEC>(px + (size_t)rr * p.C, xv[u]);
+                if (pr) ldv<T, VEC>(pr + (size_t)rr * p.C, rv[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long rr = r + (long)u * rw;
+            if (rr < r_end) {
+                float out[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float v = (xv[u][e] - mu[e]) * rs[e];
+                    if (p.gamma) v = v * ga[e] + be[e];
+                    if (pr) v += rv[u][e];
+                    out[e] = sscg_act(v, p.act, p.slope);
+                }
+                stv<T, VEC>(py + (size_t)rr * p.C, out);
+            }
+        }
+    }
+}
+
+// geometry of the slab kernels: cw = min(C / VEC, 256) channel groups per block (a power of two), rw = 256 / cw row lanes, chunks of
+// rows such that the launch has ~4096 blocks at most and a thread at least one full round of U rows
+struct SlabPlan { bool ok; int cw_shift, slabs, chunks, rows_per_chunk; };
+static SlabPlan plan_slab(int G, long L, int C, int vec, int U) {
+    SlabPlan pl = {false, 0, 1, 1, 0};
+    static const bool off = getenv("SSCG_NORM_SLAB") && atoi(getenv("SSCG_NORM_SLAB")) == 0;      // A/B aid: the flat kernels
+    if (off || vec < 4 || C % vec) return pl;
+    const int cg = C / vec;
+    if (cg & (cg - 1)) return pl;                   // channel groups per row: a power of two
+    int sh = 0;
+    while ((1 << sh) < cg && sh < 8) ++sh;
+    pl.cw_shift = sh;
+    pl.slabs = cg >> sh;
+    const int rw = 256 >> sh;
+    const long round = (long)rw * U;
+    long chunks = (L + round - 1) / round;
+    long budget = 4096 / ((long)G * pl.slabs);
+    if (budget < 1) budget = 1;
+    if (chunks > budget) chunks = budget;
+    long rpc = (L + chunks - 1) / chunks;
+    rpc = (rpc + round - 1) / round * round;
+    pl.chunks = (int)((L + rpc - 1) / rpc);
+    pl.rows_per_chunk = (int)rpc;
+    if (G > 65535 || pl.slabs > 65535 || rpc > 0x7fffffffL) return pl;
+    pl.ok = true;
+    return pl;
+}
+
 struct BwdApplyParams {
     const void* __restrict__ dy;
     const void* __restrict__ x;
@@ -475,6 +558,83 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdApplyParams p) {
         }
         stv<T, VEC>(pdx + o, gx);
         if (p.dres) stv<T, VEC>(pdres + o, gr);
+    }
+}
+
+// norm_bwd_apply_kernel with a thread bound to one channel group (see norm_apply_slab_kernel): the six per-channel parameter vectors
+// are loaded once per thread, U rows of (dy, x, y) in flight.  Same per-element expression.
+template <typename T, int VEC, int U>
+__global__ __launch_bounds__(256) void norm_bwd_apply_slab_kernel(BwdApplyParams p, int cw_shift, int rows_per_chunk) {
+    const int tid = threadIdx.x;
+    const int col = tid & ((1 << cw_shift) - 1), rl = tid >> cw_shift, rw = 256 >> cw_shift;
+    const int c = (((int)blockIdx.y << cw_shift) + col) * VEC;
+    const int g = blockIdx.z;
+    const bool remask = p.act != SSCG_ACT_NONE && p.y == nullptr;
+    const bool has_y = p.act != SSCG_ACT_NONE && !remask;
+    float mu[VEC], rsv[VEC], ga[VEC], be[VEC], c1[VEC], c2[VEC], hw[VEC];
+    const size_t s = (size_t)g * p.C + c;
+    ldv<float, VEC>(p.rstd + s, rsv);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { ga[e] = 1.f; be[e] = 0.f; mu[e] = 0.f; c1[e] = 0.f; c2[e] = 0.f; hw[e] = 0.f; }
+    if (p.gamma) ldv<float, VEC>(p.gamma + c, ga);
+    if (remask && p.beta) ldv<float, VEC>(p.beta + c, be);
+    if (p.coef || remask) ldv<float, VEC>(p.mean + s, mu);
+    if (p.coef) {
+        float kk[2 * VEC];          // (c1, c2) pairs of channels c .. c+VEC-1
+#pragma unroll
+        for (int q = 0; q < 2 * VEC; q += 4) ld4<float>(p.coef + s * 2 + q, kk + q);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { c1[e] = kk[2 * e]; c2[e] = kk[2 * e + 1]; }
+    }
+    if (p.head_w) ldv<float, VEC>(p.head_w + c, hw);
+    const size_t base = (size_t)g * p.L * p.C + c;
+    const T* pdy = p.head_w ? nullptr : reinterpret_cast<const T*>(p.dy) + base;
+    const T* px = reinterpret_cast<const T*>(p.x) + base;
+    const T* py = has_y ? reinterpret_cast<const T*>(p.y) + base : nullptr;
+    T* pdx = reinterpret_cast<T*>(p.dx) + base;
+    T* pdres = p.dres ? reinterpret_cast<T*>(p.dres) + base : nullptr;
+    const float* pdo = p.head_w ? p.head_dout + (size_t)g * p.L : nullptr;
+    const long r_begin = (long)blockIdx.x * rows_per_chunk;
+    const long r_end = r_begin + rows_per_chunk < p.L ? r_begin + rows_per_chunk : p.L;
+    for (long r = r_begin + rl; r < r_end; r += (long)rw * U) {
+        float dv[U][VEC], xv[U][VEC], yv[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long rr = r + (long)u * rw;
+            if (rr < r_end) {
+                const size_t o = (size_t)rr * p.C;
+                if (p.head_w) {
+                    const float d = pdo[rr];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) dv[u][e] = d * hw[e];
+                } else {
+                    ldv<T, VEC>(pdy + o, dv[u]);
+                }
+                ldv<T, VEC>(px + o, xv[u]);
+                if (has_y) ldv<T, VEC>(py + o, yv[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long rr = r + (long)u * rw;
+            if (rr < r_end) {
+                const size_t o = (size_t)rr * p.C;
+                float gx[VEC], gr[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float xh = (xv[u][e] - mu[e]) * rsv[e];
+                    float ym = yv[u][e];
+                    if (remask) ym = xh * ga[e] + be[e];
+                    float gg = p.act != SSCG_ACT_NONE ? act_grad(dv[u][e], ym, p.act, p.slope) : dv[u][e];
+                    gr[e] = gg;
+                    float v = gg;
+                    if (p.coef) v = gg - c1[e] - xh * c2[e];
+                    gx[e] = v * rsv[e] * ga[e];
+                }
+                stv<T, VEC>(pdx + o, gx);
+                if (pdres) stv<T, VEC>(pdres + o, gr);
+            }
+        }
     }
 }
 
@@ -709,7 +869,17 @@ int sscg_finalize_conv_stats(const double* stats, int valid_tiles, int rows_per_
 }
 
 template <typename T>
-static void launch_apply(const ApplyParams& p, int vec, hipStream_t st) {
+static void launch_apply(const ApplyParams& p, int vec, hipStream_t st, int G = 0) {
+    static const int u8 = getenv("SSCG_NORM_SLAB_U8A") ? atoi(getenv("SSCG_NORM_SLAB_U8A")) : 4;       // tuning aid: rows in flight, 8-channel groups (0 = flat kernel)
+    const int U = vec == 8 ? u8 : 4;
+    const SlabPlan sp = (G > 0 && U > 0) ? plan_slab(G, p.L, p.C, vec, U) : SlabPlan{false, 0, 1, 1, 0};
+    if (sp.ok) {
+        const dim3 grid(sp.chunks, sp.slabs, G);
+        if (vec == 8 && U == 2) hipLaunchKernelGGL((norm_apply_slab_kernel<T, 8, 2>), grid, dim3(256), 0, st, p, sp.cw_shift, sp.rows_per_chunk);
+        else if (vec == 8) hipLaunchKernelGGL((norm_apply_slab_kernel<T, 8, 4>), grid, dim3(256), 0, st, p, sp.cw_shift, sp.rows_per_chunk);
+        else hipLaunchKernelGGL((norm_apply_slab_kernel<T, 4, 4>), grid, dim3(256), 0, st, p, sp.cw_shift, sp.rows_per_chunk);
+        return;
+    }
     if (vec == 8) hipLaunchKernelGGL((norm_apply_kernel<T, 8>), dim3(ew_grid(p.total)), dim3(256), 0, st, p);
     else if (vec == 4) hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(ew_grid(p.total)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((norm_apply_kernel<T, 1>), dim3(ew_grid(p.total)), dim3(256), 0, st, p);
@@ -729,8 +899,8 @@ extern "C" int sscg_norm_apply(const void* x, const float* mean, const float* rs
     p.div_cg = make_fastdiv(C / vec);
     p.div_l = make_fastdiv((int)L);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SSCG_BF16) launch_apply<__bf16>(p, vec, st);
-    else launch_apply<float>(p, vec, st);
+    if (dtype == SSCG_BF16) launch_apply<__bf16>(p, vec, st, G);
+    else launch_apply<float>(p, vec, st, G);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -747,7 +917,18 @@ extern "C" size_t sscg_norm_bwd_workspace(int G, int64_t L, int C) {
 }
 
 template <typename T>
-static void launch_bwd_apply(const BwdApplyParams& q, int vec, hipStream_t st) {
+static void launch_bwd_apply(const BwdApplyParams& q, int vec, hipStream_t st, int G = 0) {
+    static const int u8 = getenv("SSCG_NORM_SLAB_U8B") ? atoi(getenv("SSCG_NORM_SLAB_U8B")) : 2;       // tuning aid: rows in flight, 8-channel groups (0 = flat kernel)
+    const int U = vec == 8 ? u8 : 4;
+    const SlabPlan sp = (G > 0 && U > 0) ? plan_slab(G, q.L, q.C, vec, U) : SlabPlan{false, 0, 1, 1, 0};
+    if (sp.ok) {
+        const dim3 grid(sp.chunks, sp.slabs, G);
+        if (vec == 8 && U == 1) hipLaunchKernelGGL((norm_bwd_apply_slab_kernel<T, 8, 1>), grid, dim3(256), 0, st, q, sp.cw_shift, sp.rows_per_chunk);
+        else if (vec == 8 && U == 2) hipLaunchKernelGGL((norm_bwd_apply_slab_kernel<T, 8, 2>), grid, dim3(256), 0, st, q, sp.cw_shift, sp.rows_per_chunk);
+        else if (vec == 8) hipLaunchKernelGGL((norm_bwd_apply_slab_kernel<T, 8, 4>), grid, dim3(256), 0, st, q, sp.cw_shift, sp.rows_per_chunk);
+        else hipLaunchKernelGGL((norm_bwd_apply_slab_kernel<T, 4, 4>), grid, dim3(256), 0, st, q, sp.cw_shift, sp.rows_per_chunk);
+        return;
+    }
     if (vec == 8) hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 8>), dim3(ew_grid(q.total)), dim3(256), 0, st, q);
     else if (vec == 4) hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), dim3(ew_grid(q.total)), dim3(256), 0, st, q);
     else hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(ew_grid(q.total)), dim3(256), 0, st, q);
@@ -788,8 +969,8 @@ extern "C" int sscg_norm_bwd(const void* dy, const void* x, const void* y, const
     q.total = (uint32_t)((size_t)G * L * C / vec);
     q.div_cg = make_fastdiv(C / vec);
     q.div_l = make_fastdiv((int)L);
-    if (dtype == SSCG_BF16) launch_bwd_apply<__bf16>(q, vec, st);
-    else launch_bwd_apply<float>(q, vec, st);
+    if (dtype == SSCG_BF16) launch_bwd_apply<__bf16>(q, vec, st, G);
+    else launch_bwd_apply<float>(q, vec, st, G);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -821,8 +1002,8 @@ extern "C" int sscg_norm_bwd_from_sums(const sscg_conv_desc* d, const void* sums
     q.total = (uint32_t)((size_t)G * L * C / vec);
     q.div_cg = make_fastdiv(C / vec);
     q.div_l = make_fastdiv((int)L);
-    if (dtype == SSCG_BF16) launch_bwd_apply<__bf16>(q, vec, st);
-    else launch_bwd_apply<float>(q, vec, st);
+    if (dtype == SSCG_BF16) launch_bwd_apply<__bf16>(q, vec, st, G);
+    else launch_bwd_apply<float>(q, vec, st, G);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }
@@ -902,8 +1083,8 @@ extern "C" int sscg_norm_head_bwd(const float* dout, const float* w, const void*
     q.total = (uint32_t)((size_t)G * L * C / vec);
     q.div_cg = make_fastdiv(C / vec);
     q.div_l = make_fastdiv((int)L);
-    if (dtype == SSCG_BF16) launch_bwd_apply<__bf16>(q, vec, st);
-    else launch_bwd_apply<float>(q, vec, st);
+    if (dtype == SSCG_BF16) launch_bwd_apply<__bf16>(q, vec, st, G);
+    else launch_bwd_apply<float>(q, vec, st, G);
     SSCG_LAUNCH_CHECK();
     return SSCG_OK;
 }

@@ -28,6 +28,10 @@ size_t sscg_convs_fwd_workspace(const sscg_conv_desc* d, long stat_L);
 size_t sscg_convs_dgrad_workspace(const sscg_conv_desc* d);
 int sscg_convs_fwd(const sscg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* stats, long stat_L,
                    double* xstats, void* ws, size_t ws_bytes, hipStream_t st);
+// the forward with the 1x1 conv + LeakyReLU in front of it (cin -> 64 channels) formed in the prologue (PixelDiscriminator's front half)
+bool sscg_convs_front_applies(const sscg_conv_desc* d, int cin);
+int sscg_convs_fwd_front(const sscg_conv_desc* d, const void* xf, int cin, const float* w1, const float* b1, float slope1, void* h1,
+                         const void* w, const float* bias, void* y, double* stats, long stat_L, hipStream_t st);
 // the backward sums of the normalisation layer whose output a data gradient differentiates, taken in that launch's epilogue
 struct sscg_bsums {
     const void* nx;          // the layer's input [G * L][C]

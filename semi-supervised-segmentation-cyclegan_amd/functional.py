@@ -752,6 +752,57 @@ def conv2d_fwd_norm(x, w, bias, stride, pad, dil, pad_mode, out_f32, glc, eps, r
     return y, mean, rstd
 
 
+FUSE_FRONT = [os.environ.get("SSCG_FUSE_FRONT", "1") != "0"]      # A/B aid: PixelDiscriminator's two leading convs as separate launches
+FRONT_CALLS = [0]                                                  # fused front launches issued (tests assert the path taken)
+
+
+def conv2d_front_applies(x, w1, w, stride, pad, dil, pad_mode):
+    """Does ONE launch serve Conv2d(cin, 64, 1x1) -> LeakyReLU -> Conv2d(64, K, 1x1) (PixelDiscriminator's front half,
+    arch/discriminators.py:70-73) on this input?  fp32 tensors in the split mode, cin in {3, 4, 20, 21}; the library decides the rest."""
+    if not (FUSE_FRONT[0] and _MODE[0] == "f32s" and "fwd" in SPLIT_KINDS and x.dtype == torch.float32 and x.is_cuda):
+        return False
+    if not (tuple(w1.shape[2:]) == (1, 1) and tuple(w.shape[2:]) == (1, 1) and w1.shape[0] == w.shape[1] == 64
+            and stride == 1 and pad == 0 and dil == 1 and pad_mode == PAD_ZEROS):
+        return False
+    n, cin, h, wd = x.shape
+    key = ("front", n, cin, h, wd, w.shape[0], TUNING[0])
+    v = _SPLIT_OK.get(key)
+    if v is None:
+        ws, plane = None, w.numel()
+        d = make_desc((n, 64, h, wd), w.shape, 1, 0, 1, PAD_ZEROS, ACT_NONE, 0.0, F32, BF16X3, F32, _prec(), plane)
+        v = _SPLIT_OK[key] = bool(lib.sscg_conv2d_front_applies(C.byref(d), cin))
+    return v
+
+
+def conv2d_front_fwd(x, w1, b1, slope1, w, bias, glc=None, want_h1=False):
+    """(y, h1 or None, cs or None): y = conv(lrelu(conv(x, w1) + b1), w) + bias in one launch; h1 (the 64-channel map between the two
+    convs) is written only when asked for; glc = (G, L, C): the launch also leaves the statistics records of the norm layer behind
+    it (`cs` for norm_stats_from_conv)."""
+    x = to_nhwc(x)
+    n, cin, h, wd = x.shape
+    wop, plane = weight_split(w)
+    d = make_desc((n, 64, h, wd), w.shape, 1, 0, 1, PAD_ZEROS, ACT_NONE, 0.0, F32, BF16X3, F32, _prec(), plane)
+    y = empty_nhwc(n, w.shape[0], h, wd, x.device, torch.float32)
+    h1 = empty_nhwc(n, 64, h, wd, x.device, torch.float32) if want_h1 else None
+    g = l = nb = 0
+    sbuf = None
+    if glc is not None:
+        g, l = int(glc[0]), int(glc[1])
+        nb = _stats_bytes(d, g, l)
+        if not nb:
+            raise _lib.SscgError("conv2d_front_fwd: no fused statistics for this geometry")
+        sbuf = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    FRONT_CALLS[0] += 1
+    w1f = w1.detach().reshape(64, cin)
+    if not w1f.is_contiguous():
+        w1f = w1f.contiguous()
+    # (booked under the second conv's geometry + the front conv's algorithmic FLOP; the bytes are the launch's own: x in, y [+ h1] out)
+    _timed("fwd", d, lambda: check(lib.sscg_conv2d_front_fwd(C.byref(d), x.data_ptr(), cin, w1f.data_ptr(), _ptr(b1), float(slope1), _ptr(h1),
+                                                             wop.data_ptr(), _ptr(bias), y.data_ptr(), g, l, _ptr(sbuf), nb, _stream()),
+                                   "sscg_conv2d_front_fwd"))
+    return y, h1, ((d, sbuf) if sbuf is not None else None)
+
+
 def weight_transposed(w, dtype=torch.float32):
     """[K][R][S][C] -> [C][R][S][K] (the operand layout of sscg_conv2d_dgrad), as fp32 or bf16; dtype "x3" = the three bf16
     planes of the split contraction (a flat bf16 tensor of 3 * numel elements)."""
@@ -1864,6 +1915,93 @@ class ConvNormActHeadFn(torch.autograd.Function):
         dx, dw, db = _conv_backward(dy, x, w, ctx.wref, ctx.bref if ctx.has_bias else None, (stride, pad, dil, pad_mode),
                                     ni[0], ni[1], ctx.has_bias and ni[2])
         return dx, dw, db, ret_g, ret_b, ret_hw, ret_hb, None, None, None
+
+
+class PixelDiscFn(torch.autograd.Function):
+    """The whole PixelDiscriminator (arch/discriminators.py:66-80) as one autograd node: Conv2d(cin, 64, 1x1) -> LeakyReLU ->
+    Conv2d(64, 2 ndf, 1x1) [+ the norm layer's batch statistics] in ONE launch (sscg_conv2d_front_fwd: the 64-channel map is formed
+    in LDS and written only for a backward pass), then the fused tail of ConvNormActHeadFn (norm -> LeakyReLU -> Conv2d(2 ndf, 1, 1x1)
+    while normalising).  The backward is the chain of the separate nodes: head / norm, second conv, LeakyReLU mask, first conv.
+    cfg = (slope1, per_sample, eps, momentum, act, slope)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w, bias, gamma, beta, hw, hbias, running_mean, running_var, cfg):
+        slope1, per_sample, eps, momentum, act, slope = cfg
+        x = to_nhwc(x)
+        n, _, h, wd = x.shape
+        g, l, c = _glc_shape((n, w.shape[0], h, wd), per_sample)
+        will = _will_backward(ctx)
+        y, h1, cs = conv2d_front_fwd(x, w1, b1, slope1, w, bias, (g, l, c), want_h1=will)
+        upd = running_mean is not None and per_sample is not True
+        mean, rstd = norm_stats_from_conv(cs, (g, l, c), eps, running_mean if upd else None, running_var if upd else None, momentum)
+        hw32 = hw.detach().reshape(-1)
+        if hw32.dtype != torch.float32:
+            hw32 = hw32.float()
+        out = norm_head_fwd(y, mean, rstd, gamma, beta, hw32, hbias, per_sample, act, slope)
+        ctx.cfg = cfg
+        ctx.has_b1, ctx.has_bias, ctx.has_hbias = b1 is not None, bias is not None, hbias is not None
+        ctx.w1ref, ctx.b1ref, ctx.wref, ctx.bref, ctx.gref, ctx.betaref, ctx.hwref, ctx.hbref = w1, b1, w, bias, gamma, beta, hw, hbias
+        if _will_backward(ctx, 1):
+            _note_use(w1, b1)
+        if _will_backward(ctx, 3):
+            _note_use(w, bias)
+        if will:
+            ctx.save_for_backward(x, w1, h1, w, y, mean, rstd, gamma, beta, hw32)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w1, h1, w, y, mean, rstd, gamma, beta, hw32 = ctx.saved_tensors
+        slope1, per_sample, eps, momentum, act, slope = ctx.cfg
+        ni = ctx.needs_input_grad
+        dout = dout.contiguous()
+        if dout.dtype != torch.float32:
+            dout = dout.float()
+        c = hw32.numel()
+        want_g = gamma is not None and ni[5]
+        dgb = torch.empty((2, c), dtype=torch.float32, device=y.device) if want_g else None
+        dwb = torch.empty(c + 1, dtype=torch.float32, device=y.device)
+        dy = norm_head_bwd(dout, hw32, y, mean, rstd, gamma, beta, per_sample, act, slope, True, dwb,
+                           dgb[0] if want_g else None, dgb[1] if want_g else None)
+        ret_hw = ret_hb = ret_g = ret_b = None
+        want_hw, want_hb = ni[7], ctx.has_hbias and ni[8]
+        hwacc = _acc_target(ctx.hwref) if want_hw else None
+        hbacc = _acc_target(ctx.hbref) if want_hb else None
+        if want_hw and hwacc is None:
+            ret_hw = dwb[:c].reshape(ctx.hwref.shape).to(ctx.hwref.dtype)
+        if want_hb and hbacc is None:
+            ret_hb = dwb[c:c + 1].clone()
+        gacc = _acc_target(ctx.gref) if want_g else None
+        bacc = _acc_target(ctx.betaref) if want_g else None
+        if want_g and (gacc is None or bacc is None):
+            gacc = bacc = None
+            ret_g, ret_b = dgb[0], dgb[1]
+
+        def arena_add(acc, src_ptr, count, ref, keep):      # every gradient of a parameter is accumulated on that parameter's lane
+            def go():
+                check(lib.sscg_add(acc.data_ptr(), src_ptr, acc.data_ptr(), F32, count, _stream()), "sscg_add")
+            run_on_side_stream(y.device, (keep,), go, lane=getattr(ref, "_sscg_lane", 0), defer=True)
+        if hwacc is not None:
+            arena_add(hwacc, dwb.data_ptr(), c, ctx.hwref, dwb)
+        if hbacc is not None:
+            arena_add(hbacc, dwb.data_ptr() + 4 * c, 1, ctx.hbref, dwb)
+        if gacc is not None:
+            arena_add(gacc, dgb.data_ptr(), c, ctx.gref, dgb)
+            arena_add(bacc, dgb.data_ptr() + 4 * c, c, ctx.betaref, dgb)
+        geom = (1, 0, 1, PAD_ZEROS)
+        front = ni[0] or ni[1] or (ctx.has_b1 and ni[2])
+        dh1, dw, db = _conv_backward(dy, h1, w, ctx.wref, ctx.bref if ctx.has_bias else None, geom, front, ni[3], ctx.has_bias and ni[4])
+        dx = dw1 = db1 = None
+        if front:
+            dh1 = act_bwd(dh1, h1, ACT_LRELU, slope1)
+            dx, dw1, db1 = _conv_backward(dh1, x, w1, ctx.w1ref, ctx.b1ref if ctx.has_b1 else None, geom, ni[0], ni[1], ctx.has_b1 and ni[2])
+        return dx, dw1, db1, dw, db, ret_g, ret_b, ret_hw, ret_hb, None, None, None
+
+
+def pixel_disc(x, w1, b1, slope1, w, bias, gamma, beta, hw, hbias, running_mean, running_var, per_sample, eps, momentum, act, slope):
+    _CALLER_GRAD[0] = torch.is_grad_enabled()
+    return PixelDiscFn.apply(x, w1, b1, w, bias, gamma, beta, hw, hbias, running_mean, running_var,
+                             (slope1, per_sample, eps, momentum, act, slope))
 
 
 def conv_norm_act_head(x, w, bias, stride, pad, dil, pad_mode, gamma, beta, hw, hbias, running_mean, running_var, per_sample, eps,

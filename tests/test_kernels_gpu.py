@@ -962,6 +962,85 @@ def test_fused_pixel_discriminator_tail(geom, norm, F, dev):
         assert rel_err(a[k], b[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("geom", [(3, 3, 37, 29, "instance", None), (2, 21, 64, 48, "instance", None), (2, 20, 33, 65, "batch", None),
+                                  (1, 4, 40, 40, "instance", 0), (2, 21, 64, 64, "instance", 0), (3, 3, 50, 70, "batch", 0),
+                                  (8, 3, 256, 256, "instance", None), (8, 21, 256, 256, "instance", None)],
+                         ids=lambda g: "n%d_c%d_%dx%d_%s_class%s" % g)
+def test_fused_pixel_discriminator_front(geom, F, dev):
+    """PixelDiscriminator's front half as one launch (PixelDiscFn / sscg_conv2d_front_fwd, arch/discriminators.py:70-73): Conv2d(cin, 64,
+    1x1) -> LeakyReLU formed per workgroup in LDS in front of the split contraction of Conv2d(64, 128, 1x1), whose epilogue takes the
+    norm layer's statistics.  Against the reference's module in fp64 - output, input gradient, every parameter gradient - and against
+    the unfused launch sequence of the same library (FUSE_FRONT off): 64x64 tiles (small maps), 128x128 tiles (forced, and chosen at
+    the bench size 8 x 256 x 256), both norm kinds; 3 / 4 / 20 / 21 input channels."""
+    ops = load_sub("arch.ops")
+    disc = load_sub("arch.discriminators")
+    N, Cin, H, W, norm, cls = geom
+    if F.get_conv_precision() != "f32s":
+        pytest.skip("the fused front half lives in the split contraction")
+    torch.manual_seed(N + Cin + H + W)
+    nl = ops.get_norm_layer(norm)
+    net = disc.PixelDiscriminator(Cin, 64, norm_layer=nl, use_bias=(norm == "instance")).to(dev)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn(p.shape) * (0.5 if p.dim() == 1 else 1.0 / p.shape[1] ** 0.5))
+    ref = _torch_pixel_discriminator(net, norm)
+    x0 = torch.randn(N, Cin, H, W)
+    g0 = torch.randn(N, 1, H, W)
+    xr = x0.double().requires_grad_(True)
+    torch.set_num_threads(min(torch.get_num_threads(), 32))
+    yr = ref(xr)
+    (yr * g0.double()).sum().backward()
+    want = [yr, xr.grad] + [p.grad for p in ref.parameters() if p.grad is not None]
+    got = {}
+    old = F.tuning(tile_class=cls)
+    calls = []
+    try:
+        for fused in (True, False):
+            F.FUSE_FRONT[0] = fused
+            for p in net.parameters():
+                p.grad = None
+            x = gpu(x0, dev).requires_grad_(True)
+            n0 = F.FRONT_CALLS[0]
+            y = net(x)
+            calls.append(F.FRONT_CALLS[0] - n0)
+            F.backward((y * gpu(g0, dev)).sum())
+            F.SideStream.join(dev)
+            torch.cuda.synchronize()
+            convs = [m for m in net.dis_model if hasattr(m, "kernel_size")]
+            norms = [m for m in net.dis_model if isinstance(m, ops.BatchNorm2d)]
+            grads = []
+            for m in convs:
+                grads.append(m.weight.grad)
+                if m.bias is not None:
+                    grads.append(m.bias.grad)
+            got[fused] = [y.detach(), x.grad] + grads + ([norms[0].weight.grad, norms[0].bias.grad] if norms else [])
+            # without a backward pass nothing but y is written: same output
+            with torch.no_grad():
+                y2 = net(gpu(x0, dev))
+            assert torch.equal(y2, y.detach()), fused
+    finally:
+        F.FUSE_FRONT[0] = True
+        F.TUNING[0], F.WGRAD_TUNING[0] = old
+    assert calls == [1, 0], calls          # the fused launch ran exactly where it was asked for
+    names = ["y", "dx", "w1", "b1", "w2"] + (["b2"] if norm == "instance" else []) + (["gamma", "beta"] if norm == "batch" else []) + ["w3"] + (["b3"] if norm == "instance" else [])
+    refs = dict(zip(names, want))
+    ours_names = ["y", "dx", "w1", "b1", "w2"] + (["b2"] if norm == "instance" else []) + ["w3"] + (["b3"] if norm == "instance" else []) + (["gamma", "beta"] if norm == "batch" else [])
+    errs = {}
+    for fused in (True, False):
+        vals = dict(zip(ours_names, got[fused]))
+        for k in names:
+            if k == "b2":
+                continue        # a bias in front of InstanceNorm has zero gradient: nothing to compare against but roundoff
+            errs[(fused, k)] = rel_err(vals[k].reshape(refs[k].shape), refs[k])
+    print()
+    print("  ".join("%s %.1e/%.1e" % (k, errs[(True, k)], errs[(False, k)]) for k in names if k != "b2"), "(fused / unfused, against fp64)")
+    for key, e in errs.items():
+        assert e < 3e-5, (key, e)
+    a, b = dict(zip(ours_names, got[True])), dict(zip(ours_names, got[False]))
+    for k in ("y", "dx", "w1", "w2", "w3"):
+        assert rel_err(a[k], b[k]) < 1e-5, k
+
+
 @pytest.mark.parametrize("case", [("instance", 3, 64, 20, 24, 128, 3, 1, 1), ("batch", 2, 128, 33, 33, 128, 1, 0, 1), ("batch2", 4, 64, 17, 19, 256, 3, 2, 2),
                                   ("instance", 2, 256, 33, 33, 64, 1, 0, 1), ("batch", 8, 32, 16, 16, 32, 3, 1, 1)],
                          ids=lambda c: "%s_n%d_c%d_%dx%d_k%d_r%d_p%d_d%d" % c)

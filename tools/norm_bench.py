@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Effective HBM bandwidth of the normalisation / pointwise kernels on the tensor shapes of BASELINE config 3 (tuning aid).
-usage: python tools/norm_bench.py [out.txt]      - GB/s = algorithmic bytes (tensors read + written once) / time"""
+usage: python tools/norm_bench.py [out.txt] [bf16|f32]   - GB/s = algorithmic bytes (tensors read + written once) / time;
+f32 = the fp32 tensors of BASELINE config 2 (batch 8, 33x33 maps; the stacked 16-image pass; the ResNet generators' maps)"""
 import importlib
 import os
 import sys
@@ -33,14 +34,19 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n
 
 
-out = open(sys.argv[1], "w") if len(sys.argv) > 1 else sys.stdout
+out = open(sys.argv[1], "w") if len(sys.argv) > 1 and sys.argv[1] != "-" else sys.stdout
+if len(sys.argv) > 2 and sys.argv[2] == "f32":
+    BF = torch.float32
+    SHAPES = [(8, 256, 33, 33, False), (8, 1024, 33, 33, False), (16, 256, 33, 33, 2), (16, 1024, 33, 33, 2), (8, 512, 33, 33, False),
+              (8, 2048, 33, 33, False), (8, 64, 65, 65, False), (8, 256, 65, 65, False), (16, 256, 64, 64, True), (16, 128, 128, 128, True),
+              (16, 64, 256, 256, True), (8, 128, 256, 256, True)]
 for (n, c, h, w, per) in SHAPES:
     x = torch.randn(n, c, h, w, device=dev).to(BF).contiguous(memory_format=CL)
     res = torch.randn(n, c, h, w, device=dev).to(BF).contiguous(memory_format=CL)
     dy = torch.randn(n, c, h, w, device=dev).to(BF).contiguous(memory_format=CL)
     gamma = torch.ones(c, device=dev)
     beta = torch.zeros(c, device=dev)
-    nb = x.numel() * 2
+    nb = x.numel() * x.element_size()
     mean, rstd = F.norm_stats(x, per)
     y = F.norm_apply(x, mean, rstd, gamma, beta, None, per, F.ACT_RELU)
     dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
