@@ -870,7 +870,9 @@ int sscg_finalize_conv_stats(const double* stats, int valid_tiles, int rows_per_
 
 template <typename T>
 static void launch_apply(const ApplyParams& p, int vec, hipStream_t st, int G = 0) {
-    static const int u8 = getenv("SSCG_NORM_SLAB_U8A") ? atoi(getenv("SSCG_NORM_SLAB_U8A")) : 4;       // tuning aid: rows in flight, 8-channel groups (0 = flat kernel)
+    // rows in flight per thread (measured, profiles/r06_experiments.txt item 5): 8-channel bf16 groups 2 (130 -> 86 registers: config 3
+    // -1 ms against 4), 4-channel groups 4; tuning aid SSCG_NORM_SLAB_U8A (0 = the flat kernel; 4-channel groups at 2 rows: no difference in the step)
+    static const int u8 = getenv("SSCG_NORM_SLAB_U8A") ? atoi(getenv("SSCG_NORM_SLAB_U8A")) : 2;
     const int U = vec == 8 ? u8 : 4;
     const SlabPlan sp = (G > 0 && U > 0) ? plan_slab(G, p.L, p.C, vec, U) : SlabPlan{false, 0, 1, 1, 0};
     if (sp.ok) {
@@ -918,14 +920,16 @@ extern "C" size_t sscg_norm_bwd_workspace(int G, int64_t L, int C) {
 
 template <typename T>
 static void launch_bwd_apply(const BwdApplyParams& q, int vec, hipStream_t st, int G = 0) {
-    static const int u8 = getenv("SSCG_NORM_SLAB_U8B") ? atoi(getenv("SSCG_NORM_SLAB_U8B")) : 2;       // tuning aid: rows in flight, 8-channel groups (0 = flat kernel)
+    // rows in flight (three loads each): 8-channel bf16 groups 1 (99 registers; with 4 rows - 210 registers - the kernel is slower than
+    // the flat one), 4-channel groups 4; tuning aid SSCG_NORM_SLAB_U8B (0 = the flat kernel)
+    static const int u8 = getenv("SSCG_NORM_SLAB_U8B") ? atoi(getenv("SSCG_NORM_SLAB_U8B")) : 1;
     const int U = vec == 8 ? u8 : 4;
     const SlabPlan sp = (G > 0 && U > 0) ? plan_slab(G, q.L, q.C, vec, U) : SlabPlan{false, 0, 1, 1, 0};
     if (sp.ok) {
         const dim3 grid(sp.chunks, sp.slabs, G);
         if (vec == 8 && U == 1) hipLaunchKernelGGL((norm_bwd_apply_slab_kernel<T, 8, 1>), grid, dim3(256), 0, st, q, sp.cw_shift, sp.rows_per_chunk);
         else if (vec == 8 && U == 2) hipLaunchKernelGGL((norm_bwd_apply_slab_kernel<T, 8, 2>), grid, dim3(256), 0, st, q, sp.cw_shift, sp.rows_per_chunk);
-        else if (vec == 8) hipLaunchKernelGGL((norm_bwd_apply_slab_kernel<T, 8, 4>), grid, dim3(256), 0, st, q, sp.cw_shift, sp.rows_per_chunk);
+        else if (vec == 8) return launch_bwd_apply<T>(q, vec, st);      // (4 rows of 8 channels: 210 registers, slower than the flat kernel - not built)
         else hipLaunchKernelGGL((norm_bwd_apply_slab_kernel<T, 4, 4>), grid, dim3(256), 0, st, q, sp.cw_shift, sp.rows_per_chunk);
         return;
     }
