@@ -196,10 +196,11 @@ def main():
     reserved0 = torch.cuda.memory_reserved(dev)
     dt, losses = timed(a.warmup, a.steps)
     grew = torch.cuda.memory_reserved(dev) - reserved0
-    retimed, grew2 = False, 0
+    retimed, grew2, first_ms = False, 0, None
     if dp is not None and world > 1:
         grew = int(par.max_over_ranks(float(grew)))       # every rank takes the same branch
     if grew > 0:
+        first_ms = 1e3 * dt / a.steps
         reserved0 = torch.cuda.memory_reserved(dev)
         dt, losses = timed(a.warmup, a.steps)
         retimed = True
@@ -235,6 +236,7 @@ def main():
         "mfma_peak_tflops": peak,
         "host_issue_ms_per_step": round(1e3 * host[0], 2),
         "timed_region_alloc": {"reserved_growth_bytes_first_pass": int(grew), "retimed": retimed, "reserved_growth_bytes_second_pass": int(grew2),
+                               **({"first_pass_ms_per_step": round(first_ms, 3)} if first_ms is not None else {}),
                                "reserved_bytes": int(torch.cuda.memory_reserved(dev))},
     }
     if host_bound_case is not None:
