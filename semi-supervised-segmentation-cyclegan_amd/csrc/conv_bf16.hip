@@ -468,11 +468,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         constexpr int OLD = BN + 4;
         uint32_t* ot = reinterpret_cast<uint32_t*>(smem_raw);
         uint32_t* ob = ot + ((row_w + 4 * lh) / 2) * OLD + col_w + li;        // this lane's corner; every word is a constant offset away
+        // A launch without bias and activation (round 6: every convolution of DeepLab - a norm layer follows) stages its accumulators
+        // as they are: the bias add and the activation's compare / select chain are six VALU operations per element, ~190 per tile
+        // and wave beside the 32 MFMAs of a 256-channel 1x1 reduction.  One uniform branch picks the instance of the loop.
+        auto stage_tile = [&](auto plain_tag) {
+        constexpr bool PLAIN = decltype(plain_tag)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + col_w + j * 32 + li;
             const bool nok = n < p.Ng;
-            const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+            const float bv = (!PLAIN && p.bias && nok) ? p.bias[n] : 0.f;
             double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
             float mu0, rs0, mu1, rs1, ga, be, bf_a = 0.f, bf_b = 0.f;
             bsum_params(n, nok, mu0, rs0, mu1, rs1, ga, be);
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                 for (int e = 0; e < 16; e += 2) {
                     const int ro = i * 32 + (e & 3) + 8 * (e >> 2);           // even: rows ro, ro + 1
                     const int m = m0 + row_w + 4 * lh + ro;
-                    const float pre0 = acc[i][j][e] + bv, pre1 = acc[i][j][e + 1] + bv;
+                    const float pre0 = PLAIN ? acc[i][j][e] : acc[i][j][e] + bv, pre1 = PLAIN ? acc[i][j][e + 1] : acc[i][j][e + 1] + bv;
                     if (want_bsums && nok) {
                         if (bs_fast) {
                             float fa = 0.f, fb = 0.f;
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                     }
                     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
                     typedef float f32x2_t __attribute__((ext_vector_type(2)));
-                    const f32x2_t pr = {sscg_act(pre0, p.act, p.slope), sscg_act(pre1, p.act, p.slope)};
+                    const f32x2_t pr = {PLAIN ? pre0 : sscg_act(pre0, p.act, p.slope), PLAIN ? pre1 : sscg_act(pre1, p.act, p.slope)};
                     const bf16x2_t pk = __builtin_convertvector(pr, bf16x2_t);      // RNE, v_cvt_pk_bf16_f32
                     ob[(ro / 2) * OLD + j * 32] = __builtin_bit_cast(uint32_t, pk);
                 }
@@ -516,6 +521,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             if (want_stats) put_stats(n, nok, s0, q0, s1, q1);
             if (want_bsums) { s0 += (double)bf_a; q0 += (double)bf_b; put_bsums(n, nok, s0, q0, s1, q1); }
         }
+        };
+        if (!p.bias && p.act == SSCG_ACT_NONE) stage_tile(std::true_type{});
+        else stage_tile(std::false_type{});
         __syncthreads();
         constexpr int TPR = BN / 8;             // threads per row PAIR (8 channels = two 16-byte row segments each)
         constexpr int RPP = NT / TPR;           // row pairs per pass

@@ -611,6 +611,16 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if constexpr (!ANY_NG && KS_STAGE_OUT) {
+                    // Every class but the heads' stages the RAW accumulators (round 6): bias and activation wait for the store phase,
+                    // where a thread owns four fixed channels of whole rows - the bias is one hoisted vector, the activation sits
+                    // behind a uniform branch.  Here they were six VALU operations per element whether or not the launch carries a
+                    // bias or an activation (DeepLab's convolutions carry neither): 190-380 of the ~900 fixed VALU operations a
+                    // tile costs beside its k-loop, as many as the split of a 256-channel reduction.  Same operations in the same
+                    // order per element: bit-identical.
+                    ot[(row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OLD + col_w + j * 32 + li] = acc[i][j][e];
+                    continue;
+                }
                 const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const float pre = acc[i][j][e] + bv;
                 if (reg_slow && m < ep.M && nok) {
@@ -653,10 +663,11 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
             constexpr int NLS = NT / BN;
             const int c = tid % BN, ln = tid / BN;
             double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+            const float sb = (!ANY_NG && ep.bias && n0 + c < ep.Ng) ? ep.bias[n0 + c] : 0.f;       // (the staged tile of these classes is raw)
             for (int r = ln; r < BM; r += NLS) {
                 const int m = m0 + r;
                 if (m >= ep.M) break;
-                const double d = (double)ot[r * OLD + c];
+                const double d = (double)(ot[r * OLD + c] + sb);
                 if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
             }
             double* const sr = reinterpret_cast<double*>(smem_raw + SREC_OFF);
@@ -706,12 +717,23 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
         // (a partial tile of a split-K tail goes to its slice of the workspace, rows counted from the tail's first)
         float* const obase = partial ? ep.part + ((long)split * (ep.M - ep.m_tail0) - ep.m_tail0) * (long)ep.Ng : ep.dst;
         if (n < ep.Ng && !joins) {               // (Ng % 4 == 0: a 16-byte piece is inside the row or outside it)
+            // bias and activation of the raw staged tile (the heads' class applied them before staging; a partial tile carries neither)
+            const bool has_b = !ANY_NG && !partial && ep.bias != nullptr;
+            const bool has_a = !ANY_NG && !partial && ep.act != SSCG_ACT_NONE;
+            f32x4 b4 = 0.f;
+            if (has_b) b4 = *reinterpret_cast<const f32x4*>(ep.bias + n);
 #pragma unroll
             for (int ps = 0; ps < BM / RPP; ++ps) {
                 const int r = tid / TPR + ps * RPP;
                 const int m = m0 + r;
                 if (m >= ep.M) break;
-                *reinterpret_cast<f32x4*>(obase + out_row(m) * ep.Ng + n) = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
+                f32x4 v = *reinterpret_cast<const f32x4*>(ot + r * OLD + c4);
+                if (has_b) v += b4;
+                if (has_a) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ks_act(v[e], ep.act, ep.slope);
+                }
+                *reinterpret_cast<f32x4*>(obase + out_row(m) * ep.Ng + n) = v;
             }
         }
         if (n < ep.Ng && joins) {
