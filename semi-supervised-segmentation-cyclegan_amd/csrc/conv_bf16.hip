@@ -69,7 +69,16 @@ struct K16Params {
     double* __restrict__ bn_sums;        // [G][bn_chunks][Ng][2]
     int bn_L, bn_G, bn_chunks, bn_act;
     float bn_slope;
+    FastDiv div_tn, div_hw, div_w, div_gl;   // by tiles_n, OH * OW, OW, stat_L / bn_L (launch16): tile and row decode without integer divisions (~35 VALU operations each)
 };
+
+// activations of the epilogue in every class but the heads' (32 columns): none / ReLU / LeakyReLU.  tanh - the ResNet generators' 3- and
+// 21-channel heads, the U-Net's outermost layer - lives in the 32-column class only (sscg_conv16_*_applies): its software expansion
+// (192 v_fmaak per instance) otherwise sits in every instance's epilogue (round 6; conv_split.hip did the same in round 5)
+__device__ __forceinline__ float k16_act(float v, int act, float slope) {
+    const float neg = act == SSCG_ACT_RELU ? 0.f : (act == SSCG_ACT_LRELU ? v * slope : v);
+    return v > 0.f ? v : neg;
+}
 
 __device__ __forceinline__ void store_out(void* dst, size_t idx, float v, int out_bf16) {
     if (out_bf16) reinterpret_cast<bf16*>(dst)[idx] = (bf16)v;
@@ -113,8 +122,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         tile = p.full_tiles + (t - split * ntail);
         partial = p.splits > 1;
     }
-    const int tile_n = tile % p.tiles_n;
-    const int tile_m = tile / p.tiles_n;
+    const int tile_m = fd_div(tile, p.div_tn);
+    const int tile_n = tile - tile_m * p.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -136,9 +145,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         const int m = m0 + r0 + ps * RP;
         aok[ps] = m < p.M;
         const int mm = aok[ps] ? m : 0;
-        const int img = mm / (p.OH * p.OW);
+        const int img = fd_div(mm, p.div_hw);
         const int rem = mm - img * (p.OH * p.OW);
-        const int oy = rem / p.OW;
+        const int oy = fd_div(rem, p.div_w);
         const int ox = rem - oy * p.OW;
 #if K16_BUFLD
         arow[ps] = (unsigned)img * (unsigned)(p.SH * p.SW * p.Cs) * 2u;
@@ -177,12 +186,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         if (MODE == MODE_FWD) {
             sy = ay0[ps] + tdy;
             sx = ax0[ps] + tdx;
-            int ry = sy < 0 ? -sy : sy;
-            int rx = sx < 0 ? -sx : sx;
-            ry = ry >= p.SH ? 2 * (p.SH - 1) - ry : ry;
-            rx = rx >= p.SW ? 2 * (p.SW - 1) - rx : rx;
-            sy = reflect ? ry : sy;
-            sx = reflect ? rx : sx;
+            if (reflect) {              // (uniform: only reflection-padded convolutions pay for the mirror arithmetic)
+                int ry = sy < 0 ? -sy : sy;
+                int rx = sx < 0 ? -sx : sx;
+                sy = ry >= p.SH ? 2 * (p.SH - 1) - ry : ry;
+                sx = rx >= p.SW ? 2 * (p.SW - 1) - rx : rx;
+            }
         } else {
             const int ty = ay0[ps] - tdy;
             const int tx = ax0[ps] - tdx;
@@ -207,7 +216,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
     const int f_nchunk = p.Cs / BK;
     // the copy front: (tap = (f_ky, f_kx), channel chunk) of the next k-tile to request - wave-uniform, walked incrementally
     int f_chunk, f_ky, f_kx;
-    {
+    if (kt0 == 0) {                     // (every whole tile: no integer divisions)
+        f_chunk = 0; f_ky = 0; f_kx = 0;
+    } else {
         const int tap0 = kt0 / f_nchunk;
         f_chunk = kt0 - tap0 * f_nchunk;
         f_ky = tap0 / p.S;
@@ -380,11 +391,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
     const bool want_bsums = BS && MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (the host plans these launches without split-K)
     int gb = 0x7fffffff;
     if (want_stats) {
-        const int g0 = m0 / p.stat_L;
+        const int g0 = fd_div(m0, p.div_gl);
         gb = (g0 + 1) * p.stat_L;
     }
     int bg = 0;
-    if (want_bsums) { bg = m0 / p.bn_L; gb = (bg + 1) * p.bn_L; }
+    if (want_bsums) { bg = fd_div(m0, p.div_gl); gb = (bg + 1) * p.bn_L; }
     // backward sums of the layer in front (norm.hip col_reduce_kernel<RM_BWD>, mask recomputed from the layer's input): one element
     auto bsum_add = [&](int m, int n, float pre, float mu0, float rs0, float mu1, float rs1, float ga, float be, double& s0, double& q0,
                         double& s1, double& q1) {
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                     }
                     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
                     typedef float f32x2_t __attribute__((ext_vector_type(2)));
-                    const f32x2_t pr = {PLAIN ? pre0 : sscg_act(pre0, p.act, p.slope), PLAIN ? pre1 : sscg_act(pre1, p.act, p.slope)};
+                    const f32x2_t pr = {PLAIN ? pre0 : k16_act(pre0, p.act, p.slope), PLAIN ? pre1 : k16_act(pre1, p.act, p.slope)};
                     const bf16x2_t pk = __builtin_convertvector(pr, bf16x2_t);      // RNE, v_cvt_pk_bf16_f32
                     ob[(ro / 2) * OLD + j * 32] = __builtin_bit_cast(uint32_t, pk);
                 }
@@ -533,9 +544,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         const uint32_t* src = ot + (tid / TPR) * OLD + c8;
         auto out_row = [&](int m) -> size_t {
             if (MODE == MODE_FWD || p.o_step == 1) return (size_t)m;
-            const int img = m / (p.OH * p.OW);          // parity class of a strided data gradient: rows interleave into dx
+            const int img = fd_div(m, p.div_hw);        // parity class of a strided data gradient: rows interleave into dx
             const int rem = m - img * (p.OH * p.OW);
-            const int oi = rem / p.OW;
+            const int oi = fd_div(rem, p.div_w);
             const int oj = rem - oi * p.OW;
             return (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
         };
@@ -658,13 +669,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                         }
                         size_t row = (size_t)m;
                         if (MODE == MODE_DGRAD && p.o_step != 1) {   // parity class of a strided data gradient: rows interleave into dx
-                            const int img = m / (p.OH * p.OW);
+                            const int img = fd_div(m, p.div_hw);
                             const int rem = m - img * (p.OH * p.OW);
-                            const int oi = rem / p.OW;
+                            const int oi = fd_div(rem, p.div_w);
                             const int oj = rem - oi * p.OW;
                             row = (size_t)img * p.o_HW + (size_t)(oi * p.o_step + p.o_a) * p.o_W + oj * p.o_step + p.o_b;
                         }
-                        store_out(p.dst, row * p.Ng + n, sscg_act(pre, p.act, p.slope), p.out_bf16);
+                        store_out(p.dst, row * p.Ng + n, STAGE_OUT ? k16_act(pre, p.act, p.slope) : sscg_act(pre, p.act, p.slope), p.out_bf16);
                     }
                 }
             }
@@ -778,6 +789,10 @@ int launch16(const K16Params& p0, hipStream_t st) {
     p.tiles_n = cdiv(p.Ng, BN);
     const int tiles_m = cdiv(p.M, BM);
     p.tiles = tiles_m * p.tiles_n;
+    p.div_tn = make_fastdiv(p.tiles_n);
+    p.div_hw = make_fastdiv(p.OH * p.OW);
+    p.div_w = make_fastdiv(p.OW);
+    p.div_gl = make_fastdiv((BS && MODE == MODE_DGRAD && p.bn_sums != nullptr) ? p.bn_L : (p.stat_L > 0 ? p.stat_L : 1));
     size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(bf16);
     const size_t stage = BN >= 64 ? (size_t)(BM / 2) * (BN + 4) * sizeof(uint32_t) : 0;      // output tile of the staged epilogue (bf16 row pairs)
     if (stage > smem) smem = stage;
@@ -844,7 +859,8 @@ static bool k16_extents_ok(const sscg_conv_desc* d, bool dgrad) {
 }
 
 bool sscg_conv16_fwd_applies(const sscg_conv_desc* d) {
-    return d->x_dtype == SSCG_BF16 && d->w_dtype == SSCG_BF16 && d->C % BK == 0 && k16_extents_ok(d, false);
+    return d->x_dtype == SSCG_BF16 && d->w_dtype == SSCG_BF16 && d->C % BK == 0 && (d->act != SSCG_ACT_TANH || d->K <= 32) &&
+           k16_extents_ok(d, false);
 }
 
 bool sscg_conv16_dgrad_applies(const sscg_conv_desc* d) {
@@ -918,6 +934,7 @@ bool sscg_conv16_dgrad_add_applies(const sscg_conv_desc* d) {
 
 int sscg_conv16_dgrad(const sscg_conv_desc* d, const void* dy, const void* wt, const float* bias, void* dx, int act, float slope,
                       void* ws, size_t ws_bytes, hipStream_t st, const sscg_bsums* bs, const void* addend) {
+    if (act == SSCG_ACT_TANH && d->C > 32) return SSCG_ERR_UNSUPPORTED;      // (tanh lives in the 32-column class only)
     K16Params p = {};
     bool fused = false;
     if (addend) {

@@ -219,12 +219,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
         if (MODE == MODE_FWD) {
             sy = ay0[ps] + tdy;
             sx = ax0[ps] + tdx;
-            int ry = sy < 0 ? -sy : sy;
-            int rx = sx < 0 ? -sx : sx;
-            ry = ry >= p.SH ? 2 * (p.SH - 1) - ry : ry;
-            rx = rx >= p.SW ? 2 * (p.SW - 1) - rx : rx;
-            sy = reflect ? ry : sy;
-            sx = reflect ? rx : sx;
+            if (reflect) {              // (uniform: only the ResNet generators' reflection-padded convolutions pay for the mirror arithmetic)
+                int ry = sy < 0 ? -sy : sy;
+                int rx = sx < 0 ? -sx : sx;
+                sy = ry >= p.SH ? 2 * (p.SH - 1) - ry : ry;
+                sx = rx >= p.SW ? 2 * (p.SW - 1) - rx : rx;
+            }
         } else {
             const int ty = ay0[ps] - tdy;
             const int tx = ax0[ps] - tdx;
@@ -245,7 +245,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
     const int kt1 = partial ? min(nk_all, kt0 + p.ksplit) : nk_all;
     const int f_nchunk = p.Cs / BKS;
     int f_chunk, f_ky, f_kx;
-    {
+    if (kt0 == 0) {                     // (every whole tile: the two integer divisions below are ~30 VALU operations)
+        f_chunk = 0; f_ky = 0; f_kx = 0;
+    } else {
         const int tap0 = kt0 / f_nchunk;
         f_chunk = kt0 - tap0 * f_nchunk;
         f_ky = tap0 / (p.S > 0 ? p.S : 1);
@@ -714,6 +716,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
             return (size_t)img * ep.o_HW + (size_t)(oi * ep.o_step + ep.o_a) * ep.o_W + oj * ep.o_step + ep.o_b;
         };
         const bool joins = MODE == MODE_DGRAD && !partial && (want_bsums || ep.addend != nullptr);
+        // the activation's derivative on the masked side, one scalar for the launch (none: 1, ReLU: 0, LeakyReLU: its slope)
+        const float neg_scale = ep.bn_act == SSCG_ACT_RELU ? 0.f : (ep.bn_act == SSCG_ACT_LRELU ? ep.bn_slope : 1.f);
         // (a partial tile of a split-K tail goes to its slice of the workspace, rows counted from the tail's first)
         float* const obase = partial ? ep.part + ((long)split * (ep.M - ep.m_tail0) - ep.m_tail0) * (long)ep.Ng : ep.dst;
         if (n < ep.Ng && !joins) {               // (Ng % 4 == 0: a 16-byte piece is inside the row or outside it)
@@ -771,9 +775,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
                         for (int e = 0; e < 4; ++e) {
                             const float xh = (yv[q][e] - (lo ? mu0[e] : mu1[e])) * (lo ? rs0[e] : rs1[e]);
                             const float ym = ep.bn_z ? zv[q][e] : xh * ga[e] + be[e];       // (sign of the output = sign of the pre-activation)
-                            float gg = v[e];
-                            if (ep.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? gg : 0.f;
-                            else if (ep.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? gg : gg * ep.bn_slope;
+                            const float gg = ym > 0.f ? v[e] : v[e] * neg_scale;        // (ReLU: -0 for a negative masked gradient - the sums do not see the sign of a zero)
                             if (lo) { sl[e] += gg; ql[e] = fmaf(gg, xh, ql[e]); } else { sh[e] += gg; qh[e] = fmaf(gg, xh, qh[e]); }
                         }
                     }

@@ -702,6 +702,9 @@ def _padded_weight(w, c_new):
 def conv2d_fwd(x, w, bias, stride=1, pad=0, dil=1, pad_mode=PAD_ZEROS, act=ACT_NONE, slope=0.0, out_f32=True, stats=None):
     """y = act(conv(x, w) + bias).  out_f32: keep the output fp32 in bf16 mode (network heads).
     stats = (G, L): also return the epilogue's column statistics buffer (None when the fusion does not apply)."""
+    if act == ACT_TANH and w.shape[0] > 32 and x.dtype == torch.bfloat16:
+        # (no such layer in the reference's nets: the bf16 kernels carry tanh in their 32-column heads' class only)
+        return act_fwd(conv2d_fwd(x, w, bias, stride, pad, dil, pad_mode, ACT_NONE, 0.0, out_f32), ACT_TANH, 0.0)
     if x.dtype == torch.float32:
         cp = _padded_stem(x.shape, w.shape, stride, pad, dil, pad_mode, 0)
         if cp:
@@ -857,6 +860,8 @@ def conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias=None, act=ACT_NO
     the sums then see the total).
     With bsums or addend the result is (dx, records, joined): records None where the library does not fuse the geometry (the caller
     runs the ordinary reduction pass), joined False where the addend was NOT added (the caller adds)."""
+    if act == ACT_TANH and xshape[1] > 32 and dy.dtype == torch.bfloat16 and bsums is None and addend is None:
+        return act_fwd(conv2d_dgrad(dy, wt, xshape, wshape, stride, pad, dil, bias, ACT_NONE, 0.0, out_dtype), ACT_TANH, 0.0)
     wdt = BF16X3 if (wt.dim() == 1 and wt.dtype == torch.bfloat16) else _dt(wt)      # the split copy is a flat tensor of three planes
     d = make_desc(xshape, wshape, stride, pad, dil, xdt=_DT[out_dtype], wdt=wdt, ydt=_dt(dy), prec=_prec("dgrad"))
     dx = empty_nhwc(d.N, d.C, d.H, d.W, dy.device, out_dtype)
