@@ -1015,6 +1015,7 @@ struct Wg16Params {
     int tiles_n, tiles, splits;
     float beta;
     FastDiv div_pq, div_q;
+    int buf_ok;                   // both operand tensors < 2 GB: their pixel rows are copied by buffer loads (32-bit offsets)
 };
 
 // ---- weight gradient, LDS-DMA + transpose-read version -------------------------------------------------------------------------
@@ -1107,7 +1108,30 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
     int f_pix = p_begin;                                      // first pixel of the next k-tile to request
     const int lds_wave_a = __builtin_amdgcn_readfirstlane(wave_id * A_NP * 1024);
     const int lds_wave_b = __builtin_amdgcn_readfirstlane(wave_id * B_NP * 1024);
+    // Round 6: the dy rows - and the x rows of a 1x1 stride-1 filter - are plain pixel rows: copied by buffer loads, the lane's offset
+    // inside a k-tile in ONE VGPR per copy (computed here), the k-tile's first pixel in the instruction's SGPR offset, a row past this
+    // workgroup's last pixel or a masked column at offset 2 GB (out of range = zeros).  The 64-bit address form
+    // below cost ~12 VALU operations per copy, 30-50 per k-tile of 8 MFMAs (7 VALU per MFMA measured: 8 % of config 3's VALU time).
+    const bool buf_a = p.buf_ok != 0, buf_b = p.buf_ok != 0 && plain;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, (short)0, (int)((unsigned)p.npix * (unsigned)p.Kc * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)((unsigned)p.npix * (unsigned)p.C * 2u), 0x00020000);
+    unsigned a_vo[A_NP], b_vo[B_NP];
+#pragma unroll
+    for (int s = 0; s < A_NP; ++s)
+        a_vo[s] = a_colok ? ((unsigned)((wave_id * A_NP + s) * A_PR + a_row) * (unsigned)p.Kc + (unsigned)(m0 + a_q * 8)) * 2u : 0x80000000u;
+#pragma unroll
+    for (int s = 0; s < B_NP; ++s)
+        b_vo[s] = b_colok ? ((unsigned)((wave_id * B_NP + s) * B_PR + b_row) * (unsigned)p.C + (unsigned)b_n) * 2u : 0x80000000u;
     auto request_tile = [&]() {
+        if (buf_a) {
+            const int so = __builtin_amdgcn_readfirstlane(f_pix * p.Kc * 2);
+#pragma unroll
+            for (int s = 0; s < A_NP; ++s) {
+                const bool pok = f_pix + (wave_id * A_NP + s) * A_PR + a_row < p_end;      // (the SGPR offset takes no part in the range check)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds0 + dma_stage * A_STAGE + lds_wave_a + s * 1024),
+                                                         16, (int)(pok ? a_vo[s] : 0x80000000u), so, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < A_NP; ++s) {
             const int pix = f_pix + (wave_id * A_NP + s) * A_PR + a_row;
@@ -1115,6 +1139,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(lds0 + dma_stage * A_STAGE + lds_wave_a + s * 1024), 16, 0, 0);
         }
+        }
+        if (buf_b) {
+            const int so = __builtin_amdgcn_readfirstlane(f_pix * p.C * 2);
+#pragma unroll
+            for (int s = 0; s < B_NP; ++s) {
+                const bool pok = f_pix + (wave_id * B_NP + s) * B_PR + b_row < p_end;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + dma_stage * B_STAGE + lds_wave_b + s * 1024),
+                                                         16, (int)(pok ? b_vo[s] : 0x80000000u), so, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < B_NP; ++s) {
             const int pix = f_pix + (wave_id * B_NP + s) * B_PR + b_row;
@@ -1142,6 +1176,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             const bf16* g = ok ? b_src + spix * p.C : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + dma_stage * B_STAGE + lds_wave_b + s * 1024), 16, 0, 0);
+        }
         }
         dma_stage = dma_stage + 1 == NSTAGE ? 0 : dma_stage + 1;
         f_pix += BKP;
@@ -1328,6 +1363,7 @@ int sscg_wgrad16(const sscg_conv_desc* d, const void* x, const void* dy, float* 
     p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.S = d->S;
     p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.pad_mode = d->pad_mode;
     p.npix = d->N * d->P * d->Q; p.chunk = pl.chunk;
+    p.buf_ok = ((size_t)p.npix * d->K * 2 < ((size_t)1 << 31) && (size_t)d->N * d->H * d->W * d->C * 2 < ((size_t)1 << 31)) ? 1 : 0;
     p.beta = pl.splits > 1 ? 0.f : beta;
     p.div_pq = make_fastdiv(d->P * d->Q);
     p.div_q = make_fastdiv(d->Q);
