@@ -435,7 +435,7 @@ def pmc_traffic(fam):
     kernel family (its kernel names are checked), with its source named in the line.  Units and the gfx950 correction as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes: counters are KiB; FETCH_SIZE under-reports wide coalesced reads by 2x."""
     want = {"bf16": "conv16_kernel", "split": "convs_kernel", "f32": "conv_kc_kernel"}[fam]
-    for name in ("r05_pmc_per_kernel_%s.json" % fam, "r04_pmc_per_kernel_%s.json" % fam, "r03_pmc_per_kernel_%s.json" % fam, "r02_pmc_per_kernel_%s.json" % fam):
+    for name in ("r06_pmc_per_kernel_%s.json" % fam, "r05_pmc_per_kernel_%s.json" % fam, "r04_pmc_per_kernel_%s.json" % fam, "r03_pmc_per_kernel_%s.json" % fam, "r02_pmc_per_kernel_%s.json" % fam):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
