@@ -50,19 +50,14 @@ def test_fuzzed_schedules_compute_the_serial_schedules_bits():
     assert "finite=False" not in r.stdout
 
 
-def test_bucketed_exchange_through_rccl_equals_the_serial_non_dp_bits():
-    """The same with SSCG_DP_BUCKETS=4 (the default under a process group): four all-reduces on a stream of their own, each ordered behind one event per lane, while the
-    backward is still running - 4 steps, plain and fuzzed, bit for bit the serial non-DP run."""
-    r = _run("fuzz_step.py", [1, 4, 64, 2], {"SSCG_FORCE_DP": "1", "SSCG_DP_BUCKETS": "4", "MASTER_PORT": "29733"})
-    assert r.returncode == 0 and "0 of 2 schedules differ" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
-    assert "finite=False" not in r.stdout
-
-
 def test_sixty_steps_through_rccl_equal_the_serial_non_dp_bits():
-    """SSCG_FORCE_DP=1, SSCG_DP_BUCKETS=0: the step goes through the RCCL path (broadcast, asynchronous ONE-PIECE all-reduce of the 343 MB gradient arena on
-    RCCL's own stream, the deferred generator update, the operand-copy refresh behind it).  A sum over one rank is the identity, so
-    60 steps (the image pools start swapping at 50) must equal the serial non-DP run bit for bit - plain and fuzzed."""
-    r = _run("fuzz_step.py", [1, 60, 64, 2], {"SSCG_FORCE_DP": "1", "SSCG_DP_BUCKETS": "0", "MASTER_PORT": "29732"})
+    """SSCG_FORCE_DP=1: the step goes through the RCCL path as a process group runs it (broadcast; the 343 MB generator arena in FOUR
+    reverse-order buckets - the default under a process group since round 6 - each an asynchronous all-reduce on a stream of its own
+    behind one event per lane, while the backward is still running; the one-piece exchange of the discriminator arena; the deferred
+    generator update, the operand-copy refresh behind it).  A sum over one rank is the identity, so 60 steps (the image pools start
+    swapping at 50) must equal the serial non-DP run bit for bit - plain and fuzzed.  (Until round 6 a second, 4-step test ran the
+    bucketed exchange beside a one-piece 60-step run: one process start and one RCCL initialisation less in the suite.)"""
+    r = _run("fuzz_step.py", [1, 60, 64, 2], {"SSCG_FORCE_DP": "1", "MASTER_PORT": "29732"})
     assert r.returncode == 0 and "0 of 2 schedules differ" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
     assert "finite=False" not in r.stdout
 
