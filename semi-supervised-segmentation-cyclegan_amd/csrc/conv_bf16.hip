@@ -529,13 +529,34 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                     ob[(ro / 2) * OLD + j * 32] = __builtin_bit_cast(uint32_t, pk);
                 }
             }
-            if (want_stats) put_stats(n, nok, s0, q0, s1, q1);
+            if (want_stats) {
+                // ONE record per tile (round 6; it was one per wave row): the wave rows' sums meet in LDS behind the staged tile and are
+                // added in a fixed order after the barrier below - the finalize launch behind every conv -> norm link reads WM x fewer records
+                s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+                s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+                if (lh == 0) {
+                    double* const sr = reinterpret_cast<double*>(smem_raw + (BM / 2) * OLD * 4) + (wm * BN + col_w + j * 32 + li) * 4;
+                    sr[0] = s0; sr[1] = q0; sr[2] = s1; sr[3] = q1;
+                }
+            }
             if (want_bsums) { s0 += (double)bf_a; q0 += (double)bf_b; put_bsums(n, nok, s0, q0, s1, q1); }
         }
         };
         if (!p.bias && p.act == SSCG_ACT_NONE) stage_tile(std::true_type{});
         else stage_tile(std::false_type{});
         __syncthreads();
+        if (want_stats && tid < BN && n0 + tid < p.Ng) {
+            const double* const sr = reinterpret_cast<const double*>(smem_raw + (BM / 2) * OLD * 4);
+            double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                a += sr[(w * BN + tid) * 4]; b += sr[(w * BN + tid) * 4 + 1]; c += sr[(w * BN + tid) * 4 + 2]; d += sr[(w * BN + tid) * 4 + 3];
+            }
+            const int nn = n0 + tid;
+            double* rec = p.stats + ((size_t)tile_m * 2) * p.Ng * 2;
+            rec[(size_t)nn * 2] = a; rec[(size_t)nn * 2 + 1] = b;
+            rec[((size_t)p.Ng + nn) * 2] = c; rec[((size_t)p.Ng + nn) * 2 + 1] = d;
+        }
         constexpr int TPR = BN / 8;             // threads per row PAIR (8 channels = two 16-byte row segments each)
         constexpr int RPP = NT / TPR;           // row pairs per pass
         const int c8 = (tid % TPR) * 8;
@@ -794,7 +815,7 @@ int launch16(const K16Params& p0, hipStream_t st) {
     p.div_w = make_fastdiv(p.OW);
     p.div_gl = make_fastdiv((BS && MODE == MODE_DGRAD && p.bn_sums != nullptr) ? p.bn_L : (p.stat_L > 0 ? p.stat_L : 1));
     size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(bf16);
-    const size_t stage = BN >= 64 ? (size_t)(BM / 2) * (BN + 4) * sizeof(uint32_t) : 0;      // output tile of the staged epilogue (bf16 row pairs)
+    const size_t stage = BN >= 64 ? (size_t)(BM / 2) * (BN + 4) * sizeof(uint32_t) + (size_t)WM * BN * 4 * sizeof(double) : 0;      // output tile of the staged epilogue (bf16 row pairs) + the wave rows' statistics behind it
     if (stage > smem) smem = stage;
     const size_t stage_f = (BN >= 64 && p.splits > 1) ? (size_t)BM * (BN + 4) * sizeof(float) : 0;      // fp32 tile of a split-K tail's partial workgroups
     if (stage_f > smem) smem = stage_f;
@@ -873,7 +894,7 @@ bool sscg_conv16_stats_geometry(const sscg_conv_desc* d, long L, int* bm, int* w
     const int cfg = choose16(M, d->K, d->R * d->S * d->C, d->tuning);
     if (cfg == CFG_128x32 || L < C16_BM[cfg]) return false;
     *bm = C16_BM[cfg];
-    *wm = C16_WM[cfg];
+    *wm = d->y_dtype == SSCG_BF16 ? 1 : C16_WM[cfg];       // bf16 results leave through a staged tile: its wave rows' sums meet in LDS (one record per tile)
     *tiles_n = cdiv(d->K, C16_BN[cfg]);
     K16Split sp = plan16(M, d->K, d->R * d->S * d->C, d->tuning, L);
     *splits = sp.splits; *full_tiles = sp.full_tiles; *m_tail0 = sp.m_tail0;
