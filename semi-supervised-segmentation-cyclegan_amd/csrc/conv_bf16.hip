@@ -93,8 +93,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }      // orders the consumer behind the wait above it
 
-// BS: the data gradient also takes the backward sums of the normalisation layer in front (its own instances: the sums' code - per
-// element loads of the layer's input, two accumulation paths - otherwise rides in every data-gradient launch's epilogue)
+// BS: the data gradient also takes the backward sums of the normalisation layer in front, in its store phase (its own instances: the
+// sums' code and registers otherwise ride in every data-gradient launch; a BS instance carries no fan-in code - bf16 tensors never
+// ask for both)
 template <int MODE, int WM, int WN, int TM, int TN, int NSTAGE, bool BS = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 2) void conv16_kernel(K16Params p) {
     constexpr int NT = WM * WN * 64;          // 4 waves (256 threads) or 8 waves (512)
@@ -388,56 +389,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
     // x and x^2 over this tile's rows, taken from the fp32 accumulators (+ bias), in fp64; a tile may straddle ONE group
     // boundary (rows m < gb belong to the tile's first group, the rest to the next one).
     const bool want_stats = MODE == MODE_FWD && p.stats != nullptr && !partial;      // (a data gradient never takes forward statistics)
-    const bool want_bsums = BS && MODE == MODE_DGRAD && p.bn_sums != nullptr;        // (the host plans these launches without split-K)
+    const bool want_bsp = BS && MODE == MODE_DGRAD && p.bn_sums != nullptr;          // (the host plans these launches without split-K)
     int gb = 0x7fffffff;
     if (want_stats) {
         const int g0 = fd_div(m0, p.div_gl);
         gb = (g0 + 1) * p.stat_L;
     }
     int bg = 0;
-    if (want_bsums) { bg = fd_div(m0, p.div_gl); gb = (bg + 1) * p.bn_L; }
-    // backward sums of the layer in front (norm.hip col_reduce_kernel<RM_BWD>, mask recomputed from the layer's input): one element
-    auto bsum_add = [&](int m, int n, float pre, float mu0, float rs0, float mu1, float rs1, float ga, float be, double& s0, double& q0,
-                        double& s1, double& q1) {
-        const bool lo = m < gb;
-        const float xh = ((float)p.bn_x[(size_t)m * p.Ng + n] - (lo ? mu0 : mu1)) * (lo ? rs0 : rs1);
-        const float ym = xh * ga + be;
-        float gg = pre;
-        if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? pre : 0.f;
-        else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? pre : pre * p.bn_slope;
-        const double d = (double)gg;
-        if (lo) { s0 += d; q0 += d * (double)xh; } else { s1 += d; q1 += d * (double)xh; }
-    };
-    const bool bs_fast = want_bsums && m0 + BM <= gb;      // tile inside one group: short runs of rows in fp32, their sums in fp64
-    auto bsum_add32 = [&](int m, int n, float pre, float mu0, float rs0, float ga, float be, float& fa, float& fb) {
-        const float xh = ((float)p.bn_x[(size_t)m * p.Ng + n] - mu0) * rs0;
-        const float ym = xh * ga + be;
-        float gg = pre;
-        if (p.bn_act == SSCG_ACT_RELU) gg = ym > 0.f ? pre : 0.f;
-        else if (p.bn_act == SSCG_ACT_LRELU) gg = ym > 0.f ? pre : pre * p.bn_slope;
-        fa += gg; fb = fmaf(gg, xh, fb);
-    };
-    auto put_bsums = [&](int n, bool nok, double s0, double q0, double s1, double q1) {
-        s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
-        s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-        if (lh == 0 && nok) {
-            const int k0 = (tile_m - (int)(((long)bg * p.bn_L) / BM)) * WM + wm;
-            double* r0 = p.bn_sums + (((size_t)bg * p.bn_chunks + k0) * p.Ng + n) * 2;
-            r0[0] = s0; r0[1] = q0;
-            if (m0 + BM > gb && bg + 1 < p.bn_G) {
-                double* r1 = p.bn_sums + (((size_t)(bg + 1) * p.bn_chunks + wm) * p.Ng + n) * 2;
-                r1[0] = s1; r1[1] = q1;
-            }
-        }
-    };
-    auto bsum_params = [&](int n, bool nok, float& mu0, float& rs0, float& mu1, float& rs1, float& ga, float& be) {
-        mu0 = rs0 = mu1 = rs1 = be = 0.f; ga = 1.f;
-        if (want_bsums && nok) {
-            mu0 = p.bn_mean[(size_t)bg * p.Ng + n]; rs0 = p.bn_rstd[(size_t)bg * p.Ng + n];
-            if (bg + 1 < p.bn_G) { mu1 = p.bn_mean[(size_t)(bg + 1) * p.Ng + n]; rs1 = p.bn_rstd[(size_t)(bg + 1) * p.Ng + n]; }
-            if (p.bn_gamma) { ga = p.bn_gamma[n]; be = p.bn_beta[n]; }
-        }
-    };
+    if (want_bsp) { bg = fd_div(m0, p.div_gl); gb = (bg + 1) * p.bn_L; }
     // tiles inside one group and inside the tensor (nearly all): four consecutive rows are summed in fp32, the 4-row sums in fp64
     const bool slow_stats = want_stats && (m0 + BM > gb || m0 + BM > p.M);
     const bool fast_stats = want_stats && !slow_stats;
@@ -490,8 +449,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             const bool nok = n < p.Ng;
             const float bv = (!PLAIN && p.bias && nok) ? p.bias[n] : 0.f;
             double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
-            float mu0, rs0, mu1, rs1, ga, be, bf_a = 0.f, bf_b = 0.f;
-            bsum_params(n, nok, mu0, rs0, mu1, rs1, ga, be);
             if (fast_stats) fast_sums(j, bv, s0, q0);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -500,18 +457,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                     const int ro = i * 32 + (e & 3) + 8 * (e >> 2);           // even: rows ro, ro + 1
                     const int m = m0 + row_w + 4 * lh + ro;
                     const float pre0 = PLAIN ? acc[i][j][e] : acc[i][j][e] + bv, pre1 = PLAIN ? acc[i][j][e + 1] : acc[i][j][e + 1] + bv;
-                    if (want_bsums && nok) {
-                        if (bs_fast) {
-                            float fa = 0.f, fb = 0.f;
-                            if (m < p.M) bsum_add32(m, n, pre0, mu0, rs0, ga, be, fa, fb);
-                            if (m + 1 < p.M) bsum_add32(m + 1, n, pre1, mu0, rs0, ga, be, fa, fb);
-                            bf_a += fa; bf_b += fb;
-                            if ((e & 3) == 2) { s0 += (double)bf_a; q0 += (double)bf_b; bf_a = 0.f; bf_b = 0.f; }
-                        } else {
-                            if (m < p.M) bsum_add(m, n, pre0, mu0, rs0, mu1, rs1, ga, be, s0, q0, s1, q1);
-                            if (m + 1 < p.M) bsum_add(m + 1, n, pre1, mu0, rs0, mu1, rs1, ga, be, s0, q0, s1, q1);
-                        }
-                    }
                     if (slow_stats) {
                         if (m < p.M) {
                             const double d = (double)pre0;
@@ -539,7 +484,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                     sr[0] = s0; sr[1] = q0; sr[2] = s1; sr[3] = q1;
                 }
             }
-            if (want_bsums) { s0 += (double)bf_a; q0 += (double)bf_b; put_bsums(n, nok, s0, q0, s1, q1); }
         }
         };
         if (!p.bias && p.act == SSCG_ACT_NONE) stage_tile(std::true_type{});
@@ -576,7 +520,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         constexpr bool CAN_JOIN = NPS <= 2;     // the classes the plan uses (64x64, 128x64, 128x128 of 8 waves); host: sscg_conv16_dgrad_add_applies
         constexpr int NAD = CAN_JOIN ? NPS : 1;
         uint4 ad0[NAD], ad1[NAD];
-        const bool joins = CAN_JOIN && MODE == MODE_DGRAD && p.addend != nullptr;      // (host: Ng % 8 == 0)
+        const bool joins = !BS && CAN_JOIN && MODE == MODE_DGRAD && p.addend != nullptr;      // (host: Ng % 8 == 0; never together with the sums on bf16 tensors)
         if (joins) {
 #pragma unroll
             for (int ps = 0; ps < NAD; ++ps) {
@@ -585,6 +529,73 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                 if ((tid / TPR + ps * RPP) < BM / 2 && n < p.Ng) {
                     if (m < p.M) ad0[ps] = *reinterpret_cast<const uint4*>(p.addend + out_row(m) * p.Ng + n);
                     if (m + 1 < p.M) ad1[ps] = *reinterpret_cast<const uint4*>(p.addend + out_row(m + 1) * p.Ng + n);
+                }
+            }
+        }
+        // Backward sums of the normalisation layer in front, taken HERE (round 6; conv_split.hip's store phase): a thread owns eight fixed
+        // channels of whole rows - the layer's input arrives as 16-byte row segments like the result leaves, requested up front with
+        // the addend's; sum g and sum g * xhat in fp32 over the thread's <= 4 rows, across the wave's row lanes by shuffles, across
+        // the waves in fp64 through LDS: ONE record per tile and group.  A tile that straddles a group boundary takes the rows of
+        // its second group in a sweep of its own (it reads its own dx rows back).
+        uint4 xr0[NAD], xr1[NAD];
+        float bmu[8], brs[8], bga[8], bbe[8], bsl[8], bql[8];
+        const float neg_scale = p.bn_act == SSCG_ACT_RELU ? 0.f : (p.bn_act == SSCG_ACT_LRELU ? p.bn_slope : 1.f);
+        const bool bsp = BS && CAN_JOIN && want_bsp;
+        auto bsp_params = [&](int g) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bmu[e] = 0.f; brs[e] = 0.f; bga[e] = 1.f; bbe[e] = 0.f; bsl[e] = 0.f; bql[e] = 0.f; }
+            if (n < p.Ng) {
+                ld8<float>(p.bn_mean + (size_t)g * p.Ng + n, bmu);
+                ld8<float>(p.bn_rstd + (size_t)g * p.Ng + n, brs);
+                if (p.bn_gamma) { ld8<float>(p.bn_gamma + n, bga); ld8<float>(p.bn_beta + n, bbe); }
+            }
+        };
+        auto bsp_row = [&](const uint4& v, const uint4& x) {
+            const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, xw[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int e = 2 * w + hh;
+                    const float vv = __uint_as_float(hh ? (vw[w] & 0xffff0000u) : (vw[w] << 16));
+                    const float xx = __uint_as_float(hh ? (xw[w] & 0xffff0000u) : (xw[w] << 16));
+                    const float xh = (xx - bmu[e]) * brs[e];
+                    const float ym = xh * bga[e] + bbe[e];
+                    const float gg = ym > 0.f ? vv : vv * neg_scale;
+                    bsl[e] += gg; bql[e] = fmaf(gg, xh, bql[e]);
+                }
+            }
+        };
+        auto bsp_put = [&](int g, int chunk) {
+            // row lanes of a wave (lanes TPR apart), then the waves through LDS behind the staged tile, then one record
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                for (int o = TPR; o < 64; o <<= 1) { bsl[e] += __shfl_xor(bsl[e], o, 64); bql[e] += __shfl_xor(bql[e], o, 64); }
+            }
+            float* const sf = reinterpret_cast<float*>(smem_raw + (BM / 2) * OLD * 4);       // [NT / 64 waves][BN][2]
+            __syncthreads();
+            if ((tid & 63) < TPR) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sf[((tid >> 6) * BN + c8 + e) * 2] = bsl[e]; sf[((tid >> 6) * BN + c8 + e) * 2 + 1] = bql[e]; }
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.Ng) {
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int w = 0; w < NT / 64; ++w) { a += (double)sf[(w * BN + tid) * 2]; b += (double)sf[(w * BN + tid) * 2 + 1]; }
+                double* r = p.bn_sums + (((size_t)g * p.bn_chunks + chunk) * p.Ng + n0 + tid) * 2;
+                r[0] = a; r[1] = b;
+            }
+        };
+        if (bsp) {
+            bsp_params(bg);
+#pragma unroll
+            for (int ps = 0; ps < NAD; ++ps) {
+                const int m = m0 + 2 * (tid / TPR + ps * RPP);
+                xr0[ps] = uint4{0u, 0u, 0u, 0u}; xr1[ps] = uint4{0u, 0u, 0u, 0u};
+                if ((tid / TPR + ps * RPP) < BM / 2 && n < p.Ng) {
+                    if (m < p.M) xr0[ps] = *reinterpret_cast<const uint4*>(p.bn_x + (size_t)m * p.Ng + n);
+                    if (m + 1 < p.M) xr1[ps] = *reinterpret_cast<const uint4*>(p.bn_x + (size_t)(m + 1) * p.Ng + n);
                 }
             }
         }
@@ -612,6 +623,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                 lo.x = add2(lo.x, ad0[ps % NAD].x); lo.y = add2(lo.y, ad0[ps % NAD].y); lo.z = add2(lo.z, ad0[ps % NAD].z); lo.w = add2(lo.w, ad0[ps % NAD].w);
                 hi.x = add2(hi.x, ad1[ps % NAD].x); hi.y = add2(hi.y, ad1[ps % NAD].y); hi.z = add2(hi.z, ad1[ps % NAD].z); hi.w = add2(hi.w, ad1[ps % NAD].w);
             }
+            if (bsp) {
+                if (m < gb) bsp_row(lo, xr0[ps % NAD]);
+                if (m + 1 < p.M && m + 1 < gb) bsp_row(hi, xr1[ps % NAD]);
+            }
             const bool full = n + 8 <= p.Ng;
             bf16* r0 = out + out_row(m) * p.Ng + n;
             if (full) {
@@ -628,6 +643,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
                     const uint32_t wv[4] = {hi.x, hi.y, hi.z, hi.w};
                     for (int e = 0; e < 8 && n + e < p.Ng; ++e) reinterpret_cast<uint16_t*>(r1)[e] = (uint16_t)(wv[e >> 1] >> (16 * (e & 1)));
                 }
+            }
+        }
+        if (bsp) {
+            bsp_put(bg, tile_m - (int)(((long)bg * p.bn_L) / BM));
+            if (m0 + BM > gb && bg + 1 < p.bn_G) {       // (workgroup-uniform, one tile per group) rows of the NEXT group: its first record
+                bsp_params(bg + 1);
+                if (n + 8 <= p.Ng) {
+#pragma unroll 1
+                    for (int pr = tid / TPR; pr < BM / 2; pr += RPP) {
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int m = m0 + 2 * pr + hh;
+                            if (m >= gb && m < p.M)
+                                bsp_row(*reinterpret_cast<const uint4*>(out + out_row(m) * p.Ng + n), *reinterpret_cast<const uint4*>(p.bn_x + (size_t)m * p.Ng + n));
+                        }
+                    }
+                }
+                bsp_put(bg + 1, 0);
             }
         }
         return;
@@ -666,24 +699,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
         const bool nok = n < p.Ng;
         const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
         double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
-        float mu0, rs0, mu1, rs1, ga, be, bf_a = 0.f, bf_b = 0.f;
-        bsum_params(n, nok, mu0, rs0, mu1, rs1, ga, be);
         if (fast_stats) fast_sums(j, bv, s0, q0);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (want_bsums && bs_fast && (e & 3) == 0 && e > 0) { s0 += (double)bf_a; q0 += (double)bf_b; bf_a = 0.f; bf_b = 0.f; }
                 if (m < p.M && nok) {
                     if (partial) {
                         p.part[((size_t)split * (p.M - p.m_tail0) + (m - p.m_tail0)) * p.Ng + n] = acc[i][j][e];
                     } else {
                         const float pre = acc[i][j][e] + bv;
-                        if (want_bsums) {
-                            if (bs_fast) bsum_add32(m, n, pre, mu0, rs0, ga, be, bf_a, bf_b);
-                            else bsum_add(m, n, pre, mu0, rs0, mu1, rs1, ga, be, s0, q0, s1, q1);
-                        }
                         if (slow_stats) {
                             const double d = (double)pre;
                             if (m < gb) { s0 += d; q0 += d * d; } else { s1 += d; q1 += d * d; }
@@ -702,7 +728,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && TM * TN == 2) ? 4 : 
             }
         }
         if (want_stats) put_stats(n, nok, s0, q0, s1, q1);
-        if (want_bsums) { s0 += (double)bf_a; q0 += (double)bf_b; put_bsums(n, nok, s0, q0, s1, q1); }
     }
 }
 
@@ -938,10 +963,10 @@ bool sscg_conv16_bsums_geometry(const sscg_conv_desc* d, int G, long L, int* bm,
     const long M = (long)d->N * d->H * d->W;
     if (G <= 0 || L <= 0 || (long)G * L != M) return false;
     const int cfg = choose16(M, d->C, d->R * d->S * d->K, d->tuning);
-    if (cfg == CFG_128x32 || L < C16_BM[cfg]) return false;
+    if (!(cfg == CFG_64x64 || cfg == CFG_128x64 || cfg == CFG_128x128_W8) || L < C16_BM[cfg] || d->C % 8 != 0) return false;   // (the store phase's classes, whole 16-byte segments)
     *bm = C16_BM[cfg];
-    *wm = C16_WM[cfg];
-    *chunks = (int)(cdiv(L, (long)C16_BM[cfg]) + 1) * C16_WM[cfg];
+    *wm = 1;                                // one record per tile and group (the sums are taken in the store phase, per workgroup)
+    *chunks = (int)(cdiv(L, (long)C16_BM[cfg]) + 1);
     return true;
 }
 

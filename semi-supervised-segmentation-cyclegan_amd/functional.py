@@ -406,10 +406,12 @@ FUSE_STATS = [os.environ.get("SSCG_FUSE_STATS", "1") != "0"]    # norm statistic
 # The reduction pass of a norm layer's backward from the epilogue of the data gradient that produces its upstream gradient
 # (sscg_conv2d_dgrad_bsums): ~260 col_reduce launches fewer per step.  fp32 tensors: ON - the split kernel takes
 # the sums in its coalesced store phase (config 2 134.4 -> 134.0 ms, host issue time -2 ms per step; the first version, sums in the
-# MFMA layout, LOST 0.7 ms).  bf16 tensors: off - conv16_kernel takes them in the MFMA layout (config 3 +1.9 ms); a store-phase
-# version of it was tried too and still lost (+0.5..1.9 ms, and 64 -> 111 VGPRs in the 64x64 class), so it was not kept.
-# SSCG_FUSE_BSUMS=1 / 0 forces both on / off (profiles/r04_experiments.txt items 3, 11 and 12).
-_FB = os.environ.get("SSCG_FUSE_BSUMS", "f32")
+# MFMA layout, LOST 0.7 ms).  bf16 tensors: ON since round 6 - rounds 4-5 took them in conv16_kernel's MFMA layout (per-element
+# 2-byte gathers of the layer's input: config 3 +1.9 ... +3 ms) and a first store-phase version lost too (64 -> 111 VGPRs); the round-6
+# store phase (16-byte row segments requested with the addend's, fp32 over a thread's rows, shuffles across a wave's row lanes,
+# fp64 across the waves, one record per tile; its own instances, 128 VGPRs without the fan-in code) wins 1.05 ms at config 3
+# (profiles/r06_experiments.txt item 17).  SSCG_FUSE_BSUMS=1 / 0 forces both on / off, "f32" = fp32 tensors only.
+_FB = os.environ.get("SSCG_FUSE_BSUMS", "1")
 FUSE_BSUMS = [_FB != "0"]            # master switch (tests flip it)
 FUSE_BSUMS_BF16 = [_FB == "1"]
 
