@@ -26,6 +26,7 @@
 #include "sscg_internal.h"
 #include "reduce_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -500,6 +501,103 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    constexpr bool W128 = TM == 1 && TN == 4;      // wave tile 32 x 128: every A fragment is split ONCE per workgroup, 44 VALU operations per 24 MFMAs
+    if constexpr (W128) {
+        // The k-loop of the 32 x 128 wave tile (round 6).  With the generic loop's two complete sets of weight fragments (96 registers
+        // for four column blocks) the tile spills; here planes 1 and 2 of the weight pieces are SINGLE-buffered and reloaded as soon
+        // as their products are issued, plane 0 - the last products of a half-tile - keeps two sets.  The six piece products run in
+        // plane order: a0 b2 | a1 b1, a0 b1 | a2 b0, a1 b0, a0 b0.  Issue order of the LDS reads inside a half-tile: A (2) and
+        // plane 0 (4) of the NEXT half-tile at its start, plane 2 (4) behind this one's plane-2 product, plane 1 (4) behind its
+        // plane-1 products; every wait below counts the reads issued after the ones it needs (LDS returns in order).
+        bf16x8 b12[4][2];           // [column block][0: plane 1, 1: plane 2]
+        bf16x8 b0[2][4];            // [set][column block]: plane 0
+        auto rd_a = [&](int stage, int s) {
+            const lds_char* a = lds0 + stage * A_STAGE;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(ra[0][0]) : "v"(a + aoff[s][0]));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(ra[0][1]) : "v"(a + aoff[s][1]));
+        };
+        auto rd_b0 = [&](int stage, int s, int set) {
+            const lds_char* b = lds0 + stage * B_STAGE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0[set][j]) : "v"(b + boff[s]), "n"(j * 32 * 64));
+        };
+        auto rd_b1 = [&](int stage, int s) {
+            const lds_char* b = lds0 + stage * B_STAGE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b12[j][0]) : "v"(b + boff[s]), "n"(B_PLANE + j * 32 * 64));
+        };
+        auto rd_b2 = [&](int stage, int s) {
+            const lds_char* b = lds0 + stage * B_STAGE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b12[j][1]) : "v"(b + boff[s]), "n"(2 * B_PLANE + j * 32 * 64));
+        };
+        auto mm = [&](const bf16x8& a, int j, const bf16x8& b) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0][j], 0, 0, 0); };
+        // one half-tile: pieces pa[cur], weight planes b12 / b0[cur]; NEXT: fragments of half-tile (stage_n, s_n) are fetched and split
+        auto half_w = [&](int cur, auto next_tag, int stage_n, int s_n) {
+            constexpr bool NEXT = decltype(next_tag)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (NEXT) { rd_a(stage_n, s_n); rd_b0(stage_n, s_n, cur ^ 1); }
+            if (NEXT) wait_lgkm<10>(); else wait_lgkm<4>();            // plane 2 of this half-tile (behind it: plane 1 [, A, plane 0 of the next])
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pin(b12[j][1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm(pa[cur][0][0], j, b12[j][1]);                     // a0 b2
+            __builtin_amdgcn_sched_barrier(0);
+            if (NEXT) rd_b2(stage_n, s_n);
+            if (NEXT) wait_lgkm<10>(); else wait_lgkm<0>();            // plane 1 (behind it: A, plane 0, plane 2 of the next)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pin(b12[j][0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm(pa[cur][0][1], j, b12[j][0]);                     // a1 b1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm(pa[cur][0][0], j, b12[j][0]);                     // a0 b1
+            __builtin_amdgcn_sched_barrier(0);
+            if (NEXT) {
+                rd_b1(stage_n, s_n);
+                wait_lgkm<12>();                                       // A of the next half-tile and this one's plane 0 (behind them: planes 0, 2, 1 of the next)
+                pin(ra[0][0]); pin(ra[0][1]);
+                split8(ra[0][0], ra[0][1], pa[cur ^ 1][0][0], pa[cur ^ 1][0][1], pa[cur ^ 1][0][2]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pin(b0[cur][j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm(pa[cur][0][2], j, b0[cur][j]);                    // a2 b0
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm(pa[cur][0][1], j, b0[cur][j]);                    // a1 b0
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm(pa[cur][0][0], j, b0[cur][j]);                    // a0 b0
+            if (NEXT) {
+#pragma unroll
+                for (int n = 0; n < 12; ++n) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);        // four VALU (44 in all)
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) pin(pa[cur ^ 1][0][pl]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (nk > 0) {
+            if (nk > 1) wait_vm<NPIECE>(); else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            rd_a(0, 0); rd_b0(0, 0, 0); rd_b2(0, 0); rd_b1(0, 0);
+            wait_lgkm<0>();
+            pin(ra[0][0]); pin(ra[0][1]);
+            split8(ra[0][0], ra[0][1], pa[0][0][0], pa[0][0][1], pa[0][0][2]);
+            int issued = nk > 1 ? 2 : 1;
+            for (int kt = 0; kt + 1 < nk; ++kt) {
+                const int stage = kt & 1;
+                half_w(0, std::true_type{}, stage, 1);
+                wait_lgkm<0>();         // (no stall expected: the last reads were issued in front of twelve MFMAs) every fragment of tile kt is in registers
+                wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+                if (issued < nk) { request_tile(); ++issued; }        // -> the stage of tile kt
+                half_w(1, std::true_type{}, stage ^ 1, 0);
+            }
+            half_w(0, std::true_type{}, (nk - 1) & 1, 1);
+            half_w(1, std::false_type{}, 0, 0);
+        }
+    } else
     if (nk > 0) {
         if (nk > 1) wait_vm<NPIECE>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
@@ -862,9 +960,12 @@ constexpr bool KS_STAGE_OUT_HOST = KS_STAGE_OUT != 0;      // the addend joins i
 enum { KS_128x128 = 0, KS_64x64 = 1, KS_128x64 = 2, KS_128x32 = 3, KS_NCFG = 4 };
 const int KS_BM[KS_NCFG] = {128, 64, 128, 128};
 const int KS_BN[KS_NCFG] = {128, 64, 64, 32};
-const int KS_WM[KS_NCFG] = {2, 2, 4, 4};  // wave rows of a tile = statistics records per tile row
-// (Built, measured slower and deleted - numbers in profiles/r05_experiments.txt items 3, 12 and r05_tile_classes_after_diet.txt: a 128x128
-// tile of four 32x128 waves, a 64x128 tile, the 128x64 tile as two wave groups halving the reduction, the 64x64 tile as two waves.)
+const int KS_WM[KS_NCFG] = {4, 2, 4, 4};  // wave rows of a tile
+// (Built, measured slower and deleted - numbers in profiles/r05_experiments.txt items 3, 12 and r05_tile_classes_after_diet.txt: a 64x128
+// tile, the 128x64 tile as two wave groups halving the reduction, the 64x64 tile as two waves.  The 128x128 tile of four 32x128 waves
+// lost in round 3 WITH the generic k-loop (two complete sets of weight fragments: spills); with a k-loop of its own - planes 1 / 2 of
+// the weight pieces single-buffered - it replaced the four 64x64 waves in round 6: 220.6 against 216.2 TFLOP/s alone on the 65536-row
+// 3x3, half the split operations, profiles/r06_experiments.txt item 18.)
 // A/B aids for the tile-class policy inside the step (the thresholds below were tuned on kernels timed ALONE; in the step the VALU
 // pipe is the contended resource, and classes with fewer split operations per MFMA may win there although they lose alone)
 static int ks_env(const char* name, int dflt) {
@@ -873,7 +974,7 @@ static int ks_env(const char* name, int dflt) {
 }
 
 // Measured on the step's shapes (tools/convs_bench.py, profiles/r03_convs_tile_classes.txt):
-//  * 128x128 (4 waves of 64x64) wins wherever it fills the chip twice over (>= 512 tiles; >= 1024 when the reduction is short):
+//  * 128x128 (4 waves of 32x128; 64x64 waves until round 6) wins wherever it fills the chip twice over (>= 512 tiles; >= 1024 when the reduction is short):
 //    197-200 TF/s on the 65536-row and 17424-row 3x3 convs;
 //  * 128x64 (4 waves of 32x64: every A fragment is split by ONE wave) for long reductions on the 8712 / 17424-row maps whose
 //    128x128 tiling would leave CUs idle (135-185 TF/s against 95-168);
@@ -987,7 +1088,7 @@ int launch_ks(const KsParams& p0, hipStream_t st) {
 template <int MODE>
 int dispatch_ks(const KsParams& p, int tuning, hipStream_t st) {
     switch (ks_choose(p.M, p.Ng, p.Ktot, tuning)) {
-        case KS_128x128: return launch_ks<MODE, 2, 2, 2, 2>(p, st);       // 4 waves of 64x64
+        case KS_128x128: return launch_ks<MODE, 4, 1, 1, 4>(p, st);       // 4 waves of 32x128: every A fragment split by ONE wave, 1.83 split operations per MFMA (round 6)
         case KS_64x64: return launch_ks<MODE, 2, 2, 1, 1>(p, st);
         case KS_128x64: return launch_ks<MODE, 4, 1, 1, 2>(p, st);         // 4 waves of 32x64: every A fragment split by one wave only
         case KS_128x32: return launch_ks<MODE, 4, 1, 1, 1>(p, st);        // 4 waves of 32x32: few-channel heads
@@ -999,7 +1100,7 @@ int dispatch_ks(const KsParams& p, int tuning, hipStream_t st) {
 template <int CIN>
 int dispatch_ks_front(const KsParams& p, int tuning, hipStream_t st) {
     switch (ks_choose(p.M, p.Ng, p.Ktot, tuning)) {
-        case KS_128x128: return launch_ks<MODE_FWD, 2, 2, 2, 2, CIN>(p, st);
+        case KS_128x128: return launch_ks<MODE_FWD, 4, 1, 1, 4, CIN>(p, st);
         case KS_64x64: return launch_ks<MODE_FWD, 2, 2, 1, 1, CIN>(p, st);
         default: return SSCG_ERR_UNSUPPORTED;
     }
