@@ -161,8 +161,13 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
     const int wave_id = tid >> 6;
 
     // ---- copy side
+    // OWN_A (the 32x128-wave class): a wave copies exactly the 32 A rows its own MFMAs consume (pass ps = rows 32 w + 8 ps .. + 7), so the A
+    // side of the pipeline needs no workgroup barrier and its copies go out as soon as the wave itself has read the stage (below)
+    constexpr bool OWN_A = TM == 1 && TN == 4 && WM == 4 && WN == 1 && CIN == 0;
     const int r0 = tid >> 3;                                   // A row inside a pass
     const int kqa = (tid & 7) ^ ((r0 >> 1) & 7);               // 16-byte k slot this lane fetches (lands at LDS slot tid & 7 of row r0)
+    auto a_row = [&](int ps) -> int { return OWN_A ? (tid >> 6) * 32 + ps * 8 + ((tid & 63) >> 3) : r0 + ps * RPA; };
+    auto a_kq = [&](int ps) -> int { return OWN_A ? ((tid & 7) ^ ((ps * 4 + ((tid & 63) >> 4)) & 7)) : kqa; };
     const int rb0 = (tid >> 2) % RPB;                          // B row inside a pass
     const int kqb = (tid & 3) ^ ((rb0 >> 2) & 3);
 
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
     bool aok[PA];
 #pragma unroll
     for (int ps = 0; ps < PA; ++ps) {
-        const int m = m0 + r0 + ps * RPA;
+        const int m = m0 + a_row(ps);
         aok[ps] = m < p.M;
         const int mm = aok[ps] ? m : 0;
         const int img = fd_div(mm, p.div_hw);
@@ -271,9 +276,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
             int pix;
             const bool ok = locate(ps, tdy, tdx, pix);
 #if KS_BUFLD
-            aptr[ps] = ok ? arow[ps] + ((unsigned)pix * (unsigned)p.Cs + kqa * 4) * 4u : 0x80000000u;      // out of range: the copy delivers zeros
+            aptr[ps] = ok ? arow[ps] + ((unsigned)pix * (unsigned)p.Cs + a_kq(ps) * 4) * 4u : 0x80000000u;      // out of range: the copy delivers zeros
 #else
-            aptr[ps] = ok ? arow[ps] + (size_t)pix * p.Cs + kqa * 4 : zero + kqa * 4;
+            aptr[ps] = ok ? arow[ps] + (size_t)pix * p.Cs + a_kq(ps) * 4 : zero + a_kq(ps) * 4;
 #endif
         }
     };
@@ -332,11 +337,57 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
         ++f_chunk;
         f_k += BKS;
     };
+    // OWN_A: the two operands are requested separately - A by the tap walker above (request_a), B by a walker of its own (request_b)
+    int b_chunk = f_chunk, b_ky = f_ky, b_kx = f_kx, b_stage = 0;
+    int b_k = ((p.wt_ky0 + b_ky * p.wt_step) * p.wt_S + p.wt_kx0 + b_kx * p.wt_step) * p.Cs + b_chunk * BKS;
+    const int lds_own_a = __builtin_amdgcn_readfirstlane(wave_id * 4096);
+    auto request_a = [&]() {
+        if (f_chunk == f_nchunk) {
+            f_chunk = 0;
+            ++f_kx;
+            if (f_kx == p.S) { f_kx = 0; ++f_ky; }
+            if (f_ky >= p.R) { f_ky = 0; f_kx = 0; }
+            set_tap();
+        }
+        const int so_a = __builtin_amdgcn_readfirstlane(f_chunk * (BKS * 4));
+#pragma unroll
+        for (int q = 0; q < PA; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds0 + dma_stage * A_STAGE + lds_own_a + q * 1024),
+                                                     16, (int)aptr[q], so_a, 0, 0);
+        dma_stage ^= 1;
+        ++f_chunk;
+    };
+    auto request_b = [&]() {
+        if (b_chunk == f_nchunk) {
+            b_chunk = 0;
+            ++b_kx;
+            if (b_kx == p.S) { b_kx = 0; ++b_ky; }
+            if (b_ky >= p.R) { b_ky = 0; b_kx = 0; }
+            b_k = ((p.wt_ky0 + b_ky * p.wt_step) * p.wt_S + p.wt_kx0 + b_kx * p.wt_step) * p.Cs;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const int so_b = __builtin_amdgcn_readfirstlane((int)((pl * p.wplane + b_k) * 2));
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(lds0 + NSTAGE * A_STAGE + b_stage * B_STAGE +
+                                                                                                        pl * B_PLANE + lds_wave_b + hb * (RPB * 64)),
+                                                         16, (int)brow[hb], so_b, 0, 0);
+        }
+        b_stage ^= 1;
+        ++b_chunk;
+        b_k += BKS;
+    };
     // the first two k-tiles are requested HERE, before the matrix-core side is set up: the ~150 instructions of that set-up (fragment
     // addresses, 32-64 accumulator registers to clear) run under the copies' latency instead of in front of it
     const int nk = kt1 - kt0;
-    if (nk > 0) request_tile();               // tile 0 -> stage 0
-    if (nk > 1) request_tile();               // tile 1 -> stage 1
+    if constexpr (OWN_A) {
+        if (nk > 0) { request_a(); request_b(); }
+        if (nk > 1) { request_a(); request_b(); }
+    } else {
+        if (nk > 0) request_tile();               // tile 0 -> stage 0
+        if (nk > 1) request_tile();               // tile 1 -> stage 1
+    }
     if constexpr (FRONT) {
         // (host: Ktot == 64, never split - nk == 2, both A stages are filled here, under the latency of the weight copies.)
         // Waves 2 s and 2 s + 1 form k-tile s: 128-row tiles - a thread takes all 32 channels of one of the 128 rows; 64-row tiles - 16
@@ -533,7 +584,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
         };
         auto mm = [&](const bf16x8& a, int j, const bf16x8& b) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0][j], 0, 0, 0); };
         // one half-tile: pieces pa[cur], weight planes b12 / b0[cur]; NEXT: fragments of half-tile (stage_n, s_n) are fetched and split
-        auto half_w = [&](int cur, auto next_tag, int stage_n, int s_n) {
+        auto half_w = [&](int cur, auto next_tag, int stage_n, int s_n, bool issue_a = false) {
             constexpr bool NEXT = decltype(next_tag)::value;
             __builtin_amdgcn_sched_barrier(0);
             if (NEXT) { rd_a(stage_n, s_n); rd_b0(stage_n, s_n, cur ^ 1); }
@@ -556,6 +607,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
                 rd_b1(stage_n, s_n);
                 wait_lgkm<12>();                                       // A of the next half-tile and this one's plane 0 (behind them: planes 0, 2, 1 of the next)
                 pin(ra[0][0]); pin(ra[0][1]);
+                // OWN_A: this wave has now read BOTH halves of its A rows of the current k-tile - the rows of the tile after next go
+                // into the same stage at once (1.5 k-tiles ahead of their first read; no other wave touches these rows)
+                if (OWN_A && issue_a) request_a();
                 split8(ra[0][0], ra[0][1], pa[cur ^ 1][0][0], pa[cur ^ 1][0][1], pa[cur ^ 1][0][2]);
             }
 #pragma unroll
@@ -587,11 +641,16 @@ __global__ __launch_bounds__(WM * WN * 64, ((KS_LB4 && TM * TN == 1) ? 4 : 2)) v
             int issued = nk > 1 ? 2 : 1;
             for (int kt = 0; kt + 1 < nk; ++kt) {
                 const int stage = kt & 1;
-                half_w(0, std::true_type{}, stage, 1);
+                const bool more = issued < nk;                          // tile kt + 2 exists
+                half_w(0, std::true_type{}, stage, 1, more);
                 wait_lgkm<0>();         // (no stall expected: the last reads were issued in front of twelve MFMAs) every fragment of tile kt is in registers
-                wait_vm<0>();
+                // tile kt + 1 has landed (OWN_A: behind it only this wave's A rows of tile kt + 2 may still be in flight)
+                if (OWN_A && more) wait_vm<PA>(); else wait_vm<0>();
                 __builtin_amdgcn_s_barrier();
-                if (issued < nk) { request_tile(); ++issued; }        // -> the stage of tile kt
+                if (more) {                                             // -> the stage of tile kt
+                    if constexpr (OWN_A) request_b(); else request_tile();
+                    ++issued;
+                }
                 half_w(1, std::true_type{}, stage ^ 1, 0);
             }
             half_w(0, std::true_type{}, (nk - 1) & 1, 1);
