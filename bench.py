@@ -100,7 +100,7 @@ def main():
     # SSCG_FORCE_DP=1 exercises the RCCL code path (init, broadcast, all-reduce) on a single rank
     dp = par.DataParallel() if (world > 1 or os.environ.get("SSCG_FORCE_DP")) else None
     rank = dp.rank if dp else 0
-    local = dp.local_rank if dp else 0
+    local = dp.device_index if dp else 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # before anything is built: per-rank batch >= 2, one physical device per rank, LOCAL_RANK = the device in use

@@ -73,7 +73,7 @@ def main(argv=None):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         par = importlib.import_module(PKG + ".parallel")
         dp = par.DataParallel()
-        args.gpu_ids = [dp.local_rank]
+        args.gpu_ids = [dp.device_index]
     if args.training:
         loaders = None
         root = DATA_ROOTS[args.dataset]

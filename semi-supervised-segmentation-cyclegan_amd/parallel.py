@@ -22,12 +22,17 @@ class DataParallel:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if os.environ.get("SSCG_DP_SHARED_GPU"):      # test rig: all ranks on GPU 0 (with SSCG_DP_BACKEND=gloo) - exercises the
             self.local_rank = 0                       # multi-rank control flow of the step / bench on a 1-GPU box
+        # the device this rank computes on: LOCAL_RANK among the visible devices - or device 0 where a launcher has narrowed every
+        # rank's visibility to its own GPU (HIP_VISIBLE_DEVICES per process: one visible device, LOCAL_RANK still counts up)
+        self.device_index = self.local_rank
+        if torch.cuda.is_available() and self.local_rank >= torch.cuda.device_count():
+            self.device_index = 0
         if not dist.is_initialized():
             backend = backend or os.environ.get("SSCG_DP_BACKEND")
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
+                torch.cuda.set_device(self.device_index)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             try:
@@ -39,7 +44,7 @@ class DataParallel:
                                        type(e).__name__, e)) from e
         # the rank's host thread issues ~5 000 launches per step: keep it (and everything it spawns) on the cores of the GPU's own
         # NUMA node - eight ranks on two sockets otherwise share one scheduler domain and cross the socket link for every doorbell
-        self.affinity = pin_to_device_node(self.local_rank) if torch.cuda.is_available() else None
+        self.affinity = pin_to_device_node(self.device_index) if torch.cuda.is_available() else None
         if torch.cuda.is_available():
             # side lanes made before the group existed are low-priority streams: beside RCCL's stream those cost +30 % (functional.side_priority)
             from . import functional as F
@@ -248,7 +253,7 @@ def preflight(dp, batch_per_rank, shared_gpu_ok=False):
                          "batch dimension away at B = 1; BASELINE's DDP configurations are 64 / 8 = 8 and 32 / 8 = 4)" % batch_per_rank)
     if dp is None:
         return None
-    me = {"rank": dp.rank, "device": device_identity(), "local_rank": dp.local_rank,
+    me = {"rank": dp.rank, "device": device_identity(), "local_rank": getattr(dp, "device_index", dp.local_rank),
           "current": torch.cuda.current_device() if torch.cuda.is_available() else -1, "affinity": getattr(dp, "affinity", None)}
     rows = [None] * dist.get_world_size()
     if dist.get_world_size() > 1:
@@ -262,7 +267,7 @@ def preflight(dp, batch_per_rank, shared_gpu_ok=False):
                          "rig)" % (len(rows), distinct, [r["device"] for r in rows], len(rows)))
     for r in rows:
         if r["current"] >= 0 and r["current"] != r["local_rank"]:
-            raise SystemExit("preflight: rank %d computes on device %d but LOCAL_RANK says %d" % (r["rank"], r["current"], r["local_rank"]))
+            raise SystemExit("preflight: rank %d computes on device %d but its LOCAL_RANK / visibility says %d" % (r["rank"], r["current"], r["local_rank"]))
     return rows
 
 

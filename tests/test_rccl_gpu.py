@@ -21,7 +21,7 @@ par = importlib.import_module(%(pkg)r + ".parallel")
 import torch.distributed as dist
 dp = par.DataParallel(backend="nccl")
 assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
-dev = torch.device("cuda", dp.local_rank)
+dev = torch.device("cuda", dp.device_index)
 n = 85_700_000
 arena = torch.randn(n, device=dev)
 ref = arena.clone()
