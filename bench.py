@@ -384,12 +384,24 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)
 
-    if rank == 0:
-        print(json.dumps(out))
+    # The JSON line is the LAST line this job writes to stdout.  RCCL prints a version banner through C stdio when its first
+    # communicator comes up; on a pipe that text sits in libc's buffer until exit() - behind anything Python printed (measured:
+    # gpurun_out/r06x_fdp.out had the banner after the line).  Every rank empties both buffers, the ranks meet, rank 0 prints.
+    # Rank 0 tears its process group down first, empties both buffers and prints; the other ranks empty theirs BEFORE the last barrier
+    # and write nothing to stdout after it.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
     if dp:
         import torch.distributed as dist
+        if rank != 0:
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
         dist.barrier()
         dist.destroy_process_group()
+        libc.fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def spawn_ranks(n):

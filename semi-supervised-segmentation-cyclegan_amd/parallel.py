@@ -305,16 +305,16 @@ def broadcast_flat(flat, src=0, chunk=CHUNK_ELEMS):
 
 
 def device_identity(index=None):
-    """A string that names the physical GPU this rank computes on: the device UUID where torch exposes it, else PCI domain:bus:device
+    """A string that names the physical GPU this rank computes on: the device UUID where torch exposes it, and PCI domain:bus:device
     (two ranks on one GPU report the same string; a CPU-only rank reports "cpu")."""
     if not torch.cuda.is_available():
         return "cpu"
     index = torch.cuda.current_device() if index is None else index
     p = torch.cuda.get_device_properties(index)
+    pci = "pci %04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", index), getattr(p, "pci_device_id", 0))
     uuid = getattr(p, "uuid", None)
-    if uuid is not None:
-        return str(uuid)
-    return "pci %04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", index), getattr(p, "pci_device_id", 0))
+    # (both: a runtime that reports one placeholder UUID for every device must not make eight GPUs look like one to the preflight)
+    return pci if uuid is None else "%s %s" % (uuid, pci)
 
 
 def collective_version():
