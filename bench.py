@@ -384,21 +384,26 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)
 
-    # The JSON line is the LAST line this job writes to stdout.  RCCL prints a version banner through C stdio when its first
-    # communicator comes up; on a pipe that text sits in libc's buffer until exit() - behind anything Python printed (measured:
-    # gpurun_out/r06x_fdp.out had the banner after the line).  Every rank empties both buffers, the ranks meet, rank 0 prints.
-    # Rank 0 tears its process group down first, empties both buffers and prints; the other ranks empty theirs BEFORE the last barrier
-    # and write nothing to stdout after it.
+    emit_line(out, rank, bool(dp))
+
+
+def emit_line(out, rank, in_group):
+    """The JSON line is the LAST line this job writes to stdout.  RCCL prints a version banner through C stdio when its first
+    communicator comes up; on a pipe that text sits in libc's buffer until exit() - behind anything Python printed (measured:
+    the banner followed the line, profiles/r06_experiments.txt item 23).  Every rank empties both buffers; the other ranks do so
+    BEFORE the last barrier and point fd 1 at /dev/null for whatever their teardown may still print; rank 0 tears its process
+    group down, empties the buffers once more and prints.  (tests/test_host_logic.py runs this over gloo with a banner in libc's buffer.)"""
     import ctypes
     libc = ctypes.CDLL(None)
     sys.stdout.flush()
     libc.fflush(None)
-    if dp:
+    if in_group:
         import torch.distributed as dist
         if rank != 0:
             os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
         dist.barrier()
         dist.destroy_process_group()
+        sys.stdout.flush()
         libc.fflush(None)
     if rank == 0:
         print(json.dumps(out), flush=True)

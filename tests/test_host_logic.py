@@ -276,6 +276,33 @@ def test_bench_spawns_its_own_ranks_when_no_launcher_is_present(monkeypatch):
         assert seen["env"]["SSCG_DP_SHARED_GPU"] == "1" and seen["env"]["SSCG_DP_BACKEND"] == "gloo"
 
 
+def test_bench_line_is_the_last_line_on_stdout(tmp_path):
+    """Under a process group the collective library prints through C stdio (RCCL's version banner): on a pipe that text left libc's
+    buffer at exit(), BEHIND the JSON line (profiles/r06_experiments.txt item 23).  Two gloo ranks share one stdout pipe here, each
+    with a banner in libc's buffer: the line is the last thing rank 0 or anyone else writes."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "stdout.txt"
+    procs = []
+    with open(out, "wb") as f:
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "aids", "emit_line_ranks.py")], stdout=f, env=env))
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    lines = out.read_text().strip().splitlines()
+    assert json.loads(lines[-1]) == {"metric": "m", "value": 1.0, "rank_count": 2}, lines
+    assert sum(ln.startswith("{") for ln in lines) == 1
+    # what was buffered BEFORE the line came out before it - on both ranks; rank 0's own later text would follow (there is none in bench.py)
+    assert any(ln.startswith("BANNER of rank 0") for ln in lines[:-1]) and any(ln.startswith("BANNER of rank 1") for ln in lines[:-1])
+    assert not any(ln.startswith("LATE text of rank 1") for ln in lines)
+
+
 def test_pixel_discriminator_tail_is_recognised_and_lane_priority_follows_the_context(monkeypatch):
     """Host decisions of round 3 (no GPU): (1) `FusedSequential` hands the PixelDiscriminator's second conv -> norm -> LeakyReLU ->
     Conv2d(2 ndf, 1, 1x1) to the fused-tail node exactly when the library serves the width (a power of two in [16, 256]) and the norm
