@@ -317,7 +317,9 @@ def run_on_side_stream(device, tensors, fn, lane=0, defer=False):
     return r
 
 
-SIDE_BATCH = [int(os.environ.get("SSCG_SIDE_BATCH", "8"))]
+# (8 until the end of round 6; re-swept on the final kernels, profiles/r06_experiments.txt item 27: 4 / 8 / 16 alike, 32 -0.45 and
+# -0.8 ms per config-2 step on two boxes, 64 +0.4; config 3 indifferent)
+SIDE_BATCH = [int(os.environ.get("SSCG_SIDE_BATCH", "32"))]
 _SIDE_PENDING = {}      # (device, lane) -> [(fn, tensors, raw handle of the stream that produced the tensors)]
 _STREAM_BY_HANDLE = {}  # raw stream handle -> torch.cuda.Stream (built once per stream: the object costs ~6 us to make)
 
